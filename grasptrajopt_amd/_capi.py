@@ -1,0 +1,330 @@
+"""ctypes binding of the C ABI in include/gto_solver.h (libgto_hip.so).
+
+There is deliberately NO fallback: if the HIP library is missing or no GPU is present the calls
+raise.  (The CPU oracle under oracle/ is test infrastructure and is never imported from here.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from .robot_desc import RobotDesc
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libgto_hip.so")
+
+GTO_MAX_FRAMES, GTO_MAX_LINKS, GTO_MAX_OPT, GTO_MAX_DOF = 32, 32, 8, 32
+GRAD_CENTRAL_DIFF, GRAD_ZERO = 0, 1
+STATUS_CONVERGED, STATUS_MAX_ITER, STATUS_NUMERICAL = 0, 1, 2
+
+_pd = C.POINTER(C.c_double)
+_pi = C.POINTER(C.c_int32)
+_pf = C.POINTER(C.c_float)
+
+
+class CRobotDesc(C.Structure):
+    _fields_ = [
+        ("n_frames", C.c_int32), ("parent", _pi), ("joint_type", _pi), ("q_index", _pi),
+        ("origin_xyz", _pd), ("origin_rpy", _pd), ("axis", _pd),
+        ("ndof", C.c_int32), ("n_opt", C.c_int32), ("opt_index", _pi), ("lower", _pd), ("upper", _pd),
+        ("n_links", C.c_int32), ("link_frame", _pi), ("visual_xyz", _pd), ("visual_rpy", _pd),
+        ("n_points", C.c_int32), ("points", _pd), ("point_link", _pi),
+        ("frame_ee", C.c_int32), ("frame_gripper", C.c_int32),
+        ("n_gripper_points", C.c_int32), ("gripper_points", _pd),
+    ]
+
+
+class CSolverOpts(C.Structure):
+    _fields_ = [
+        ("T", C.c_int32), ("Tmax", C.c_double), ("standoff_offset", C.c_int32),
+        ("w_obstacle", C.c_double), ("w_vel", C.c_double), ("max_iter", C.c_int32),
+        ("tol_step", C.c_double), ("tol_rel_f", C.c_double), ("lambda0", C.c_double),
+        ("grad_mode", C.c_int32),
+    ]
+
+    def copy(self) -> "CSolverOpts":
+        o = CSolverOpts()
+        C.memmove(C.byref(o), C.byref(self), C.sizeof(CSolverOpts))
+        return o
+
+
+def _f64(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _i32(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _p(a: Optional[np.ndarray], typ):
+    return None if a is None else a.ctypes.data_as(typ)
+
+
+def pack_robot_desc(desc: RobotDesc, link_ee: str, link_gripper: str,
+                    n_gripper_points: Optional[int] = None) -> Tuple[CRobotDesc, list]:
+    """Build the C struct; the returned list keeps the backing arrays alive."""
+    keep: List[np.ndarray] = []
+
+    def k(a):
+        keep.append(a)
+        return a
+
+    gp = desc.link_points(link_gripper)  # gto/gto_planner.py:37
+    if n_gripper_points is not None:
+        gp = gp[:n_gripper_points]
+    opt = desc.opt_index
+    c = CRobotDesc()
+    c.n_frames = desc.n_frames
+    c.parent = _p(k(_i32(desc.parent)), _pi)
+    c.joint_type = _p(k(_i32(desc.joint_type)), _pi)
+    c.q_index = _p(k(_i32(desc.q_index)), _pi)
+    c.origin_xyz = _p(k(_f64(desc.origin_xyz)), _pd)
+    c.origin_rpy = _p(k(_f64(desc.origin_rpy)), _pd)
+    c.axis = _p(k(_f64(desc.axis)), _pd)
+    c.ndof = desc.ndof
+    c.n_opt = desc.n_opt
+    c.opt_index = _p(k(_i32(opt)), _pi)
+    c.lower = _p(k(_f64(desc.lower[opt])), _pd)
+    c.upper = _p(k(_f64(desc.upper[opt])), _pd)
+    c.n_links = desc.n_links
+    c.link_frame = _p(k(_i32(desc.link_frame)), _pi)
+    c.visual_xyz = _p(k(_f64(desc.visual_xyz)), _pd)
+    c.visual_rpy = _p(k(_f64(desc.visual_rpy)), _pd)
+    c.n_points = desc.n_points
+    c.points = _p(k(_f64(desc.points)), _pd)
+    c.point_link = _p(k(_i32(desc.point_link)), _pi)
+    c.frame_ee = desc.frame_index(link_ee)
+    c.frame_gripper = desc.frame_index(link_gripper)
+    c.n_gripper_points = int(gp.shape[0])
+    c.gripper_points = _p(k(_f64(gp)), _pd)
+    return c, keep
+
+
+_lib = None
+
+
+def load_library(path: Optional[str] = None):
+    """Load libgto_hip.so (built by __graft_entry__.build()). Raises if it is not there."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise RuntimeError(
+            f"HIP library not found at {p}: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback for the GTO solve path.")
+    lib = C.CDLL(p)
+    H = C.c_void_p
+    lib.gto_default_opts.argtypes = [C.POINTER(CSolverOpts)]
+    lib.gto_default_opts.restype = None
+    lib.gto_version.restype = C.c_int32
+    lib.gto_create.argtypes = [C.POINTER(CRobotDesc), C.POINTER(CSolverOpts), C.c_int, C.POINTER(H)]
+    lib.gto_destroy.argtypes = [H]
+    lib.gto_destroy.restype = None
+    lib.gto_last_error.argtypes = [H]
+    lib.gto_last_error.restype = C.c_char_p
+    lib.gto_set_opts.argtypes = [H, C.POINTER(CSolverOpts)]
+    lib.gto_set_scene.argtypes = [H, C.c_int32, _pf, _pf, _pi, _pd, C.c_double]
+    lib.gto_drop_scene.argtypes = [H, C.c_int32]
+    solve_args = [H, C.c_int32, C.c_int32] + [C.c_void_p] * 12
+    lib.gto_solve_batch.argtypes = solve_args
+    lib.gto_solve_batch_device.argtypes = solve_args + [C.c_void_p]
+    lib.gto_last_kernel_time.argtypes = [H, _pd, _pi]
+    lib.gto_set_profiling.argtypes = [H, C.c_int32]
+    lib.gto_eval_fk.argtypes = [H, C.c_int32, _pd, _pd]
+    lib.gto_eval_points.argtypes = [H, C.c_int32, C.c_int32, _pd, _pd, C.c_int32, _pd, _pi, _pd, _pd]
+    lib.gto_eval_objective.argtypes = [H, C.c_int32, C.c_int32, _pi, _pd, _pi, _pd, _pd, _pd, _pd, _pd, _pd, _pi]
+    lib.gto_eval_obstacle_normal_eq.argtypes = [H, C.c_int32, _pi, _pd, _pd, _pd, _pd, _pd]
+    lib.gto_plan_cost.argtypes = [H, C.c_int32, C.c_int32, _pd, _pd, _pd, _pd]
+    for fn in ("gto_create", "gto_set_opts", "gto_set_scene", "gto_drop_scene", "gto_solve_batch",
+               "gto_solve_batch_device", "gto_last_kernel_time", "gto_set_profiling", "gto_eval_fk",
+               "gto_eval_points", "gto_eval_objective", "gto_eval_obstacle_normal_eq", "gto_plan_cost"):
+        getattr(lib, fn).restype = C.c_int
+    if path is None:
+        _lib = lib
+    return lib
+
+
+EXPORTED_SYMBOLS = (
+    "gto_default_opts", "gto_version", "gto_create", "gto_destroy", "gto_last_error", "gto_set_opts",
+    "gto_set_scene", "gto_drop_scene", "gto_solve_batch", "gto_solve_batch_device",
+    "gto_last_kernel_time", "gto_set_profiling", "gto_eval_fk", "gto_eval_points",
+    "gto_eval_objective", "gto_eval_obstacle_normal_eq", "gto_plan_cost",
+)
+
+
+def default_opts() -> CSolverOpts:
+    o = CSolverOpts()
+    load_library().gto_default_opts(C.byref(o))
+    return o
+
+
+class GTOError(RuntimeError):
+    pass
+
+
+class SolverHandle:
+    """Owns one gto_handle (one HIP device, one stream)."""
+
+    def __init__(self, desc: RobotDesc, link_ee: str, link_gripper: str,
+                 opts: Optional[CSolverOpts] = None, device: int = -1,
+                 n_gripper_points: Optional[int] = None):
+        self.lib = load_library()
+        self.desc = desc
+        self.opts = opts.copy() if opts is not None else default_opts()
+        self._cdesc, self._keep = pack_robot_desc(desc, link_ee, link_gripper, n_gripper_points)
+        h = C.c_void_p()
+        rc = self.lib.gto_create(C.byref(self._cdesc), C.byref(self.opts), device, C.byref(h))
+        if rc != 0:
+            msg = self.lib.gto_last_error(None)
+            raise GTOError(f"gto_create failed ({rc}): {msg.decode() if msg else ''}")
+        self._h = h
+        self.scenes = {}
+
+    # -------------------------------------------------------------- helpers
+    def _check(self, rc: int, what: str):
+        if rc != 0:
+            msg = self.lib.gto_last_error(self._h)
+            raise GTOError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.gto_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def T(self) -> int:
+        return int(self.opts.T)
+
+    def set_opts(self, **kw):
+        for k, v in kw.items():
+            if not hasattr(self.opts, k):
+                raise AttributeError(k)
+            setattr(self.opts, k, v)
+        self._check(self.lib.gto_set_opts(self._h, C.byref(self.opts)), "gto_set_opts")
+
+    def set_scene(self, scene_id: int, c_all, c_obs, shape: Sequence[int], origin, res: float):
+        ca = np.ascontiguousarray(c_all, dtype=np.float32).reshape(-1)
+        co = None if c_obs is None else np.ascontiguousarray(c_obs, dtype=np.float32).reshape(-1)
+        shp = _i32(list(shape))
+        n = int(shp[0]) * int(shp[1]) * int(shp[2])
+        if ca.size != n or (co is not None and co.size != n):
+            raise ValueError(f"field size {ca.size} does not match shape {tuple(shp)}")
+        org = _f64(np.asarray(origin).reshape(3))
+        self._check(self.lib.gto_set_scene(self._h, scene_id, _p(ca, _pf), _p(co, _pf), _p(shp, _pi),
+                                           _p(org, _pd), float(res)), "gto_set_scene")
+        self.scenes[scene_id] = (tuple(int(s) for s in shp), org.copy(), float(res))
+
+    def drop_scene(self, scene_id: int):
+        self._check(self.lib.gto_drop_scene(self._h, scene_id), "gto_drop_scene")
+        self.scenes.pop(scene_id, None)
+
+    # -------------------------------------------------------------- solve
+    def solve_batch(self, scene_id, qc, goals, n_goals, standoff, base_pos, Q0):
+        d, T = self.desc, self.T
+        qc = _f64(qc).reshape(-1, d.ndof)
+        B = qc.shape[0]
+        goals = _f64(goals).reshape(B, -1, 16)
+        n_max = goals.shape[1]
+        n_goals = _i32(np.broadcast_to(np.asarray(n_goals), (B,)))
+        scene_id = _i32(np.broadcast_to(np.asarray(scene_id), (B,)))
+        so = None if standoff is None else _f64(np.broadcast_to(_f64(standoff).reshape(-1, 16), (B, 16)))
+        base = _f64(np.broadcast_to(_f64(base_pos).reshape(-1, 3), (B, 3)))
+        Q0 = _f64(Q0).reshape(B, d.ndof, T)
+        Q = np.empty((B, d.ndof, T))
+        dQ = np.empty((B, d.ndof, T - 1))
+        cost = np.empty(B)
+        iters = np.empty(B, dtype=np.int32)
+        status = np.empty(B, dtype=np.int32)
+        vp = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
+        rc = self.lib.gto_solve_batch(self._h, B, n_max, vp(scene_id), vp(qc), vp(goals), vp(n_goals),
+                                      vp(so), vp(base), vp(Q0), vp(Q), vp(dQ), vp(cost), vp(iters), vp(status))
+        self._check(rc, "gto_solve_batch")
+        return Q, dQ, cost, iters, status
+
+    def solve_batch_device(self, B, n_max, scene_id, qc, goals, n_goals, standoff, base_pos, Q0,
+                           Q_out, dQ_out, cost_out, iters_out, status_out, stream=None):
+        """All arguments are device pointers (ints, e.g. torch.Tensor.data_ptr()) or None."""
+        vp = lambda a: None if a is None else C.c_void_p(int(a))
+        rc = self.lib.gto_solve_batch_device(self._h, B, n_max, vp(scene_id), vp(qc), vp(goals), vp(n_goals),
+                                             vp(standoff), vp(base_pos), vp(Q0), vp(Q_out), vp(dQ_out),
+                                             vp(cost_out), vp(iters_out), vp(status_out), vp(stream))
+        self._check(rc, "gto_solve_batch_device")
+
+    def set_profiling(self, enabled: bool):
+        self._check(self.lib.gto_set_profiling(self._h, int(enabled)), "gto_set_profiling")
+
+    def last_kernel_time(self):
+        ms = C.c_double()
+        n = C.c_int32()
+        self._check(self.lib.gto_last_kernel_time(self._h, C.byref(ms), C.byref(n)), "gto_last_kernel_time")
+        return ms.value, n.value
+
+    # -------------------------------------------------------------- evaluation entry points
+    def eval_fk(self, q):
+        q = _f64(q).reshape(-1, self.desc.ndof)
+        out = np.empty((q.shape[0], self.desc.n_frames, 4, 4))
+        self._check(self.lib.gto_eval_fk(self._h, q.shape[0], _p(q, _pd), _p(out, _pd)), "gto_eval_fk")
+        return out
+
+    def eval_points(self, scene_id, q, base_pos, use_obs=False, want_field=True):
+        q = _f64(q).reshape(-1, self.desc.ndof)
+        nq, P = q.shape[0], self.desc.n_points
+        base = _f64(np.broadcast_to(_f64(base_pos).reshape(-1, 3), (nq, 3)))
+        xyz = np.empty((nq, P, 3))
+        off = np.empty((nq, P), dtype=np.int32) if want_field else None
+        val = np.empty((nq, P)) if want_field else None
+        grad = np.empty((nq, P, 3)) if want_field else None
+        self._check(self.lib.gto_eval_points(self._h, scene_id, nq, _p(q, _pd), _p(base, _pd), int(use_obs),
+                                             _p(xyz, _pd), _p(off, _pi), _p(val, _pd), _p(grad, _pd)),
+                    "gto_eval_points")
+        return xyz, off, val, grad
+
+    def eval_objective(self, scene_id, goals, n_goals, standoff, base_pos, Q):
+        d, T = self.desc, self.T
+        Q = _f64(Q).reshape(-1, d.ndof, T)
+        B = Q.shape[0]
+        goals = _f64(goals).reshape(B, -1, 16)
+        n_max = goals.shape[1]
+        n_goals = _i32(np.broadcast_to(np.asarray(n_goals), (B,)))
+        scene_id = _i32(np.broadcast_to(np.asarray(scene_id), (B,)))
+        so = None if standoff is None else _f64(np.broadcast_to(_f64(standoff).reshape(-1, 16), (B, 16)))
+        base = _f64(np.broadcast_to(_f64(base_pos).reshape(-1, 3), (B, 3)))
+        fg, fo, fv = np.empty(B), np.empty(B), np.empty(B)
+        am = np.empty(B, dtype=np.int32)
+        self._check(self.lib.gto_eval_objective(self._h, B, n_max, _p(scene_id, _pi), _p(goals, _pd),
+                                                _p(n_goals, _pi), _p(so, _pd), _p(base, _pd), _p(Q, _pd),
+                                                _p(fg, _pd), _p(fo, _pd), _p(fv, _pd), _p(am, _pi)),
+                    "gto_eval_objective")
+        return fg, fo, fv, am
+
+    def eval_obstacle_normal_eq(self, scene_id, base_pos, Q):
+        d, T, n = self.desc, self.T, self.desc.n_opt
+        Q = _f64(Q).reshape(-1, d.ndof, T)
+        B = Q.shape[0]
+        scene_id = _i32(np.broadcast_to(np.asarray(scene_id), (B,)))
+        base = _f64(np.broadcast_to(_f64(base_pos).reshape(-1, 3), (B, 3)))
+        JtJ, Jtr, ss = np.empty((B, T, n, n)), np.empty((B, T, n)), np.empty((B, T))
+        self._check(self.lib.gto_eval_obstacle_normal_eq(self._h, B, _p(scene_id, _pi), _p(base, _pd),
+                                                         _p(Q, _pd), _p(JtJ, _pd), _p(Jtr, _pd), _p(ss, _pd)),
+                    "gto_eval_obstacle_normal_eq")
+        return JtJ, Jtr, ss
+
+    def plan_cost(self, scene_id, plans, base_pos):
+        d, T = self.desc, self.T
+        plans = _f64(plans).reshape(-1, d.ndof, T)
+        n = plans.shape[0]
+        base = _f64(np.asarray(base_pos).reshape(3))
+        cost, dist = np.empty(n), np.empty(n)
+        self._check(self.lib.gto_plan_cost(self._h, scene_id, n, _p(plans, _pd), _p(base, _pd),
+                                           _p(cost, _pd), _p(dist, _pd)), "gto_plan_cost")
+        return cost, dist

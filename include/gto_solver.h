@@ -1,0 +1,215 @@
+/*
+ * gto_solver.h — C ABI of the MI355X-native GTO inner solver (libgto_hip.so).
+ *
+ * Drop-in boundary for the ONE hot path of IRVLUTD/GraspTrajOpt: the optimisation solve behind
+ *   GTOPlanner.plan_goalset()/plan()            reference gto/gto_planner.py:145-245
+ *   -> optas.CasADiSolver("ipopt").solve()      reference optas/solver.py:126-159, 388-400
+ * The reference has no native FFI (it is 100 % Python on top of CasADi/IPOPT); the entry points
+ * below are what a ctypes binding inside the reference's GTOPlanner would call instead of
+ * `self.solver.solve()` (see INTEGRATION.md for the stub).  Each function cites the reference
+ * code whose role it takes over.
+ *
+ * Conventions
+ *   - plain C, no torch / HIP types in any signature; `void* stream` is a hipStream_t passed as an
+ *     opaque pointer (NULL = the handle's own stream).
+ *   - host arrays are row-major (NumPy default) double / float / int32 unless stated.
+ *   - every function returns GTO_OK (0) or a negative error code; gto_last_error() gives text.
+ *   - a handle is bound to one HIP device and one stream; it is not thread-safe; host-pointer
+ *     calls are synchronous on return (the reference is synchronous single-threaded Python).
+ *   - the caller owns all host buffers; the library owns all device memory behind the handle.
+ */
+#ifndef GTO_SOLVER_H
+#define GTO_SOLVER_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GTO_OK 0
+#define GTO_ERR_INVALID_ARG (-1)
+#define GTO_ERR_HIP (-2)
+#define GTO_ERR_NO_DEVICE (-3)
+#define GTO_ERR_UNSUPPORTED (-4)
+#define GTO_ERR_NO_SCENE (-5)
+#define GTO_ERR_ALLOC (-6)
+
+/* compile-time capacity of the kernels */
+#define GTO_MAX_FRAMES 32 /* kinematic frames after pruning            */
+#define GTO_MAX_LINKS 32  /* collision links carrying surface points   */
+#define GTO_MAX_OPT 8     /* optimised joints (Panda/Fetch arm: 7)      */
+#define GTO_MAX_DOF 32    /* actuated joints (Panda 9, Fetch 15)        */
+
+/* joint types (optas/models.py:850-866) */
+#define GTO_JOINT_FIXED 0
+#define GTO_JOINT_REVOLUTE 1 /* revolute and continuous */
+#define GTO_JOINT_PRISMATIC 2
+
+/* obstacle-gradient source */
+#define GTO_GRAD_CENTRAL_DIFF 0 /* gto/sdf_callback.py:90-114 JacFun numerics (shipped default) */
+#define GTO_GRAD_ZERO 1         /* what CasADi AD sees through floor()+gather in the reference   */
+
+/* per-instance solver status (mirrors "return the iterate anyway", optas/solver.py:135) */
+#define GTO_STATUS_CONVERGED 0
+#define GTO_STATUS_MAX_ITER 1
+#define GTO_STATUS_NUMERICAL 2
+
+/*
+ * Robot description: the facts the reference pulls from the URDF through optas.RobotModel
+ * (optas/models.py:236-321, 826-868) and GTORobotModel (gto/gto_models.py:62-101).
+ * Frames are listed parents-before-children; frame i is reached from parent[i] by the fixed
+ * origin transform rt2tr(rpy2r(rpy), xyz) followed by the joint motion about/along `axis`.
+ */
+typedef struct gto_robot_desc {
+  int32_t n_frames;
+  const int32_t* parent;     /* [n_frames]    -1 for the root                                  */
+  const int32_t* joint_type; /* [n_frames]    GTO_JOINT_*                                      */
+  const int32_t* q_index;    /* [n_frames]    index into q (0..ndof-1) or -1 for fixed joints  */
+  const double* origin_xyz;  /* [n_frames*3]  joint origin (optas/models.py:642-651)           */
+  const double* origin_rpy;  /* [n_frames*3]                                                   */
+  const double* axis;        /* [n_frames*3]  NOT yet normalised (optas/models.py:653-659)     */
+  int32_t ndof;              /* actuated joints, URDF order (optas/models.py:349-354)          */
+  int32_t n_opt;             /* optimised joints (optas/models.py:366-386)                     */
+  const int32_t* opt_index;  /* [n_opt]       indexes into q                                   */
+  const double* lower;       /* [n_opt]       joint limits of the optimised joints             */
+  const double* upper;       /* [n_opt]                                                        */
+  int32_t n_links;           /* links with surface points (gto/gto_models.py:62-80)            */
+  const int32_t* link_frame; /* [n_links]     frame index of each collision link               */
+  const double* visual_xyz;  /* [n_links*3]   visual origin (gto/gto_models.py:95-100)         */
+  const double* visual_rpy;  /* [n_links*3]                                                    */
+  int32_t n_points;
+  const double* points;      /* [n_points*3]  surface points in the visual-mesh frame          */
+  const int32_t* point_link; /* [n_points]    in [0, n_links)                                  */
+  int32_t frame_ee;          /* link_ee      (gto/gto_planner.py:35)                           */
+  int32_t frame_gripper;     /* link_gripper (gto/gto_planner.py:36)                           */
+  int32_t n_gripper_points;
+  const double* gripper_points; /* [n_gripper_points*3] in the gripper LINK frame (:37)        */
+} gto_robot_desc;
+
+/* Planner constants the reference hard-codes (gto/gto_planner.py:25-30,131,135,141). */
+typedef struct gto_solver_opts {
+  int32_t T;               /* waypoints, reference 50                                        */
+  double Tmax;             /* reference 10.0 -> dt = Tmax/(T-1)                              */
+  int32_t standoff_offset; /* reference -10 -> standoff waypoint T+offset                    */
+  double w_obstacle;       /* reference 10                                                   */
+  double w_vel;            /* reference 0.01                                                 */
+  int32_t max_iter;        /* Gauss-Newton/LM iterations (reference IPOPT cap: 100)          */
+  double tol_step;         /* stop when max|dq| of an accepted step is below this [rad]      */
+  double tol_rel_f;        /* stop when an accepted step lowers f by less than this * (1+f)  */
+  double lambda0;          /* initial LM damping                                             */
+  int32_t grad_mode;       /* GTO_GRAD_*                                                     */
+} gto_solver_opts;
+
+typedef struct gto_handle gto_handle;
+
+/* Fill opts with the reference's constants and this solver's defaults. */
+void gto_default_opts(gto_solver_opts* opts);
+
+/* Library/ABI version (major*1000 + minor). */
+int32_t gto_version(void);
+
+/*
+ * Create a solver bound to HIP device `device` (a negative value keeps the current device).
+ * Copies everything it needs out of `desc`.  Fails loudly (GTO_ERR_NO_DEVICE) without a GPU:
+ * there is no CPU fallback behind this ABI.
+ * Replaces: GTOPlanner.__init__ + setup_optimization graph construction
+ *           (gto/gto_planner.py:22-142) and CasADiSolver.setup (optas/solver.py:335-386).
+ */
+int gto_create(const gto_robot_desc* desc, const gto_solver_opts* opts, int device, gto_handle** out);
+void gto_destroy(gto_handle* h);
+const char* gto_last_error(const gto_handle* h); /* h may be NULL: error of the last failed create */
+
+/* Change solver options that do not alter problem dimensions (max_iter, tolerances, weights,
+ * lambda0, grad_mode). T must stay the same. */
+int gto_set_opts(gto_handle* h, const gto_solver_opts* opts);
+
+/*
+ * Upload (or replace) the voxelised cost fields of scene `scene_id` (0 <= scene_id < 65536).
+ * c_all / c_obs: float32 [shape0*shape1*shape2], C order, x slowest (gto/gto_models.py:155-171,
+ * 184-186); c_obs may be NULL (then c_obs = c_all).  origin/res: gto/gto_models.py:159,46.
+ * Replaces: reset_parameters({"sdf_cost_all":..,"sdf_cost_obstacle":..}) (gto/gto_planner.py:227-236).
+ * One-time per scene; not part of the timed solve.
+ */
+int gto_set_scene(gto_handle* h, int32_t scene_id, const float* c_all, const float* c_obs,
+                  const int32_t shape[3], const double origin[3], double res);
+int gto_drop_scene(gto_handle* h, int32_t scene_id);
+
+/*
+ * Solve B independent (scene, goal-set) instances.  Host pointers; synchronous.
+ *   scene_id  [B]
+ *   qc        [B, ndof]        current configuration (gto/gto_planner.py:47-49,59-62)
+ *   goals     [B, n_max, 16]   goal poses of link_ee in the robot-base frame, each 4x4 row-major
+ *                              (tf_goal column = RT.flatten(), gto/gto_planner.py:188-191)
+ *   n_goals   [B]              1 <= n_goals[b] <= n_max (goal-set min, gto/gto_planner.py:105)
+ *   standoff  [B, 16] or NULL  standoff pose S (optas/spatialmath.py:160-183); NULL = use_standoff False
+ *   base_pos  [B, 3]           base_position parameter (gto/gto_planner.py:56,116)
+ *   Q0        [B, ndof, T]     seed trajectory incl. parameter-joint rows (gto/gto_planner.py:193-224,234)
+ * Outputs (any may be NULL):
+ *   Q_out [B, ndof, T], dQ_out [B, ndof, T-1], cost_out [B] (objective f, Appendix A of SURVEY.md),
+ *   iters_out [B], status_out [B] (GTO_STATUS_*).
+ * Replaces: reset_initial_seed + reset_parameters + solve + solution unpacking
+ *           (gto/gto_planner.py:222-245, optas/solver.py:103-159).
+ */
+int gto_solve_batch(gto_handle* h, int32_t B, int32_t n_max, const int32_t* scene_id,
+                    const double* qc, const double* goals, const int32_t* n_goals,
+                    const double* standoff, const double* base_pos, const double* Q0,
+                    double* Q_out, double* dQ_out, double* cost_out, int32_t* iters_out,
+                    int32_t* status_out);
+
+/*
+ * Same contract with every array already resident in device memory (HBM) and the work enqueued
+ * on `stream` (asynchronous; outputs are valid after the stream is synchronised).
+ */
+int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_t* scene_id,
+                           const double* qc, const double* goals, const int32_t* n_goals,
+                           const double* standoff, const double* base_pos, const double* Q0,
+                           double* Q_out, double* dQ_out, double* cost_out, int32_t* iters_out,
+                           int32_t* status_out, void* stream);
+
+/* Time spent inside the dominant kernel (gto_obstacle_gram) during the most recent solve,
+ * measured with HIP events on the launch stream: total milliseconds and launch count. */
+int gto_last_kernel_time(gto_handle* h, double* total_ms, int32_t* launches);
+/* Enable/disable per-launch event timing of the dominant kernel (off by default). */
+int gto_set_profiling(gto_handle* h, int32_t enabled);
+
+/* ---- evaluation entry points (host pointers, synchronous): the pieces of the objective the
+ * reference evaluates through CasADi Functions; used by the parity tests and by the seed /
+ * collision-filter steps around the solve. ---------------------------------------------------- */
+
+/* Global transform of every frame, [nq, n_frames, 16] row-major 4x4
+ * (optas/models.py:826-868 get_global_link_transform). */
+int gto_eval_fk(gto_handle* h, int32_t nq, const double* q /*[nq,ndof]*/, double* frames_out);
+
+/* World surface points x = visual_tf(q) p + base (gto/gto_planner.py:114-116), their flat voxel
+ * offsets (gto/gto_models.py:174-187), nearest-voxel cost values of both fields and the
+ * central-difference gradient of the field selected by `use_obs` (gto/sdf_callback.py:43-49,
+ * 90-114).  Any output may be NULL.  Points are reported in the caller's original order. */
+int gto_eval_points(gto_handle* h, int32_t scene_id, int32_t nq, const double* q /*[nq,ndof]*/,
+                    const double* base_pos /*[nq,3]*/, int32_t use_obs,
+                    double* xyz_out /*[nq,P,3]*/, int32_t* offset_out /*[nq,P]*/,
+                    double* value_out /*[nq,P]*/, double* grad_out /*[nq,P,3]*/);
+
+/* Objective terms of SURVEY.md Appendix A at given trajectories Q [B, ndof, T]:
+ * f_goal (min over the goal set), f_obs (incl. w_obstacle), f_vel (incl. w_vel), arg-min goal.
+ * (gto/gto_planner.py:84-105, 108-131, 133-135.) */
+int gto_eval_objective(gto_handle* h, int32_t B, int32_t n_max, const int32_t* scene_id,
+                       const double* goals, const int32_t* n_goals, const double* standoff,
+                       const double* base_pos, const double* Q, double* f_goal, double* f_obs,
+                       double* f_vel, int32_t* goal_argmin);
+
+/* Gauss-Newton normal equations of the obstacle term at Q [B, ndof, T], per waypoint:
+ * JtJ [B, T, n_opt, n_opt], Jtr [B, T, n_opt], sumsq [B, T] (unweighted: residual = cost value). */
+int gto_eval_obstacle_normal_eq(gto_handle* h, int32_t B, const int32_t* scene_id,
+                                const double* base_pos, const double* Q, double* JtJ, double* Jtr,
+                                double* sumsq);
+
+/* Seed scoring: compute_plan_cost (gto/gto_models.py:204-215): plain sum of c_obs over all
+ * waypoints and surface points, and ||q_0 - q_{T-1}||.  plans [n, ndof, T]. */
+int gto_plan_cost(gto_handle* h, int32_t scene_id, int32_t n, const double* plans,
+                  const double* base_pos /*[3]*/, double* cost_out /*[n]*/, double* dist_out /*[n]*/);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GTO_SOLVER_H */
