@@ -1,0 +1,742 @@
+// gto_api.hip — host side of libgto_hip.so: the C ABI declared in include/gto_solver.h.
+// Owns all device memory behind the opaque handle; no torch, no CPU fallback.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "gto_kernels.h"
+
+#define GTO_VERSION 1000
+
+static std::string g_create_error;
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+};
+
+struct gto_handle {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  gto_solver_opts opts;
+  RobotDev rb;  // host copy
+  RobotDev* d_rb = nullptr;
+  double *d_px = nullptr, *d_py = nullptr, *d_pz = nullptr;
+  int32_t *d_plink = nullptr, *d_perm = nullptr;
+  Chunk* d_chunks = nullptr;
+  std::vector<SceneDev> scenes;  // host mirror, index = scene id
+  SceneDev* d_scenes = nullptr;
+  size_t d_scenes_cap = 0;
+  // solve workspace (grown on demand)
+  DevBuf state, Qcur, Qtry, vis, screw, blocks, goalblk, ssfixed;
+  // staging for the host-pointer entry points
+  DevBuf in[8], out[8];
+  // profiling of the dominant kernel
+  bool profiling = false;
+  std::vector<hipEvent_t> ev;
+  double last_ms = 0.0;
+  int last_launches = 0;
+  size_t lm_lds = 0;
+};
+
+#define HIPCHK(h, call)                                                                              \
+  do {                                                                                               \
+    hipError_t e_ = (call);                                                                          \
+    if (e_ != hipSuccess) {                                                                          \
+      (h)->err = std::string(#call) + ": " + hipGetErrorString(e_);                                  \
+      return GTO_ERR_HIP;                                                                            \
+    }                                                                                                \
+  } while (0)
+
+static int fail(gto_handle* h, int code, const std::string& msg) {
+  if (h) h->err = msg;
+  else g_create_error = msg;
+  return code;
+}
+
+static int ensure(gto_handle* h, DevBuf& b, size_t bytes) {
+  if (bytes <= b.cap) return GTO_OK;
+  if (b.p) HIPCHK(h, hipFree(b.p));
+  b.p = nullptr;
+  b.cap = 0;
+  size_t want = bytes + bytes / 4 + 256;
+  HIPCHK(h, hipMalloc(&b.p, want));
+  b.cap = want;
+  return GTO_OK;
+}
+
+extern "C" {
+
+void gto_default_opts(gto_solver_opts* o) {
+  o->T = 50;  // gto/gto_planner.py:25
+  o->Tmax = 10.0;  // :26
+  o->standoff_offset = -10;  // :22
+  o->w_obstacle = 10.0;  // :131
+  o->w_vel = 0.01;  // :135
+  o->max_iter = 100;  // :141
+  o->tol_step = 1e-7;
+  o->tol_rel_f = 1e-10;
+  o->lambda0 = 1e-3;
+  o->grad_mode = GTO_GRAD_CENTRAL_DIFF;
+}
+
+int32_t gto_version(void) { return GTO_VERSION; }
+
+const char* gto_last_error(const gto_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+static int validate_opts(const gto_solver_opts* o, std::string& why) {
+  if (o->T < 4) { why = "T must be >= 4"; return 0; }
+  if (!(o->Tmax > 0)) { why = "Tmax must be positive"; return 0; }
+  if (o->max_iter < 0) { why = "max_iter must be >= 0"; return 0; }
+  int ts = o->T + o->standoff_offset;
+  if (ts < 2 || ts > o->T - 1) { why = "standoff waypoint T+standoff_offset must lie in [2, T-1]"; return 0; }
+  if (o->grad_mode != GTO_GRAD_CENTRAL_DIFF && o->grad_mode != GTO_GRAD_ZERO) { why = "unknown grad_mode"; return 0; }
+  if (!(o->lambda0 > 0)) { why = "lambda0 must be positive"; return 0; }
+  return 1;
+}
+
+static size_t lm_lds_bytes(int T) {
+  size_t m = (size_t)T - 2;
+  size_t dbl = m * 64 + 4 * m * 8 + 8 * (size_t)T + 64 + 8 + 48 + 2 * GTO_MAX_OPT * 6;
+  return dbl * sizeof(double) + m * 8 * sizeof(int) + 64;
+}
+
+int gto_create(const gto_robot_desc* d, const gto_solver_opts* opts, int device, gto_handle** out) {
+  if (!d || !opts || !out) return fail(nullptr, GTO_ERR_INVALID_ARG, "null argument");
+  *out = nullptr;
+  std::string why;
+  if (!validate_opts(opts, why)) return fail(nullptr, GTO_ERR_INVALID_ARG, why);
+  if (d->n_frames < 1 || d->n_frames > GTO_MAX_FRAMES) return fail(nullptr, GTO_ERR_UNSUPPORTED, "n_frames out of range (max 32)");
+  if (d->n_links < 1 || d->n_links > GTO_MAX_LINKS) return fail(nullptr, GTO_ERR_UNSUPPORTED, "n_links out of range (max 32)");
+  if (d->n_opt < 1 || d->n_opt > GTO_MAX_OPT) return fail(nullptr, GTO_ERR_UNSUPPORTED, "n_opt out of range (max 8)");
+  if (d->ndof < d->n_opt || d->ndof > GTO_MAX_DOF) return fail(nullptr, GTO_ERR_UNSUPPORTED, "ndof out of range (max 32)");
+  if (d->n_points < 1) return fail(nullptr, GTO_ERR_INVALID_ARG, "robot has no surface points");
+  if (d->n_gripper_points < 1) return fail(nullptr, GTO_ERR_INVALID_ARG, "robot has no gripper points");
+  if (d->frame_ee < 0 || d->frame_ee >= d->n_frames || d->frame_gripper < 0 || d->frame_gripper >= d->n_frames)
+    return fail(nullptr, GTO_ERR_INVALID_ARG, "frame_ee / frame_gripper out of range");
+
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    return fail(nullptr, GTO_ERR_NO_DEVICE, "no HIP device visible: the GTO solve path has no CPU fallback");
+  if (device >= ndev) return fail(nullptr, GTO_ERR_INVALID_ARG, "device index out of range");
+
+  gto_handle* h = new gto_handle();
+  if (device >= 0) {
+    if (hipSetDevice(device) != hipSuccess) { delete h; return fail(nullptr, GTO_ERR_HIP, "hipSetDevice failed"); }
+    h->device = device;
+  } else {
+    (void)hipGetDevice(&h->device);
+  }
+  h->opts = *opts;
+  RobotDev& rb = h->rb;
+  memset(&rb, 0, sizeof rb);
+  rb.n_frames = d->n_frames;
+  rb.ndof = d->ndof;
+  rb.n_opt = d->n_opt;
+  rb.n_links = d->n_links;
+  rb.n_points = d->n_points;
+  rb.n_gripper_points = d->n_gripper_points;
+  rb.frame_ee = d->frame_ee;
+  rb.frame_gripper = d->frame_gripper;
+  for (int j = 0; j < d->n_opt; ++j) {
+    if (d->opt_index[j] < 0 || d->opt_index[j] >= d->ndof) { delete h; return fail(nullptr, GTO_ERR_INVALID_ARG, "opt_index out of range"); }
+    rb.opt_index[j] = d->opt_index[j];
+    rb.lower[j] = d->lower[j];
+    rb.upper[j] = d->upper[j];
+    if (!(d->lower[j] <= d->upper[j])) { delete h; return fail(nullptr, GTO_ERR_INVALID_ARG, "lower > upper"); }
+  }
+  for (int i = 0; i < d->n_frames; ++i) {
+    int p = d->parent[i];
+    if (p >= i || p < -1) { delete h; return fail(nullptr, GTO_ERR_INVALID_ARG, "frames must list parents before children"); }
+    int jt = d->joint_type[i];
+    if (jt != GTO_JOINT_FIXED && jt != GTO_JOINT_REVOLUTE && jt != GTO_JOINT_PRISMATIC) {
+      delete h;
+      return fail(nullptr, GTO_ERR_UNSUPPORTED, "joint type not supported (optas/models.py:865-866)");
+    }
+    if (jt != GTO_JOINT_FIXED && (d->q_index[i] < 0 || d->q_index[i] >= d->ndof)) {
+      delete h;
+      return fail(nullptr, GTO_ERR_INVALID_ARG, "q_index out of range for an actuated joint");
+    }
+    rb.parent[i] = p;
+    rb.joint_type[i] = jt;
+    rb.q_index[i] = (jt == GTO_JOINT_FIXED) ? -1 : d->q_index[i];
+    double R[9];
+    rpy2r(d->origin_rpy + 3 * i, R);
+    rt2aff(R, d->origin_xyz + 3 * i, rb.origin[i]);
+    const double* ax = d->axis + 3 * i;
+    double nrm = std::sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
+    if (jt != GTO_JOINT_FIXED && !(nrm > 0)) { delete h; return fail(nullptr, GTO_ERR_INVALID_ARG, "zero joint axis"); }
+    for (int k = 0; k < 3; ++k) rb.axis_unit[i][k] = (nrm > 0) ? ax[k] / nrm : 0.0;
+    rb.opt_of_frame[i] = -1;
+    uint32_t anc = (p >= 0) ? rb.frame_anc[p] : 0u;
+    if (rb.q_index[i] >= 0)
+      for (int j = 0; j < d->n_opt; ++j)
+        if (d->opt_index[j] == rb.q_index[i]) {
+          rb.opt_of_frame[i] = j;
+          anc |= 1u << j;
+        }
+    rb.frame_anc[i] = anc;
+  }
+  for (int l = 0; l < d->n_links; ++l) {
+    int f = d->link_frame[l];
+    if (f < 0 || f >= d->n_frames) { delete h; return fail(nullptr, GTO_ERR_INVALID_ARG, "link_frame out of range"); }
+    rb.link_frame[l] = f;
+    rb.link_anc[l] = rb.frame_anc[f];
+    double R[9];
+    rpy2r(d->visual_rpy + 3 * l, R);
+    rt2aff(R, d->visual_xyz + 3 * l, rb.vis_origin[l]);
+  }
+  // moments of the gripper point cloud
+  rb.grip_count = (double)d->n_gripper_points;
+  for (int k = 0; k < d->n_gripper_points; ++k) {
+    const double* p = d->gripper_points + 3 * k;
+    for (int r = 0; r < 3; ++r) {
+      rb.grip_mu[r] += p[r];
+      for (int c = 0; c < 3; ++c) rb.grip_M[3 * r + c] += p[r] * p[c];
+    }
+  }
+  // points sorted by link (stable), chunk table of <= 64 link-uniform points
+  const int P = d->n_points;
+  std::vector<int32_t> perm(P);
+  for (int i = 0; i < P; ++i) {
+    perm[i] = i;
+    if (d->point_link[i] < 0 || d->point_link[i] >= d->n_links) { delete h; return fail(nullptr, GTO_ERR_INVALID_ARG, "point_link out of range"); }
+  }
+  std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return d->point_link[a] < d->point_link[b]; });
+  std::vector<double> px(P), py(P), pz(P);
+  std::vector<int32_t> plink(P);
+  for (int i = 0; i < P; ++i) {
+    px[i] = d->points[3 * perm[i]];
+    py[i] = d->points[3 * perm[i] + 1];
+    pz[i] = d->points[3 * perm[i] + 2];
+    plink[i] = d->point_link[perm[i]];
+  }
+  std::vector<Chunk> chunks;
+  for (int i = 0; i < P;) {
+    int l = plink[i], j = i;
+    while (j < P && plink[j] == l && j - i < GTO_WAVE) ++j;
+    chunks.push_back(Chunk{l, i, j - i, 0});
+    i = j;
+  }
+  rb.n_chunks = (int)chunks.size();
+
+  if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return fail(nullptr, GTO_ERR_HIP, "hipStreamCreate failed"); }
+  auto up = [&](void** dst, const void* src, size_t bytes) -> bool {
+    if (hipMalloc(dst, bytes) != hipSuccess) return false;
+    return hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) == hipSuccess;
+  };
+  bool ok = up((void**)&h->d_rb, &rb, sizeof rb) && up((void**)&h->d_px, px.data(), P * sizeof(double)) &&
+            up((void**)&h->d_py, py.data(), P * sizeof(double)) && up((void**)&h->d_pz, pz.data(), P * sizeof(double)) &&
+            up((void**)&h->d_plink, plink.data(), P * sizeof(int32_t)) && up((void**)&h->d_perm, perm.data(), P * sizeof(int32_t)) &&
+            up((void**)&h->d_chunks, chunks.data(), chunks.size() * sizeof(Chunk));
+  if (!ok) { gto_destroy(h); return fail(nullptr, GTO_ERR_ALLOC, "device allocation failed in gto_create"); }
+  h->lm_lds = lm_lds_bytes(opts->T);
+  if (h->lm_lds > 160 * 1024) { gto_destroy(h); return fail(nullptr, GTO_ERR_UNSUPPORTED, "T too large for the step kernel's LDS"); }
+  if (hipFuncSetAttribute((const void*)k_lm_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lm_lds) != hipSuccess) {
+    gto_destroy(h);
+    return fail(nullptr, GTO_ERR_HIP, "hipFuncSetAttribute(k_lm_step) failed");
+  }
+  *out = h;
+  return GTO_OK;
+}
+
+void gto_destroy(gto_handle* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  for (auto& s : h->scenes) {
+    if (s.valid) {
+      if (s.c_obs != s.c_all) (void)hipFree((void*)s.c_obs);
+      (void)hipFree((void*)s.c_all);
+    }
+  }
+  (void)hipFree(h->d_scenes);
+  (void)hipFree(h->d_rb);
+  (void)hipFree(h->d_px);
+  (void)hipFree(h->d_py);
+  (void)hipFree(h->d_pz);
+  (void)hipFree(h->d_plink);
+  (void)hipFree(h->d_perm);
+  (void)hipFree(h->d_chunks);
+  DevBuf* bufs[] = {&h->state, &h->Qcur, &h->Qtry, &h->vis, &h->screw, &h->blocks, &h->goalblk, &h->ssfixed};
+  for (DevBuf* b : bufs) (void)hipFree(b->p);
+  for (auto& b : h->in) (void)hipFree(b.p);
+  for (auto& b : h->out) (void)hipFree(b.p);
+  for (auto e : h->ev) (void)hipEventDestroy(e);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+int gto_set_opts(gto_handle* h, const gto_solver_opts* o) {
+  if (!h || !o) return GTO_ERR_INVALID_ARG;
+  std::string why;
+  if (!validate_opts(o, why)) return fail(h, GTO_ERR_INVALID_ARG, why);
+  if (o->T != h->opts.T) return fail(h, GTO_ERR_INVALID_ARG, "T cannot change after gto_create");
+  h->opts = *o;
+  return GTO_OK;
+}
+
+static int sync_scene_table(gto_handle* h) {
+  size_t n = h->scenes.size();
+  if (n > h->d_scenes_cap) {
+    if (h->d_scenes) HIPCHK(h, hipFree(h->d_scenes));
+    h->d_scenes = nullptr;
+    size_t cap = std::max<size_t>(16, n * 2);
+    HIPCHK(h, hipMalloc((void**)&h->d_scenes, cap * sizeof(SceneDev)));
+    h->d_scenes_cap = cap;
+  }
+  HIPCHK(h, hipMemcpy(h->d_scenes, h->scenes.data(), n * sizeof(SceneDev), hipMemcpyHostToDevice));
+  return GTO_OK;
+}
+
+int gto_set_scene(gto_handle* h, int32_t id, const float* c_all, const float* c_obs, const int32_t shape[3],
+                  const double origin[3], double res) {
+  if (!h) return GTO_ERR_INVALID_ARG;
+  if (!c_all || !shape || !origin) return fail(h, GTO_ERR_INVALID_ARG, "null argument");
+  if (id < 0 || id >= 65536) return fail(h, GTO_ERR_INVALID_ARG, "scene_id out of range [0,65536)");
+  if (shape[0] < 1 || shape[1] < 1 || shape[2] < 1 || !(res > 0)) return fail(h, GTO_ERR_INVALID_ARG, "bad field geometry");
+  const size_t nvox = (size_t)shape[0] * shape[1] * shape[2];
+  if (nvox >= ((size_t)1 << 31)) return fail(h, GTO_ERR_UNSUPPORTED, "field larger than 2^31 voxels");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if ((size_t)id >= h->scenes.size()) {
+    SceneDev z;
+    memset(&z, 0, sizeof z);
+    h->scenes.resize(id + 1, z);
+  }
+  SceneDev& s = h->scenes[id];
+  if (s.valid) {
+    if (s.c_obs != s.c_all) HIPCHK(h, hipFree((void*)s.c_obs));
+    HIPCHK(h, hipFree((void*)s.c_all));
+    s.valid = 0;
+  }
+  float *da = nullptr, *dob = nullptr;
+  HIPCHK(h, hipMalloc((void**)&da, nvox * sizeof(float)));
+  HIPCHK(h, hipMemcpy(da, c_all, nvox * sizeof(float), hipMemcpyHostToDevice));
+  if (c_obs && c_obs != c_all) {
+    HIPCHK(h, hipMalloc((void**)&dob, nvox * sizeof(float)));
+    HIPCHK(h, hipMemcpy(dob, c_obs, nvox * sizeof(float), hipMemcpyHostToDevice));
+  } else {
+    dob = da;
+  }
+  s.c_all = da;
+  s.c_obs = dob;
+  s.nx = shape[0];
+  s.ny = shape[1];
+  s.nz = shape[2];
+  s.ox = origin[0];
+  s.oy = origin[1];
+  s.oz = origin[2];
+  s.res = res;
+  s.rinv = 1.0 / res;
+  s.inv2r = 1.0 / (2.0 * res);
+  s.valid = 1;
+  return sync_scene_table(h);
+}
+
+int gto_drop_scene(gto_handle* h, int32_t id) {
+  if (!h) return GTO_ERR_INVALID_ARG;
+  if (id < 0 || (size_t)id >= h->scenes.size() || !h->scenes[id].valid) return fail(h, GTO_ERR_NO_SCENE, "unknown scene");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  SceneDev& s = h->scenes[id];
+  if (s.c_obs != s.c_all) HIPCHK(h, hipFree((void*)s.c_obs));
+  HIPCHK(h, hipFree((void*)s.c_all));
+  memset(&s, 0, sizeof s);
+  return sync_scene_table(h);
+}
+
+int gto_set_profiling(gto_handle* h, int32_t enabled) {
+  if (!h) return GTO_ERR_INVALID_ARG;
+  h->profiling = enabled != 0;
+  return GTO_OK;
+}
+
+int gto_last_kernel_time(gto_handle* h, double* total_ms, int32_t* launches) {
+  if (!h) return GTO_ERR_INVALID_ARG;
+  if (total_ms) *total_ms = h->last_ms;
+  if (launches) *launches = h->last_launches;
+  return GTO_OK;
+}
+
+// -------------------------------------------------------------------------------------------------
+static SolveParams make_params(const gto_handle* h, int n_max, bool use_standoff) {
+  const gto_solver_opts& o = h->opts;
+  SolveParams sp;
+  sp.T = o.T;
+  sp.ts = o.T + o.standoff_offset;
+  sp.use_standoff = use_standoff ? 1 : 0;
+  sp.n_max = n_max;
+  sp.max_iter = o.max_iter;
+  sp.grad_mode = o.grad_mode;
+  sp.dt = o.Tmax / (double)(o.T - 1);  // gto/gto_planner.py:27-28
+  sp.alpha = o.w_vel / (sp.dt * sp.dt);
+  sp.w_obstacle = o.w_obstacle;
+  sp.w_vel = o.w_vel;
+  sp.tol_step = o.tol_step;
+  sp.tol_rel_f = o.tol_rel_f;
+  sp.lambda0 = o.lambda0;
+  return sp;
+}
+
+static int ensure_workspace(gto_handle* h, int B) {
+  const RobotDev& rb = h->rb;
+  const size_t T = h->opts.T, n = rb.n_opt, L = rb.n_links;
+  int rc;
+  if ((rc = ensure(h, h->state, (size_t)B * sizeof(InstState)))) return rc;
+  if ((rc = ensure(h, h->Qcur, (size_t)B * n * T * sizeof(double)))) return rc;
+  if ((rc = ensure(h, h->Qtry, (size_t)B * n * T * sizeof(double)))) return rc;
+  if ((rc = ensure(h, h->vis, (size_t)B * T * L * 12 * sizeof(double)))) return rc;
+  if ((rc = ensure(h, h->screw, (size_t)B * T * n * 6 * sizeof(double)))) return rc;
+  if ((rc = ensure(h, h->blocks, (size_t)2 * B * T * BLK_STRIDE * sizeof(double)))) return rc;
+  if ((rc = ensure(h, h->goalblk, (size_t)2 * B * 2 * BLK_STRIDE * sizeof(double)))) return rc;
+  if ((rc = ensure(h, h->ssfixed, (size_t)B * 2 * sizeof(double)))) return rc;
+  return GTO_OK;
+}
+
+static BatchPtrs make_ptrs(gto_handle* h, const int32_t* scene_id, const double* qc, const double* goals,
+                           const int32_t* n_goals, const double* standoff, const double* base_pos, const double* Q0) {
+  BatchPtrs bp;
+  bp.scene_id = scene_id;
+  bp.qc = qc;
+  bp.goals = goals;
+  bp.n_goals = n_goals;
+  bp.standoff = standoff;
+  bp.base_pos = base_pos;
+  bp.Q0 = Q0;
+  bp.state = (InstState*)h->state.p;
+  bp.Qcur = (double*)h->Qcur.p;
+  bp.Qtry = (double*)h->Qtry.p;
+  bp.vis = (double*)h->vis.p;
+  bp.screw = (double*)h->screw.p;
+  bp.blocks = (double*)h->blocks.p;
+  bp.goalblk = (double*)h->goalblk.p;
+  bp.ss_fixed = (double*)h->ssfixed.p;
+  return bp;
+}
+
+static inline int obstacle_grid(int B, int nT) { return 8 * ((B + 7) / 8) * nT; }
+
+static int launch_obstacle(gto_handle* h, hipStream_t st, const BatchPtrs& bp, const SolveParams& sp, int B, int t_begin,
+                           int nT, int fixed_mode, bool timed) {
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (timed) {
+    size_t need = (size_t)(h->last_launches + 1) * 2;
+    while (h->ev.size() < need) {
+      hipEvent_t e;
+      HIPCHK(h, hipEventCreate(&e));
+      h->ev.push_back(e);
+    }
+    e0 = h->ev[2 * h->last_launches];
+    e1 = h->ev[2 * h->last_launches + 1];
+    HIPCHK(h, hipEventRecord(e0, st));
+  }
+  hipLaunchKernelGGL(k_obstacle_gram, dim3(obstacle_grid(B, nT)), dim3(256), 0, st, h->d_rb, h->d_px, h->d_py, h->d_pz,
+                     h->d_chunks, h->d_scenes, bp, sp, B, t_begin, nT, fixed_mode);
+  if (timed) {
+    HIPCHK(h, hipEventRecord(e1, st));
+    h->last_launches++;
+  }
+  return GTO_OK;
+}
+
+static int check_scene_ids_host(gto_handle* h, const int32_t* ids, int B) {
+  for (int b = 0; b < B; ++b)
+    if (ids[b] < 0 || (size_t)ids[b] >= h->scenes.size() || !h->scenes[ids[b]].valid)
+      return fail(h, GTO_ERR_NO_SCENE, "scene_id refers to a scene that was never set");
+  return GTO_OK;
+}
+
+int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_t* scene_id, const double* qc,
+                           const double* goals, const int32_t* n_goals, const double* standoff, const double* base_pos,
+                           const double* Q0, double* Q_out, double* dQ_out, double* cost_out, int32_t* iters_out,
+                           int32_t* status_out, void* stream) {
+  if (!h) return GTO_ERR_INVALID_ARG;
+  if (B < 0 || n_max < 1) return fail(h, GTO_ERR_INVALID_ARG, "B must be >= 0 and n_max >= 1");
+  if (B == 0) return GTO_OK;
+  if (!scene_id || !qc || !goals || !n_goals || !base_pos || !Q0) return fail(h, GTO_ERR_INVALID_ARG, "null input array");
+  if (h->scenes.empty()) return fail(h, GTO_ERR_NO_SCENE, "no scene has been set");
+  HIPCHK(h, hipSetDevice(h->device));
+  hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+  int rc = ensure_workspace(h, B);
+  if (rc) return rc;
+  SolveParams sp = make_params(h, n_max, standoff != nullptr);
+  BatchPtrs bp = make_ptrs(h, scene_id, qc, goals, n_goals, standoff, base_pos, Q0);
+  const int T = sp.T;
+  h->last_launches = 0;
+  h->last_ms = 0.0;
+
+  hipLaunchKernelGGL(k_lm_init, dim3(B), dim3(64), 0, st, h->d_rb, bp, sp, B, 0);
+  if ((rc = launch_obstacle(h, st, bp, sp, B, 0, 2, 1, false))) return rc;
+  // one round = evaluate the trial trajectory (obstacle kernel) + accept/solve/new trial (step kernel);
+  // instances that are done exit both kernels immediately
+  for (int k = 0; k <= sp.max_iter; ++k) {
+    if ((rc = launch_obstacle(h, st, bp, sp, B, 2, T - 2, 0, h->profiling))) return rc;
+    hipLaunchKernelGGL(k_lm_step, dim3(B), dim3(64), h->lm_lds, st, h->d_rb, bp, sp, B);
+  }
+  hipLaunchKernelGGL(k_lm_finalize, dim3(B), dim3(64), 0, st, h->d_rb, bp, sp, B, Q_out, dQ_out, cost_out, iters_out,
+                     status_out);
+  HIPCHK(h, hipGetLastError());
+  if (h->profiling) {
+    HIPCHK(h, hipStreamSynchronize(st));
+    double tot = 0.0;
+    for (int i = 0; i < h->last_launches; ++i) {
+      float ms = 0.f;
+      HIPCHK(h, hipEventElapsedTime(&ms, h->ev[2 * i], h->ev[2 * i + 1]));
+      tot += ms;
+    }
+    h->last_ms = tot;
+  }
+  return GTO_OK;
+}
+
+// host-pointer staging helpers
+static int stage_in(gto_handle* h, int slot, const void* src, size_t bytes, const void** dptr) {
+  *dptr = nullptr;
+  if (!src) return GTO_OK;
+  int rc = ensure(h, h->in[slot], bytes);
+  if (rc) return rc;
+  HIPCHK(h, hipMemcpyAsync(h->in[slot].p, src, bytes, hipMemcpyHostToDevice, h->stream));
+  *dptr = h->in[slot].p;
+  return GTO_OK;
+}
+static int stage_out(gto_handle* h, int slot, const void* host, size_t bytes, void** dptr) {
+  *dptr = nullptr;
+  if (!host) return GTO_OK;
+  int rc = ensure(h, h->out[slot], bytes);
+  if (rc) return rc;
+  *dptr = h->out[slot].p;
+  return GTO_OK;
+}
+static int fetch_out(gto_handle* h, int slot, void* host, size_t bytes) {
+  if (!host) return GTO_OK;
+  HIPCHK(h, hipMemcpyAsync(host, h->out[slot].p, bytes, hipMemcpyDeviceToHost, h->stream));
+  return GTO_OK;
+}
+
+int gto_solve_batch(gto_handle* h, int32_t B, int32_t n_max, const int32_t* scene_id, const double* qc, const double* goals,
+                    const int32_t* n_goals, const double* standoff, const double* base_pos, const double* Q0,
+                    double* Q_out, double* dQ_out, double* cost_out, int32_t* iters_out, int32_t* status_out) {
+  if (!h) return GTO_ERR_INVALID_ARG;
+  if (B < 0 || n_max < 1) return fail(h, GTO_ERR_INVALID_ARG, "B must be >= 0 and n_max >= 1");
+  if (B == 0) return GTO_OK;
+  if (!scene_id || !qc || !goals || !n_goals || !base_pos || !Q0) return fail(h, GTO_ERR_INVALID_ARG, "null input array");
+  int rc = check_scene_ids_host(h, scene_id, B);
+  if (rc) return rc;
+  for (int b = 0; b < B; ++b)
+    if (n_goals[b] < 1 || n_goals[b] > n_max) return fail(h, GTO_ERR_INVALID_ARG, "n_goals[b] must be in [1, n_max]");
+  HIPCHK(h, hipSetDevice(h->device));
+  const size_t ndof = h->rb.ndof, T = h->opts.T;
+  const void *d_sid, *d_qc, *d_goals, *d_ng, *d_so, *d_base, *d_Q0;
+  void *d_Q, *d_dQ, *d_cost, *d_it, *d_stat;
+  if ((rc = stage_in(h, 0, scene_id, B * sizeof(int32_t), &d_sid))) return rc;
+  if ((rc = stage_in(h, 1, qc, B * ndof * sizeof(double), &d_qc))) return rc;
+  if ((rc = stage_in(h, 2, goals, (size_t)B * n_max * 16 * sizeof(double), &d_goals))) return rc;
+  if ((rc = stage_in(h, 3, n_goals, B * sizeof(int32_t), &d_ng))) return rc;
+  if ((rc = stage_in(h, 4, standoff, (size_t)B * 16 * sizeof(double), &d_so))) return rc;
+  if ((rc = stage_in(h, 5, base_pos, (size_t)B * 3 * sizeof(double), &d_base))) return rc;
+  if ((rc = stage_in(h, 6, Q0, B * ndof * T * sizeof(double), &d_Q0))) return rc;
+  if ((rc = stage_out(h, 0, Q_out, B * ndof * T * sizeof(double), &d_Q))) return rc;
+  if ((rc = stage_out(h, 1, dQ_out, B * ndof * (T - 1) * sizeof(double), &d_dQ))) return rc;
+  if ((rc = stage_out(h, 2, cost_out, B * sizeof(double), &d_cost))) return rc;
+  if ((rc = stage_out(h, 3, iters_out, B * sizeof(int32_t), &d_it))) return rc;
+  if ((rc = stage_out(h, 4, status_out, B * sizeof(int32_t), &d_stat))) return rc;
+  rc = gto_solve_batch_device(h, B, n_max, (const int32_t*)d_sid, (const double*)d_qc, (const double*)d_goals,
+                              (const int32_t*)d_ng, (const double*)d_so, (const double*)d_base, (const double*)d_Q0,
+                              (double*)d_Q, (double*)d_dQ, (double*)d_cost, (int32_t*)d_it, (int32_t*)d_stat, nullptr);
+  if (rc) return rc;
+  if ((rc = fetch_out(h, 0, Q_out, B * ndof * T * sizeof(double)))) return rc;
+  if ((rc = fetch_out(h, 1, dQ_out, B * ndof * (T - 1) * sizeof(double)))) return rc;
+  if ((rc = fetch_out(h, 2, cost_out, B * sizeof(double)))) return rc;
+  if ((rc = fetch_out(h, 3, iters_out, B * sizeof(int32_t)))) return rc;
+  if ((rc = fetch_out(h, 4, status_out, B * sizeof(int32_t)))) return rc;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return GTO_OK;
+}
+
+// -------------------------------------------------------------------------------------------------
+int gto_eval_fk(gto_handle* h, int32_t nq, const double* q, double* frames_out) {
+  if (!h || !q || !frames_out || nq < 0) return h ? fail(h, GTO_ERR_INVALID_ARG, "bad argument") : GTO_ERR_INVALID_ARG;
+  if (nq == 0) return GTO_OK;
+  HIPCHK(h, hipSetDevice(h->device));
+  const void* dq;
+  void* dout;
+  int rc;
+  size_t ob = (size_t)nq * h->rb.n_frames * 16 * sizeof(double);
+  if ((rc = stage_in(h, 0, q, (size_t)nq * h->rb.ndof * sizeof(double), &dq))) return rc;
+  if ((rc = stage_out(h, 0, frames_out, ob, &dout))) return rc;
+  hipLaunchKernelGGL(k_eval_fk, dim3((nq + 63) / 64), dim3(64), 0, h->stream, h->d_rb, nq, (const double*)dq, (double*)dout);
+  if ((rc = fetch_out(h, 0, frames_out, ob))) return rc;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return GTO_OK;
+}
+
+int gto_eval_points(gto_handle* h, int32_t scene_id, int32_t nq, const double* q, const double* base_pos, int32_t use_obs,
+                    double* xyz_out, int32_t* offset_out, double* value_out, double* grad_out) {
+  if (!h || !q || !base_pos || nq < 0) return h ? fail(h, GTO_ERR_INVALID_ARG, "bad argument") : GTO_ERR_INVALID_ARG;
+  if (nq == 0) return GTO_OK;
+  const bool want_field = offset_out || value_out || grad_out;
+  if (want_field && (scene_id < 0 || (size_t)scene_id >= h->scenes.size() || !h->scenes[scene_id].valid))
+    return fail(h, GTO_ERR_NO_SCENE, "unknown scene");
+  HIPCHK(h, hipSetDevice(h->device));
+  const int P = h->rb.n_points, L = h->rb.n_links;
+  const void *dq, *dbase;
+  void *dx, *doff, *dval, *dgrad;
+  int rc;
+  if ((rc = stage_in(h, 0, q, (size_t)nq * h->rb.ndof * sizeof(double), &dq))) return rc;
+  if ((rc = stage_in(h, 1, base_pos, (size_t)nq * 3 * sizeof(double), &dbase))) return rc;
+  if ((rc = ensure(h, h->vis, (size_t)nq * L * 12 * sizeof(double)))) return rc;
+  if ((rc = stage_out(h, 0, xyz_out, (size_t)nq * P * 3 * sizeof(double), &dx))) return rc;
+  if ((rc = stage_out(h, 1, offset_out, (size_t)nq * P * sizeof(int32_t), &doff))) return rc;
+  if ((rc = stage_out(h, 2, value_out, (size_t)nq * P * sizeof(double), &dval))) return rc;
+  if ((rc = stage_out(h, 3, grad_out, (size_t)nq * P * 3 * sizeof(double), &dgrad))) return rc;
+  hipLaunchKernelGGL(k_eval_kin, dim3((nq + 63) / 64), dim3(64), 0, h->stream, h->d_rb, nq, (const double*)dq, (double*)h->vis.p);
+  hipLaunchKernelGGL(k_eval_points, dim3((P + 255) / 256, nq), dim3(256), 0, h->stream, h->d_rb, h->d_px, h->d_py, h->d_pz,
+                     h->d_plink, h->d_perm, want_field ? h->d_scenes + scene_id : nullptr, nq, (const double*)h->vis.p,
+                     (const double*)dbase, use_obs, (double*)dx, (int32_t*)doff, (double*)dval, (double*)dgrad);
+  if ((rc = fetch_out(h, 0, xyz_out, (size_t)nq * P * 3 * sizeof(double)))) return rc;
+  if ((rc = fetch_out(h, 1, offset_out, (size_t)nq * P * sizeof(int32_t)))) return rc;
+  if ((rc = fetch_out(h, 2, value_out, (size_t)nq * P * sizeof(double)))) return rc;
+  if ((rc = fetch_out(h, 3, grad_out, (size_t)nq * P * 3 * sizeof(double)))) return rc;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return GTO_OK;
+}
+
+// Shared by gto_eval_objective / gto_eval_obstacle_normal_eq: run init (kinematics + goal terms of Q as
+// the "trial") and the obstacle kernel over all waypoints, then read the pieces back.
+static int eval_common(gto_handle* h, int B, int n_max, const int32_t* scene_id, const double* goals,
+                       const int32_t* n_goals, const double* standoff, const double* base_pos, const double* Q,
+                       bool with_goals, std::vector<InstState>& states, std::vector<double>& blocks,
+                       std::vector<double>& ssfixed) {
+  int rc = check_scene_ids_host(h, scene_id, B);
+  if (rc) return rc;
+  HIPCHK(h, hipSetDevice(h->device));
+  const size_t ndof = h->rb.ndof, T = h->opts.T;
+  // a neutral goal set when the caller only wants obstacle terms
+  std::vector<double> dummy_goal;
+  std::vector<int32_t> dummy_n;
+  std::vector<double> qc(B * ndof);
+  for (int b = 0; b < B; ++b)
+    for (size_t i = 0; i < ndof; ++i) qc[b * ndof + i] = Q[((size_t)b * ndof + i) * T];
+  if (!with_goals) {
+    n_max = 1;
+    dummy_goal.assign((size_t)B * 16, 0.0);
+    for (int b = 0; b < B; ++b) dummy_goal[b * 16] = dummy_goal[b * 16 + 5] = dummy_goal[b * 16 + 10] = dummy_goal[b * 16 + 15] = 1.0;
+    dummy_n.assign(B, 1);
+    goals = dummy_goal.data();
+    n_goals = dummy_n.data();
+    standoff = nullptr;
+  }
+  const void *d_sid, *d_qc, *d_goals, *d_ng, *d_so, *d_base, *d_Q0;
+  if ((rc = stage_in(h, 0, scene_id, B * sizeof(int32_t), &d_sid))) return rc;
+  if ((rc = stage_in(h, 1, qc.data(), B * ndof * sizeof(double), &d_qc))) return rc;
+  if ((rc = stage_in(h, 2, goals, (size_t)B * n_max * 16 * sizeof(double), &d_goals))) return rc;
+  if ((rc = stage_in(h, 3, n_goals, B * sizeof(int32_t), &d_ng))) return rc;
+  if ((rc = stage_in(h, 4, standoff, (size_t)B * 16 * sizeof(double), &d_so))) return rc;
+  if ((rc = stage_in(h, 5, base_pos, (size_t)B * 3 * sizeof(double), &d_base))) return rc;
+  if ((rc = stage_in(h, 6, Q, B * ndof * T * sizeof(double), &d_Q0))) return rc;
+  if ((rc = ensure_workspace(h, B))) return rc;
+  SolveParams sp = make_params(h, n_max, standoff != nullptr);
+  BatchPtrs bp = make_ptrs(h, (const int32_t*)d_sid, (const double*)d_qc, (const double*)d_goals, (const int32_t*)d_ng,
+                           (const double*)d_so, (const double*)d_base, (const double*)d_Q0);
+  hipLaunchKernelGGL(k_lm_init, dim3(B), dim3(64), 0, h->stream, h->d_rb, bp, sp, B, 1 /* raw: evaluate Q as given */);
+  if ((rc = launch_obstacle(h, h->stream, bp, sp, B, 0, 2, 1, false))) return rc;
+  if ((rc = launch_obstacle(h, h->stream, bp, sp, B, 2, (int)T - 2, 0, false))) return rc;
+  states.resize(B);
+  blocks.resize((size_t)B * T * BLK_STRIDE);
+  ssfixed.resize((size_t)B * 2);
+  HIPCHK(h, hipMemcpyAsync(states.data(), h->state.p, B * sizeof(InstState), hipMemcpyDeviceToHost, h->stream));
+  // trial slot is 1 right after init (slot = 0)
+  HIPCHK(h, hipMemcpyAsync(blocks.data(), (double*)h->blocks.p + (size_t)1 * B * T * BLK_STRIDE,
+                           blocks.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipMemcpyAsync(ssfixed.data(), h->ssfixed.p, ssfixed.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, hipGetLastError());
+  return GTO_OK;
+}
+
+int gto_eval_objective(gto_handle* h, int32_t B, int32_t n_max, const int32_t* scene_id, const double* goals,
+                       const int32_t* n_goals, const double* standoff, const double* base_pos, const double* Q,
+                       double* f_goal, double* f_obs, double* f_vel, int32_t* goal_argmin) {
+  if (!h) return GTO_ERR_INVALID_ARG;
+  if (B < 0 || n_max < 1 || !scene_id || !goals || !n_goals || !base_pos || !Q) return fail(h, GTO_ERR_INVALID_ARG, "bad argument");
+  if (B == 0) return GTO_OK;
+  std::vector<InstState> st;
+  std::vector<double> blocks, ssf;
+  int rc = eval_common(h, B, n_max, scene_id, goals, n_goals, standoff, base_pos, Q, true, st, blocks, ssf);
+  if (rc) return rc;
+  const int T = h->opts.T;
+  for (int b = 0; b < B; ++b) {
+    double so = ssf[2 * b] + ssf[2 * b + 1];
+    for (int t = 2; t < T; ++t) so += blocks[((size_t)b * T + t) * BLK_STRIDE + BLK_SS];
+    if (f_goal) f_goal[b] = st[b].fgoal_try;
+    if (f_obs) f_obs[b] = h->opts.w_obstacle * so;
+    if (f_vel) f_vel[b] = st[b].fvel_try;
+    if (goal_argmin) goal_argmin[b] = st[b].argmin_try;
+  }
+  return GTO_OK;
+}
+
+int gto_eval_obstacle_normal_eq(gto_handle* h, int32_t B, const int32_t* scene_id, const double* base_pos, const double* Q,
+                                double* JtJ, double* Jtr, double* sumsq) {
+  if (!h) return GTO_ERR_INVALID_ARG;
+  if (B < 0 || !scene_id || !base_pos || !Q) return fail(h, GTO_ERR_INVALID_ARG, "bad argument");
+  if (B == 0) return GTO_OK;
+  std::vector<InstState> st;
+  std::vector<double> blocks, ssf;
+  int rc = eval_common(h, B, 1, scene_id, nullptr, nullptr, nullptr, base_pos, Q, false, st, blocks, ssf);
+  if (rc) return rc;
+  const int T = h->opts.T, n = h->rb.n_opt;
+  for (int b = 0; b < B; ++b)
+    for (int t = 0; t < T; ++t) {
+      const double* blk = &blocks[((size_t)b * T + t) * BLK_STRIDE];
+      for (int i = 0; i < n; ++i) {
+        for (int j = 0; j < n; ++j)
+          if (JtJ) JtJ[(((size_t)b * T + t) * n + i) * n + j] = (t < 2) ? 0.0 : blk[BLK_JTJ + 8 * i + j];
+        if (Jtr) Jtr[((size_t)b * T + t) * n + i] = (t < 2) ? 0.0 : blk[BLK_JTR + i];
+      }
+      if (sumsq) sumsq[(size_t)b * T + t] = (t < 2) ? ssf[2 * b + t] : blk[BLK_SS];
+    }
+  return GTO_OK;
+}
+
+int gto_plan_cost(gto_handle* h, int32_t scene_id, int32_t n, const double* plans, const double* base_pos, double* cost_out,
+                  double* dist_out) {
+  if (!h) return GTO_ERR_INVALID_ARG;
+  if (n < 0 || !plans || !base_pos || !cost_out) return fail(h, GTO_ERR_INVALID_ARG, "bad argument");
+  if (n == 0) return GTO_OK;
+  if (scene_id < 0 || (size_t)scene_id >= h->scenes.size() || !h->scenes[scene_id].valid) return fail(h, GTO_ERR_NO_SCENE, "unknown scene");
+  HIPCHK(h, hipSetDevice(h->device));
+  const size_t ndof = h->rb.ndof, T = h->opts.T;
+  const void *dplans, *dbase;
+  void* dpart;
+  int rc;
+  if ((rc = stage_in(h, 0, plans, (size_t)n * ndof * T * sizeof(double), &dplans))) return rc;
+  if ((rc = stage_in(h, 1, base_pos, 3 * sizeof(double), &dbase))) return rc;
+  std::vector<double> part((size_t)n * T);
+  if ((rc = stage_out(h, 0, part.data(), part.size() * sizeof(double), &dpart))) return rc;
+  hipLaunchKernelGGL(k_plan_cost, dim3((unsigned)T, n), dim3(256), 0, h->stream, h->d_rb, h->d_px, h->d_py, h->d_pz, h->d_plink,
+                     h->d_scenes + scene_id, (int)T, (const double*)dplans, (const double*)dbase, (double*)dpart);
+  if ((rc = fetch_out(h, 0, part.data(), part.size() * sizeof(double)))) return rc;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, hipGetLastError());
+  for (int i = 0; i < n; ++i) {
+    double c = 0.0, dd = 0.0;
+    for (size_t t = 0; t < T; ++t) c += part[(size_t)i * T + t];  // waypoint order, like the reference loop
+    for (size_t j = 0; j < ndof; ++j) {
+      double v = plans[((size_t)i * ndof + j) * T] - plans[((size_t)i * ndof + j) * T + T - 1];
+      dd += v * v;
+    }
+    cost_out[i] = c;
+    if (dist_out) dist_out[i] = std::sqrt(dd);
+  }
+  return GTO_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,146 @@
+// gto_device.h — device-side data layout and small math shared by the GTO kernels (gfx950).
+//
+// Data layout in HBM (all FP64 unless stated; "n" = optimised joints, "L" = collision links):
+//   RobotDev            one per handle, read through scalar loads (uniform addresses)
+//   points              SoA px[], py[], pz[], sorted by collision link; chunk table {link,start,count<=64}
+//                       so that one wavefront processes one link-uniform chunk per step
+//   scene fields        float32 [nx*ny*nz] C order (x slowest), c_all and c_obs per scene
+//   per-instance state  SoA over the batch: Q [B][n][T], kinematics handed from the step kernel to
+//                       the obstacle kernel as visual transforms [B][T][L][12] and joint screws
+//                       [B][T][n][6]; Gauss-Newton blocks [2 slots][B][T][n*n + n + 1]
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/gto_solver.h"
+
+#define GTO_NB 8            // padded block size of the per-waypoint normal-equation blocks
+#define GTO_GRAM 28         // 21 (6x6 symmetric wrench Gram) + 6 (c * wrench) + 1 (c^2)
+#define GTO_WAVE 64
+
+struct RobotDev {
+  int32_t n_frames, ndof, n_opt, n_links, n_points, n_chunks, n_gripper_points;
+  int32_t frame_ee, frame_gripper;
+  int32_t parent[GTO_MAX_FRAMES];
+  int32_t joint_type[GTO_MAX_FRAMES];
+  int32_t q_index[GTO_MAX_FRAMES];
+  int32_t opt_of_frame[GTO_MAX_FRAMES];  // optimised-joint slot driven by this frame's joint, or -1
+  uint32_t frame_anc[GTO_MAX_FRAMES];    // bit j: optimised joint j moves this frame
+  double origin[GTO_MAX_FRAMES][12];     // rt2tr(rpy2r(rpy), xyz)  (optas/models.py:848-857)
+  double axis_unit[GTO_MAX_FRAMES][3];   // unit(axis)              (optas/models.py:653-659)
+  int32_t link_frame[GTO_MAX_LINKS];
+  uint32_t link_anc[GTO_MAX_LINKS];
+  double vis_origin[GTO_MAX_LINKS][12];  // rt2tr(rpy2r(vis_rpy), vis_xyz) (gto/gto_models.py:95-96)
+  int32_t opt_index[GTO_MAX_OPT];
+  double lower[GTO_MAX_OPT], upper[GTO_MAX_OPT];
+  // moments of the gripper point cloud p_k (gto/gto_planner.py:37): K, mu = sum p, M = sum p p^T
+  double grip_count, grip_mu[3], grip_M[9];
+};
+
+struct SceneDev {
+  const float* c_all;
+  const float* c_obs;
+  int32_t nx, ny, nz, valid;
+  double ox, oy, oz, res, rinv, inv2r;
+};
+
+struct Chunk {
+  int32_t link, start, count, pad;
+};
+
+// ---------------------------------------------------------------- 3x4 affine helpers (row-major)
+__host__ __device__ inline void aff_identity(double* m) {
+  for (int i = 0; i < 12; ++i) m[i] = 0.0;
+  m[0] = m[5] = m[10] = 1.0;
+}
+__host__ __device__ inline void aff_mul(const double* a, const double* b, double* c) {
+  double r[12];
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 4; ++j) {
+      double s = a[4 * i] * b[j] + a[4 * i + 1] * b[4 + j] + a[4 * i + 2] * b[8 + j];
+      if (j == 3) s += a[4 * i + 3];
+      r[4 * i + j] = s;
+    }
+  }
+  for (int i = 0; i < 12; ++i) c[i] = r[i];
+}
+__host__ __device__ inline void mat3_mul(const double* a, const double* b, double* c) {
+  double r[9];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) r[3 * i + j] = a[3 * i] * b[j] + a[3 * i + 1] * b[3 + j] + a[3 * i + 2] * b[6 + j];
+  for (int i = 0; i < 9; ++i) c[i] = r[i];
+}
+// optas/spatialmath.py:186-211 rpy2r 'zyx' = rotz(y) @ roty(p) @ rotx(r)
+__host__ __device__ inline void rpy2r(const double* rpy, double* R) {
+  double cr = cos(rpy[0]), sr = sin(rpy[0]), cp = cos(rpy[1]), sp = sin(rpy[1]), cy = cos(rpy[2]), sy = sin(rpy[2]);
+  double Rz[9] = {cy, -sy, 0, sy, cy, 0, 0, 0, 1};
+  double Ry[9] = {cp, 0, sp, 0, 1, 0, -sp, 0, cp};
+  double Rx[9] = {1, 0, 0, 0, cr, -sr, 0, sr, cr};
+  double t[9];
+  mat3_mul(Rz, Ry, t);
+  mat3_mul(t, Rx, R);
+}
+__host__ __device__ inline void rt2aff(const double* R, const double* t, double* m) {
+  for (int i = 0; i < 3; ++i) {
+    m[4 * i] = R[3 * i];
+    m[4 * i + 1] = R[3 * i + 1];
+    m[4 * i + 2] = R[3 * i + 2];
+    m[4 * i + 3] = t[i];
+  }
+}
+// optas/spatialmath.py:90-100 angvec2r with a unit axis u
+__host__ __device__ inline void angvec2r_unit(double theta, const double* u, double* R) {
+  double sk[9] = {0, -u[2], u[1], u[2], 0, -u[0], -u[1], u[0], 0};
+  double sk2[9];
+  mat3_mul(sk, sk, sk2);
+  double s = sin(theta), c1 = 1.0 - cos(theta);
+  for (int i = 0; i < 9; ++i) R[i] = s * sk[i] + c1 * sk2[i];
+  R[0] += 1.0;
+  R[4] += 1.0;
+  R[8] += 1.0;
+}
+__host__ __device__ inline void cross3(const double* a, const double* b, double* c) {
+  c[0] = a[1] * b[2] - a[2] * b[1];
+  c[1] = a[2] * b[0] - a[0] * b[2];
+  c[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+// Forward kinematics of every frame (optas/models.py:826-868, prefix-shared).
+// frames: [n_frames][12], indexed with `stride` doubles between consecutive entries of one frame
+// element so that per-thread scratch (stride 1) and LDS/transposed layouts can share the code.
+__host__ __device__ inline void fk_frames(const RobotDev* rb, const double* q, double* frames) {
+  for (int i = 0; i < rb->n_frames; ++i) {
+    double T[12];
+    if (rb->parent[i] < 0) {
+      double I[12];
+      aff_identity(I);
+      aff_mul(I, rb->origin[i], T);
+    } else {
+      aff_mul(frames + 12 * rb->parent[i], rb->origin[i], T);
+    }
+    int jt = rb->joint_type[i];
+    if (jt == GTO_JOINT_REVOLUTE) {
+      double R[9], M[12], z[3] = {0, 0, 0};
+      angvec2r_unit(q[rb->q_index[i]], rb->axis_unit[i], R);
+      rt2aff(R, z, M);
+      aff_mul(T, M, T);
+    } else if (jt == GTO_JOINT_PRISMATIC) {
+      double qi = q[rb->q_index[i]];
+      double tr[3] = {qi * rb->axis_unit[i][0], qi * rb->axis_unit[i][1], qi * rb->axis_unit[i][2]};
+      double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, M[12];
+      rt2aff(I3, tr, M);
+      aff_mul(T, M, T);
+    }
+    for (int k = 0; k < 12; ++k) frames[12 * i + k] = T[k];
+  }
+}
+
+// index of (i,j), i<=j, in the packed upper triangle of a symmetric 6x6
+__host__ __device__ inline int sym6(int i, int j) {
+  if (i > j) {
+    int t = i;
+    i = j;
+    j = t;
+  }
+  return i * 6 - (i * (i - 1)) / 2 + (j - i);
+}

@@ -1,0 +1,918 @@
+// gto_kernels.h — HIP kernels of the GTO inner solver for CDNA4 (gfx950, wave64).
+//
+//   k_obstacle_gram   the dominant kernel: one workgroup per (instance, waypoint); every lane owns
+//                     surface points: visual transform from LDS -> world point -> exact voxel index ->
+//                     nearest-voxel cost + 6 central-difference neighbours gathered from the f32 field
+//                     -> wrench (y x grad, grad) -> per-lane 6x6 Gram accumulation -> wave reduction
+//                     -> per-link LDS accumulators -> projection onto the joint screws -> J^T J, J^T r
+//   k_lm_init/k_lm_step  one wavefront per instance: accept/reject, bound active set, block-tridiagonal
+//                     solve, projected step, forward kinematics + goal-set terms of the new trial
+//   k_lm_finalize     assemble Q / dQ / cost / status
+// Roofline: HBM/L2-gather bound (28 B of field gathers per point-waypoint); MFMA is not
+// used: the only dense algebra is 7x7 blocks, <1 % of the flops.
+#pragma once
+#include "gto_device.h"
+
+#define BLK_JTJ 0
+#define BLK_JTR 64
+#define BLK_SS 72
+#define BLK_STRIDE 80  // doubles per (instance, waypoint) block: 8x8 J^T J, 8 J^T r, sum c^2, pad
+
+struct InstState {
+  double f, lambda, nu, pred;
+  double fgoal_try, fvel_try;
+  int32_t slot, first, done, status, evals, argmin_try, argmin_cur, pad;
+};
+
+struct SolveParams {
+  int32_t T, ts, use_standoff, n_max, max_iter, grad_mode;
+  double dt, alpha, w_obstacle, w_vel, tol_step, tol_rel_f, lambda0;
+};
+
+struct BatchPtrs {
+  // inputs (device)
+  const int32_t* scene_id;  // [B]
+  const double* qc;         // [B][ndof]
+  const double* goals;      // [B][n_max][16]
+  const int32_t* n_goals;   // [B]
+  const double* standoff;   // [B][16] or null
+  const double* base_pos;   // [B][3]
+  const double* Q0;         // [B][ndof][T]
+  // workspace
+  InstState* state;  // [B]
+  double* Qcur;      // [B][n][T]
+  double* Qtry;      // [B][n][T]
+  double* vis;       // [B][T][L][12]
+  double* screw;     // [B][T][n][6]
+  double* blocks;    // [2][B][T][BLK_STRIDE]
+  double* goalblk;   // [2][B][2][BLK_STRIDE]
+  double* ss_fixed;  // [B][2]  sum c^2 of the two pinned waypoints
+};
+
+// ------------------------------------------------------------------------------------------------
+__device__ inline double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ inline double wave_max(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// floor((x - o) / res) clipped to [0, n-1], bit-identical to the reference's index
+// (gto/gto_models.py:174-187): the true quotient is only formed when the fast product lands within
+// 1e-9 of a voxel face (the two can differ by an ulp there and nowhere else).
+__device__ inline int voxel_axis(double x, double o, double res, double rinv, int n) {
+  double d = x - o;
+  double u = d * rinv;
+  double k = floor(u);
+  double fr = u - k;
+  if (fr < 1e-9 || fr > 1.0 - 1e-9) k = floor(d / res);
+  double hi = (double)(n - 1);
+  k = (k >= 0.0) ? k : 0.0;  // NaN -> 0 like fmax(.,0)
+  k = (k > hi) ? hi : k;
+  return (int)k;
+}
+
+// Kinematics of one configuration: visual transforms of the collision links, world screws of the
+// optimised joints and (optionally) the gripper / ee frames. Runs in ONE thread (private scratch).
+__device__ inline void kin_eval(const RobotDev* rb, const double* q, double* vis, double* screw, double* grip_ee) {
+  double frames[GTO_MAX_FRAMES * 12];
+  fk_frames(rb, q, frames);
+  const int L = rb->n_links;
+  if (vis) {
+    for (int l = 0; l < L; ++l) {
+      double V[12];
+      aff_mul(frames + 12 * rb->link_frame[l], rb->vis_origin[l], V);
+      for (int k = 0; k < 12; ++k) vis[12 * l + k] = V[k];
+    }
+  }
+  if (screw) {
+    for (int i = 0; i < rb->n_frames; ++i) {
+      int j = rb->opt_of_frame[i];
+      if (j < 0) continue;
+      const double* F = frames + 12 * i;
+      const double* u = rb->axis_unit[i];
+      double a[3], o[3];
+      for (int r = 0; r < 3; ++r) {
+        a[r] = F[4 * r] * u[0] + F[4 * r + 1] * u[1] + F[4 * r + 2] * u[2];
+        o[r] = F[4 * r + 3];
+      }
+      double* s = screw + 6 * j;
+      if (rb->joint_type[i] == GTO_JOINT_PRISMATIC) {
+        s[0] = s[1] = s[2] = 0.0;
+        s[3] = a[0];
+        s[4] = a[1];
+        s[5] = a[2];
+      } else {
+        double oxa[3];
+        cross3(o, a, oxa);
+        s[0] = a[0];
+        s[1] = a[1];
+        s[2] = a[2];
+        s[3] = oxa[0];
+        s[4] = oxa[1];
+        s[5] = oxa[2];
+      }
+    }
+  }
+  if (grip_ee) {
+    for (int k = 0; k < 12; ++k) {
+      grip_ee[k] = frames[12 * rb->frame_gripper + k];
+      grip_ee[12 + k] = frames[12 * rb->frame_ee + k];
+    }
+  }
+}
+
+__device__ inline void load_full_q(const RobotDev* rb, const double* Q0b, const double* Qopt, int T, int t, double* q) {
+  for (int i = 0; i < rb->ndof; ++i) q[i] = Q0b[(size_t)i * T + t];
+  for (int j = 0; j < rb->n_opt; ++j) q[rb->opt_index[j]] = Qopt[(size_t)j * T + t];
+}
+
+// ------------------------------------------------------------------------------------------------
+// Dominant kernel.  grid.x = 8 * ceil(B/8) * nT  (XCD-aware: all waypoints of one instance, hence all
+// gathers into one scene's field, are issued from the same XCD and share its 4 MiB L2).
+// t_begin/nT select the waypoint range (the two pinned waypoints are evaluated once at init).
+__global__ __launch_bounds__(256) void k_obstacle_gram(const RobotDev* __restrict__ rb, const double* __restrict__ px,
+                                                       const double* __restrict__ py, const double* __restrict__ pz,
+                                                       const Chunk* __restrict__ chunks, const SceneDev* __restrict__ scenes,
+                                                       BatchPtrs bp, SolveParams sp, int B, int t_begin, int nT,
+                                                       int fixed_mode) {
+  // blockIdx -> (instance, waypoint), bijective, with b % 8 == blockIdx % 8
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, k = bid >> 3;
+  const int b = (k / nT) * 8 + xcd;
+  const int t = t_begin + (k % nT);
+  if (b >= B) return;
+  const InstState* st = bp.state + b;
+  if (st->done) return;
+
+  __shared__ double s_vis[GTO_MAX_LINKS * 12];
+  __shared__ double s_screw[GTO_MAX_OPT * 6];
+  __shared__ double s_gram[GTO_MAX_LINKS * GTO_GRAM];
+  __shared__ double s_u[GTO_MAX_LINKS * GTO_MAX_OPT * 6];
+  __shared__ double s_out[BLK_STRIDE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int L = rb->n_links, n = rb->n_opt, T = sp.T;
+  const double* visg = bp.vis + ((size_t)b * T + t) * L * 12;
+  const double* scrg = bp.screw + ((size_t)b * T + t) * n * 6;
+  for (int i = tid; i < L * 12; i += 256) s_vis[i] = visg[i];
+  for (int i = tid; i < n * 6; i += 256) s_screw[i] = scrg[i];
+  for (int i = tid; i < L * GTO_GRAM; i += 256) s_gram[i] = 0.0;
+  if (tid < BLK_STRIDE) s_out[tid] = 0.0;
+  __syncthreads();
+
+  const SceneDev sc = scenes[bp.scene_id[b]];
+  const float* __restrict__ field = (t < sp.ts) ? sc.c_all : sc.c_obs;  // gto/gto_planner.py:117-131
+  const double bx = bp.base_pos[3 * b], by = bp.base_pos[3 * b + 1], bz = bp.base_pos[3 * b + 2];
+  const bool need_grad = !fixed_mode && sp.grad_mode == GTO_GRAD_CENTRAL_DIFF;
+  const int nyz = sc.ny * sc.nz;
+
+  // contiguous chunk range per wave: few link changes -> few wave reductions
+  const int C = rb->n_chunks;
+  const int c0 = (int)(((long)C * wave) / 4), c1 = (int)(((long)C * (wave + 1)) / 4);
+  double acc[GTO_GRAM];
+#pragma unroll
+  for (int i = 0; i < GTO_GRAM; ++i) acc[i] = 0.0;
+  int cur_link = -1;
+
+  auto flush = [&](int link) {
+#pragma unroll
+    for (int i = 0; i < GTO_GRAM; ++i) {
+      double v = wave_sum(acc[i]);
+      if (lane == i) atomicAdd(&s_gram[link * GTO_GRAM + i], v);
+      acc[i] = 0.0;
+    }
+  };
+
+  for (int c = c0; c < c1; ++c) {
+    const Chunk ch = chunks[c];
+    if (ch.link != cur_link) {
+      if (cur_link >= 0) flush(cur_link);
+      cur_link = ch.link;
+    }
+    if (lane < ch.count) {
+      const int p = ch.start + lane;
+      const double* V = s_vis + 12 * ch.link;
+      const double x0 = px[p], x1 = py[p], x2 = pz[p];
+      // point in the robot-base frame and in the field frame (gto/gto_planner.py:114-116)
+      const double y0 = V[0] * x0 + V[1] * x1 + V[2] * x2 + V[3];
+      const double y1 = V[4] * x0 + V[5] * x1 + V[6] * x2 + V[7];
+      const double y2 = V[8] * x0 + V[9] * x1 + V[10] * x2 + V[11];
+      const int ix = voxel_axis(y0 + bx, sc.ox, sc.res, sc.rinv, sc.nx);
+      const int iy = voxel_axis(y1 + by, sc.oy, sc.res, sc.rinv, sc.ny);
+      const int iz = voxel_axis(y2 + bz, sc.oz, sc.res, sc.rinv, sc.nz);
+      const int off = iz + sc.nz * (iy + sc.ny * ix);
+      const double cval = (double)field[off];
+      acc[27] += cval * cval;
+      if (need_grad) {
+        // central differences with clipped neighbours, divisor stays 2*res (gto/sdf_callback.py:90-114)
+        const int ixp = min(ix + 1, sc.nx - 1), ixm = max(ix - 1, 0);
+        const int iyp = min(iy + 1, sc.ny - 1), iym = max(iy - 1, 0);
+        const int izp = min(iz + 1, sc.nz - 1), izm = max(iz - 1, 0);
+        const int rowyz = iz + sc.nz * iy, rowx = sc.nz * (iy + sc.ny * ix);
+        const float fxp = field[rowyz + nyz * ixp], fxm = field[rowyz + nyz * ixm];
+        const float fyp = field[iz + sc.nz * (iyp + sc.ny * ix)], fym = field[iz + sc.nz * (iym + sc.ny * ix)];
+        const float fzp = field[izp + rowx], fzm = field[izm + rowx];
+        const double w0 = ((double)fxp - (double)fxm) * sc.inv2r;
+        const double w1 = ((double)fyp - (double)fym) * sc.inv2r;
+        const double w2 = ((double)fzp - (double)fzm) * sc.inv2r;
+        if (w0 != 0.0 || w1 != 0.0 || w2 != 0.0) {
+          // wrench of the gradient about the base-frame origin: (y x w, w)
+          double om[6];
+          om[0] = y1 * w2 - y2 * w1;
+          om[1] = y2 * w0 - y0 * w2;
+          om[2] = y0 * w1 - y1 * w0;
+          om[3] = w0;
+          om[4] = w1;
+          om[5] = w2;
+          int q = 0;
+#pragma unroll
+          for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = i; j < 6; ++j) acc[q++] += om[i] * om[j];
+#pragma unroll
+          for (int i = 0; i < 6; ++i) acc[21 + i] += cval * om[i];
+        }
+      }
+    }
+  }
+  if (cur_link >= 0) flush(cur_link);
+  __syncthreads();
+
+  // projection of the per-link wrench Grams onto the joint screws:
+  //   JtJ[i][j] = sum_l [i,j in anc(l)] s_i^T W_l s_j ,  Jtr[i] = sum_l [i in anc(l)] s_i . v_l
+  for (int idx = tid; idx < L * n; idx += 256) {
+    const int l = idx / n, j = idx % n;
+    const double* W = s_gram + l * GTO_GRAM;
+    const double* s = s_screw + 6 * j;
+    const bool on = (rb->link_anc[l] >> j) & 1u;
+    for (int r = 0; r < 6; ++r) {
+      double u = 0.0;
+      if (on)
+        for (int c = 0; c < 6; ++c) u += W[sym6(r, c)] * s[c];
+      s_u[(l * GTO_MAX_OPT + j) * 6 + r] = u;
+    }
+  }
+  __syncthreads();
+  for (int idx = tid; idx < L * 73; idx += 256) {
+    const int l = idx / 73, item = idx % 73;
+    const uint32_t anc = rb->link_anc[l];
+    if (item < 64) {
+      const int i = item >> 3, j = item & 7;
+      if (i < n && j < n && ((anc >> i) & 1u) && ((anc >> j) & 1u)) {
+        const double* si = s_screw + 6 * i;
+        const double* u = s_u + (l * GTO_MAX_OPT + j) * 6;
+        double v = 0.0;
+        for (int r = 0; r < 6; ++r) v += si[r] * u[r];
+        atomicAdd(&s_out[BLK_JTJ + item], v);
+      }
+    } else if (item < 72) {
+      const int i = item - 64;
+      if (i < n && ((anc >> i) & 1u)) {
+        const double* si = s_screw + 6 * i;
+        const double* vv = s_gram + l * GTO_GRAM + 21;
+        double v = 0.0;
+        for (int r = 0; r < 6; ++r) v += si[r] * vv[r];
+        atomicAdd(&s_out[BLK_JTR + i], v);
+      }
+    } else {
+      atomicAdd(&s_out[BLK_SS], s_gram[l * GTO_GRAM + 27]);
+    }
+  }
+  __syncthreads();
+  if (fixed_mode) {
+    if (tid == 0) bp.ss_fixed[2 * b + t] = s_out[BLK_SS];
+  } else {
+    double* out = bp.blocks + (((size_t)(1 - st->slot) * B + b) * T + t) * BLK_STRIDE;
+    if (tid < BLK_STRIDE) out[tid] = s_out[tid];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Goal-set terms of one trajectory (gto/gto_planner.py:84-105), closed form in the moments of the
+// gripper point cloud.  Executed by one wavefront.  gaff: [2][24] gripper+ee affines at the final
+// and the standoff waypoint; scr: [2][n][6] screws at those waypoints.
+struct GoalOut {
+  double f_goal;
+  int argmin;
+};
+
+__device__ inline void goal_target(const double* grip_ee, const double* RT16, const double* S16, double* Y) {
+  const double* Tg = grip_ee;
+  const double* Te = grip_ee + 12;
+  double inv[12], G[12], RT[12];
+  for (int r = 0; r < 3; ++r) {  // invt (optas/spatialmath.py:271-280)
+    for (int c = 0; c < 3; ++c) inv[4 * r + c] = Te[4 * c + r];
+    inv[4 * r + 3] = -(Te[r] * Te[3] + Te[4 + r] * Te[7] + Te[8 + r] * Te[11]);
+  }
+  aff_mul(inv, Tg, G);
+  for (int i = 0; i < 12; ++i) RT[i] = RT16[i];
+  if (S16) {
+    double S[12];
+    for (int i = 0; i < 12; ++i) S[i] = S16[i];
+    aff_mul(RT, S, RT);
+  }
+  aff_mul(RT, G, Y);
+}
+
+// sum_k || A p_k - Y p_k ||^2 = tr(D M D^T) + 2 d.(D mu) + K |d|^2, D = R_A - R_Y, d = t_A - t_Y
+__device__ inline double goal_cost_moments(const RobotDev* rb, const double* A, const double* Y) {
+  double D[9], d[3];
+  for (int r = 0; r < 3; ++r) {
+    for (int c = 0; c < 3; ++c) D[3 * r + c] = A[4 * r + c] - Y[4 * r + c];
+    d[r] = A[4 * r + 3] - Y[4 * r + 3];
+  }
+  double s = 0.0;
+  for (int r = 0; r < 3; ++r) {
+    double dm[3];
+    for (int c = 0; c < 3; ++c)
+      dm[c] = D[3 * r] * rb->grip_M[c] + D[3 * r + 1] * rb->grip_M[3 + c] + D[3 * r + 2] * rb->grip_M[6 + c];
+    s += dm[0] * D[3 * r] + dm[1] * D[3 * r + 1] + dm[2] * D[3 * r + 2];
+    double dmu = D[3 * r] * rb->grip_mu[0] + D[3 * r + 1] * rb->grip_mu[1] + D[3 * r + 2] * rb->grip_mu[2];
+    s += 2.0 * d[r] * dmu + rb->grip_count * d[r] * d[r];
+  }
+  return s;
+}
+
+// 6x6 Gram sum X^T X (packed upper, 21) and gradient sum X^T r (6) of the point-matching residuals
+__device__ inline void goal_gram_moments(const RobotDev* rb, const double* A, const double* Y, double* W21, double* v6) {
+  const double K = rb->grip_count;
+  double R[9], t[3], D[9], d[3];
+  for (int r = 0; r < 3; ++r) {
+    for (int c = 0; c < 3; ++c) {
+      R[3 * r + c] = A[4 * r + c];
+      D[3 * r + c] = A[4 * r + c] - Y[4 * r + c];
+    }
+    t[r] = A[4 * r + 3];
+    d[r] = A[4 * r + 3] - Y[4 * r + 3];
+  }
+  double Rmu[3], Dmu[3], RM[9], XX[9], N[9];
+  for (int r = 0; r < 3; ++r) {
+    Rmu[r] = R[3 * r] * rb->grip_mu[0] + R[3 * r + 1] * rb->grip_mu[1] + R[3 * r + 2] * rb->grip_mu[2];
+    Dmu[r] = D[3 * r] * rb->grip_mu[0] + D[3 * r + 1] * rb->grip_mu[1] + D[3 * r + 2] * rb->grip_mu[2];
+    for (int c = 0; c < 3; ++c)
+      RM[3 * r + c] = R[3 * r] * rb->grip_M[c] + R[3 * r + 1] * rb->grip_M[3 + c] + R[3 * r + 2] * rb->grip_M[6 + c];
+  }
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) {
+      // sum x x^T = R M R^T + (R mu) t^T + t (R mu)^T + K t t^T ;  N = R M D^T
+      XX[3 * r + c] = RM[3 * r] * R[3 * c] + RM[3 * r + 1] * R[3 * c + 1] + RM[3 * r + 2] * R[3 * c + 2] +
+                      Rmu[r] * t[c] + t[r] * Rmu[c] + K * t[r] * t[c];
+      N[3 * r + c] = RM[3 * r] * D[3 * c] + RM[3 * r + 1] * D[3 * c + 1] + RM[3 * r + 2] * D[3 * c + 2];
+    }
+  const double trxx = XX[0] + XX[4] + XX[8];
+  double sx[3] = {Rmu[0] + K * t[0], Rmu[1] + K * t[1], Rmu[2] + K * t[2]};
+  double W[36];
+  for (int i = 0; i < 36; ++i) W[i] = 0.0;
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) W[6 * r + c] = ((r == c) ? trxx : 0.0) - XX[3 * r + c];
+  // upper-right block [sum x]_x
+  W[6 * 0 + 4] = -sx[2];
+  W[6 * 0 + 5] = sx[1];
+  W[6 * 1 + 3] = sx[2];
+  W[6 * 1 + 5] = -sx[0];
+  W[6 * 2 + 3] = -sx[1];
+  W[6 * 2 + 4] = sx[0];
+  W[6 * 3 + 3] = W[6 * 4 + 4] = W[6 * 5 + 5] = K;
+  for (int i = 0; i < 6; ++i)
+    for (int j = i; j < 6; ++j) W21[sym6(i, j)] = W[6 * i + j];
+  // sum x x r = eps(N) + (R mu) x d + t x (D mu) + K t x d ;  sum r = D mu + K d
+  double c1[3], c2[3], c3[3];
+  cross3(Rmu, d, c1);
+  cross3(t, Dmu, c2);
+  cross3(t, d, c3);
+  v6[0] = (N[5] - N[7]) + c1[0] + c2[0] + K * c3[0];
+  v6[1] = (N[6] - N[2]) + c1[1] + c2[1] + K * c3[1];
+  v6[2] = (N[1] - N[3]) + c1[2] + c2[2] + K * c3[2];
+  v6[3] = Dmu[0] + K * d[0];
+  v6[4] = Dmu[1] + K * d[1];
+  v6[5] = Dmu[2] + K * d[2];
+}
+
+// One wavefront.  s_gaff [2][24], s_gscr [2][GTO_MAX_OPT*6] in LDS.  goalblk_out: [2][BLK_STRIDE] or null.
+__device__ inline GoalOut goal_terms_wave(const RobotDev* rb, const SolveParams& sp, const double* goals, int n_goals,
+                                          const double* standoff, const double* s_gaff, const double* s_gscr,
+                                          double* goalblk_out, int lane) {
+  // cost of every goal in the set, lanes stride over goals
+  double best = INFINITY;
+  int besti = 0x7fffffff;
+  for (int g = lane; g < n_goals; g += 64) {
+    double Y[12];
+    goal_target(s_gaff, goals + 16 * g, nullptr, Y);
+    double c = goal_cost_moments(rb, s_gaff, Y);
+    if (sp.use_standoff) {
+      goal_target(s_gaff + 24, goals + 16 * g, standoff, Y);
+      c += goal_cost_moments(rb, s_gaff + 24, Y);
+    }
+    if (c < best) {
+      best = c;
+      besti = g;
+    }
+  }
+  // first minimum over the wave (optas.mmin, gto/gto_planner.py:105)
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    double ob = __shfl_xor(best, o, 64);
+    int oi = __shfl_xor(besti, o, 64);
+    if (ob < best || (ob == best && oi < besti)) {
+      best = ob;
+      besti = oi;
+    }
+  }
+  GoalOut out;
+  out.f_goal = best;
+  out.argmin = besti;
+  if (goalblk_out) {
+    const int n = rb->n_opt;
+    const uint32_t anc = rb->frame_anc[rb->frame_gripper];
+    for (int which = 0; which < 2; ++which) {
+      double* blk = goalblk_out + which * BLK_STRIDE;
+      if (which == 1 && !sp.use_standoff) {
+        for (int i = lane; i < BLK_STRIDE; i += 64) blk[i] = 0.0;
+        continue;
+      }
+      double Y[12], W21[21], v6[6];
+      goal_target(s_gaff + 24 * which, goals + 16 * besti, which ? standoff : nullptr, Y);
+      goal_gram_moments(rb, s_gaff + 24 * which, Y, W21, v6);
+      const double* S = s_gscr + which * GTO_MAX_OPT * 6;
+      const int i = lane >> 3, j = lane & 7;
+      double v = 0.0;
+      if (i < n && j < n && ((anc >> i) & 1u) && ((anc >> j) & 1u)) {
+        for (int r = 0; r < 6; ++r) {
+          double u = 0.0;
+          for (int c = 0; c < 6; ++c) u += W21[sym6(r, c)] * S[6 * j + c];
+          v += S[6 * i + r] * u;
+        }
+      }
+      blk[BLK_JTJ + lane] = v;
+      if (lane < 8) {
+        double g = 0.0;
+        if (lane < n && ((anc >> lane) & 1u))
+          for (int r = 0; r < 6; ++r) g += S[6 * lane + r] * v6[r];
+        blk[BLK_JTR + lane] = g;
+      }
+    }
+  }
+  return out;
+}
+
+// Kinematics of the trial trajectory + goal terms + velocity term; one wavefront per instance.
+// Writes vis / screw for the obstacle kernel and fgoal_try / fvel_try / goal blocks (trial slot).
+__device__ inline void trial_kinematics_wave(const RobotDev* rb, const BatchPtrs& bp, const SolveParams& sp, int B,
+                                             int b, int lane, int trial, InstState* st, double* s_gaff, double* s_gscr) {
+  const int T = sp.T, n = rb->n_opt, L = rb->n_links;
+  const double* Q0b = bp.Q0 + (size_t)b * rb->ndof * T;
+  const double* Qt = bp.Qtry + (size_t)b * n * T;
+  for (int t = lane; t < T; t += 64) {
+    double q[GTO_MAX_DOF], ge[24];
+    load_full_q(rb, Q0b, Qt, T, t, q);
+    double* vis = bp.vis + ((size_t)b * T + t) * L * 12;
+    double* scr = bp.screw + ((size_t)b * T + t) * n * 6;
+    const bool isg = (t == T - 1), iss = (sp.use_standoff && t == sp.ts);
+    kin_eval(rb, q, vis, scr, (isg || iss) ? ge : nullptr);
+    if (isg) {
+      for (int k = 0; k < 24; ++k) s_gaff[k] = ge[k];
+      for (int k = 0; k < n * 6; ++k) s_gscr[k] = scr[k];
+    }
+    if (iss) {
+      for (int k = 0; k < 24; ++k) s_gaff[24 + k] = ge[k];
+      for (int k = 0; k < n * 6; ++k) s_gscr[GTO_MAX_OPT * 6 + k] = scr[k];
+    }
+  }
+  __syncthreads();
+  double* gblk = bp.goalblk + ((size_t)trial * B + b) * 2 * BLK_STRIDE;
+  GoalOut go = goal_terms_wave(rb, sp, bp.goals + (size_t)b * sp.n_max * 16, bp.n_goals[b],
+                               bp.standoff ? bp.standoff + (size_t)b * 16 : nullptr, s_gaff, s_gscr, gblk, lane);
+  // velocity term with eliminated velocities (gto/gto_planner.py:133-135)
+  double fv = 0.0;
+  for (int idx = lane; idx < n * (T - 2); idx += 64) {
+    const int j = idx / (T - 2), t = 1 + idx % (T - 2);
+    const double v = (Qt[(size_t)j * T + t + 1] - Qt[(size_t)j * T + t]) / sp.dt;
+    fv += v * v;
+  }
+  fv = wave_sum(fv);
+  if (lane == 0) {
+    st->fgoal_try = go.f_goal;
+    st->fvel_try = sp.w_vel * fv;
+    st->argmin_try = go.argmin;
+  }
+}
+
+// raw != 0: take Q0's optimised rows as they are (evaluation entry points); otherwise build the seed.
+__global__ __launch_bounds__(64) void k_lm_init(const RobotDev* __restrict__ rb, BatchPtrs bp, SolveParams sp, int B, int raw) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  __shared__ double s_gaff[48];
+  __shared__ double s_gscr[2 * GTO_MAX_OPT * 6];
+  const int T = sp.T, n = rb->n_opt;
+  InstState* st = bp.state + b;
+  if (lane == 0) {
+    st->f = INFINITY;
+    st->lambda = sp.lambda0;
+    st->nu = 2.0;
+    st->pred = 0.0;
+    st->slot = 0;
+    st->first = 1;
+    st->done = 0;
+    st->status = GTO_STATUS_MAX_ITER;
+    st->evals = 0;
+    st->argmin_cur = 0;
+  }
+  // seed: optimised rows of Q0, first two waypoints pinned to qc, the rest clipped into the bounds
+  const double* Q0b = bp.Q0 + (size_t)b * rb->ndof * T;
+  double* Qt = bp.Qtry + (size_t)b * n * T;
+  double* Qc = bp.Qcur + (size_t)b * n * T;
+  for (int idx = lane; idx < n * T; idx += 64) {
+    const int j = idx / T, t = idx % T;
+    double v = Q0b[(size_t)rb->opt_index[j] * T + t];
+    if (!raw) {
+      if (t < 2) v = bp.qc[(size_t)b * rb->ndof + rb->opt_index[j]];
+      else v = fmin(fmax(v, rb->lower[j]), rb->upper[j]);
+    }
+    Qt[idx] = v;
+    Qc[idx] = v;
+  }
+  __syncthreads();
+  trial_kinematics_wave(rb, bp, sp, B, b, lane, 1, st, s_gaff, s_gscr);
+}
+
+// dynamic LDS layout of k_lm_step (doubles): Z [m][64] | bfull [m][8] | rhs/y [m][8] | e [m][8] |
+// x [m][8] | Q [8][T] | tile [64] | zv [8] | gaff [48] | gscr [96];  act flags reuse the e array sign.
+__global__ __launch_bounds__(64) void k_lm_step(const RobotDev* __restrict__ rb, BatchPtrs bp, SolveParams sp, int B) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  InstState* st = bp.state + b;
+  if (st->done) return;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int T = sp.T, n = rb->n_opt, m = T - 2;
+  double* s_Z = smem;
+  double* s_b = s_Z + (size_t)m * 64;
+  double* s_y = s_b + m * 8;
+  double* s_e = s_y + m * 8;
+  double* s_x = s_e + m * 8;
+  double* s_Q = s_x + m * 8;
+  double* s_tile = s_Q + 8 * T;
+  double* s_zv = s_tile + 64;
+  double* s_gaff = s_zv + 8;
+  double* s_gscr = s_gaff + 48;
+  int* s_act = (int*)(s_gscr + 2 * GTO_MAX_OPT * 6);  // [m][8]
+
+  const int r = lane >> 3, c = lane & 7;
+  const int trial = 1 - st->slot;
+
+  // ---- P0: objective of the trial point
+  double fo = 0.0;
+  {
+    const double* blk = bp.blocks + ((size_t)trial * B + b) * T * BLK_STRIDE;
+    for (int t = 2 + lane; t < T; t += 64) fo += blk[(size_t)t * BLK_STRIDE + BLK_SS];
+    fo = wave_sum(fo);
+    fo += bp.ss_fixed[2 * b] + bp.ss_fixed[2 * b + 1];
+  }
+  const double f_try = st->fgoal_try + sp.w_obstacle * fo + st->fvel_try;
+
+  // ---- P1: accept / reject (all lanes take the same branch: inputs are wave-uniform)
+  double f = st->f, lambda = st->lambda, nu = st->nu;
+  int slot = st->slot, done = 0, status = st->status;
+  const int k = st->evals;
+  bool accept = false;
+  if (st->first) {
+    accept = true;
+  } else if (f_try < f && st->pred > 0.0) {
+    accept = true;
+    const double df = f - f_try, rho = df / st->pred;
+    const double s = 2.0 * rho - 1.0;
+    double fac = 1.0 - s * s * s;
+    fac = fmax(fac, 1.0 / 3.0);
+    lambda = fmax(lambda * fac, 1e-12);
+    nu = 2.0;
+    if (df <= sp.tol_rel_f * (1.0 + f_try)) {
+      status = GTO_STATUS_CONVERGED;
+      done = 1;
+    }
+  } else {
+    lambda *= nu;
+    nu *= 2.0;
+    if (lambda > 1e15) {
+      status = GTO_STATUS_CONVERGED;
+      done = 1;
+    }
+  }
+  double* Qc = bp.Qcur + (size_t)b * n * T;
+  double* Qt = bp.Qtry + (size_t)b * n * T;
+  if (accept) {
+    for (int idx = lane; idx < n * T; idx += 64) Qc[idx] = Qt[idx];
+    f = f_try;
+    slot = trial;
+  }
+  if (!done && k >= sp.max_iter) {
+    status = GTO_STATUS_MAX_ITER;
+    done = 1;
+  }
+  __syncthreads();
+  if (done) {
+    if (lane == 0) {
+      st->f = f;
+      st->lambda = lambda;
+      st->nu = nu;
+      st->slot = slot;
+      st->first = 0;
+      st->done = 1;
+      st->status = status;
+      if (accept) st->argmin_cur = st->argmin_try;
+    }
+    return;
+  }
+
+  // ---- P2: normal equations at the current iterate (A = J^T J, b = J^T r; f = sum r^2)
+  for (int idx = lane; idx < 8 * T; idx += 64) {
+    const int j = idx / T;
+    s_Q[idx] = (j < n) ? Qc[(size_t)j * T + idx % T] : 0.0;
+  }
+  __syncthreads();
+  const double* oblk = bp.blocks + ((size_t)slot * B + b) * T * BLK_STRIDE;
+  const double* gblk = bp.goalblk + ((size_t)slot * B + b) * 2 * BLK_STRIDE;
+  const double alpha = sp.alpha;
+  // undamped diagonal block entry A_t[r][c]
+  auto A_entry = [&](int t, int rr, int cc) -> double {
+    if (rr >= n || cc >= n) return 0.0;
+    double v = sp.w_obstacle * oblk[(size_t)t * BLK_STRIDE + BLK_JTJ + rr * 8 + cc];
+    if (t == T - 1) v += gblk[BLK_JTJ + rr * 8 + cc];
+    if (sp.use_standoff && t == sp.ts) v += gblk[BLK_STRIDE + BLK_JTJ + rr * 8 + cc];
+    if (rr == cc) v += (t < T - 1) ? 2.0 * alpha : alpha;
+    return v;
+  };
+  for (int idx = lane; idx < m * 8; idx += 64) {
+    const int s = idx >> 3, i = idx & 7, t = s + 2;
+    double bv = 0.0;
+    int act = 1;
+    if (i < n) {
+      bv = sp.w_obstacle * oblk[(size_t)t * BLK_STRIDE + BLK_JTR + i];
+      if (t == T - 1) bv += gblk[BLK_JTR + i];
+      if (sp.use_standoff && t == sp.ts) bv += gblk[BLK_STRIDE + BLK_JTR + i];
+      const double qt = s_Q[i * T + t], qm = s_Q[i * T + t - 1];
+      bv += alpha * (qt - qm);
+      if (t < T - 1) bv -= alpha * (s_Q[i * T + t + 1] - qt);
+      // active set: on a bound with the descent direction pointing outward
+      act = (qt <= rb->lower[i] && bv > 0.0) || (qt >= rb->upper[i] && bv < 0.0);
+    }
+    s_b[idx] = bv;
+    s_act[idx] = act;  // padded rows count as frozen
+  }
+  __syncthreads();
+  for (int s = 0; s < m; ++s) {
+    const int t = s + 2;
+    double v = A_entry(t, r, c);
+    const int ar = s_act[s * 8 + r], ac = s_act[s * 8 + c];
+    if (ar || ac) v = (r == c) ? 1.0 : 0.0;
+    else if (r == c) v *= (1.0 + lambda);
+    s_Z[(size_t)s * 64 + lane] = v;
+  }
+  for (int idx = lane; idx < m * 8; idx += 64) {
+    const int s = idx >> 3, i = idx & 7;
+    const int a0 = s_act[idx];
+    const int a1 = (s < m - 1) ? s_act[idx + 8] : 1;
+    s_e[idx] = (a0 || a1) ? 0.0 : -alpha;
+    s_y[idx] = a0 ? 0.0 : -s_b[idx];  // right-hand side
+    (void)i;
+  }
+  __syncthreads();
+
+  // ---- P3: block-tridiagonal solve, inverse-based Schur recursion (one 8x8 block per step,
+  // lane (r,c) owns entry (r,c); Gauss-Jordan without pivoting: the blocks are SPD)
+  int fail = 0;
+  double Zprev = 0.0;
+  for (int s = 0; s < m; ++s) {
+    double S = s_Z[(size_t)s * 64 + lane];
+    if (s > 0) {
+      S -= s_e[(s - 1) * 8 + r] * s_e[(s - 1) * 8 + c] * Zprev;
+      // z_s = rhs_s - e_{s-1} o y_{s-1}
+      if (lane < 8) s_y[s * 8 + lane] -= s_e[(s - 1) * 8 + lane] * s_x[(s - 1) * 8 + lane];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      s_tile[lane] = S;
+      __syncthreads();
+      const double pjj = s_tile[j * 9], prj = s_tile[r * 8 + j], pjc = s_tile[j * 8 + c];
+      __syncthreads();
+      if (!(pjj > 0.0)) fail = 1;
+      const double piv = 1.0 / pjj;
+      if (r == j && c == j) S = piv;
+      else if (r == j) S = pjc * piv;
+      else if (c == j) S = -prj * piv;
+      else S = S - prj * pjc * piv;
+    }
+    s_Z[(size_t)s * 64 + lane] = S;  // Z_s = S_s^{-1}
+    Zprev = S;
+    // y_s = Z_s z_s  (kept in s_x as scratch during the forward sweep)
+    double pr = S * s_y[s * 8 + c];
+    pr += __shfl_xor(pr, 1, 64);
+    pr += __shfl_xor(pr, 2, 64);
+    pr += __shfl_xor(pr, 4, 64);
+    if (c == 0) s_x[s * 8 + r] = pr;
+    __syncthreads();
+  }
+  if (__any(fail)) {
+    if (lane == 0) {
+      st->f = f;
+      st->slot = slot;
+      st->first = 0;
+      st->done = 1;
+      st->status = GTO_STATUS_NUMERICAL;
+      if (accept) st->argmin_cur = st->argmin_try;
+    }
+    return;
+  }
+  // backward sweep: x_s = y_s - Z_s (e_s o x_{s+1})
+  for (int s = m - 2; s >= 0; --s) {
+    double pr = s_Z[(size_t)s * 64 + lane] * (s_e[s * 8 + c] * s_x[(s + 1) * 8 + c]);
+    pr += __shfl_xor(pr, 1, 64);
+    pr += __shfl_xor(pr, 2, 64);
+    pr += __shfl_xor(pr, 4, 64);
+    __syncthreads();
+    if (c == 0) s_x[s * 8 + r] -= pr;
+    __syncthreads();
+  }
+
+  // ---- P4: projected trial point
+  double maxstep = 0.0;
+  for (int idx = lane; idx < m * 8; idx += 64) {
+    const int s = idx >> 3, i = idx & 7, t = s + 2;
+    double sv = 0.0;
+    if (i < n) {
+      const double q0 = s_Q[i * T + t];
+      double v = q0 + s_x[idx];
+      v = fmin(fmax(v, rb->lower[i]), rb->upper[i]);
+      Qt[(size_t)i * T + t] = v;
+      sv = v - q0;
+    }
+    s_x[idx] = sv;  // actual (projected) step
+    maxstep = fmax(maxstep, fabs(sv));
+  }
+  for (int idx = lane; idx < n * 2; idx += 64) Qt[(size_t)(idx >> 1) * T + (idx & 1)] = s_Q[(idx >> 1) * T + (idx & 1)];
+  maxstep = wave_max(maxstep);
+  __syncthreads();
+  if (maxstep < sp.tol_step) {
+    if (lane == 0) {
+      st->f = f;
+      st->lambda = lambda;
+      st->nu = nu;
+      st->slot = slot;
+      st->first = 0;
+      st->done = 1;
+      st->status = GTO_STATUS_CONVERGED;
+      if (accept) st->argmin_cur = st->argmin_try;
+    }
+    return;
+  }
+  // ---- P5: predicted decrease of the undamped model: -(2 b.s + s^T A s)
+  double acc = 0.0;
+  for (int s = 0; s < m; ++s) {
+    const int t = s + 2;
+    const double sr = s_x[s * 8 + r], scv = s_x[s * 8 + c];
+    double v = A_entry(t, r, c) * sr * scv;
+    if (c == 0) {
+      v += 2.0 * s_b[s * 8 + r] * sr;
+      if (s < m - 1) v += 2.0 * (-alpha) * sr * s_x[(s + 1) * 8 + r];
+    }
+    acc += v;
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) {
+    st->f = f;
+    st->lambda = lambda;
+    st->nu = nu;
+    st->pred = -acc;
+    st->slot = slot;
+    st->first = 0;
+    st->status = status;
+    st->evals = k + 1;
+    if (accept) st->argmin_cur = st->argmin_try;
+  }
+  __syncthreads();
+  // ---- P6: kinematics + goal terms of the new trial
+  trial_kinematics_wave(rb, bp, sp, B, b, lane, 1 - slot, st, s_gaff, s_gscr);
+}
+
+__global__ __launch_bounds__(64) void k_lm_finalize(const RobotDev* __restrict__ rb, BatchPtrs bp, SolveParams sp, int B,
+                                                    double* Q_out, double* dQ_out, double* cost_out,
+                                                    int32_t* iters_out, int32_t* status_out) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const int T = sp.T, n = rb->n_opt, ndof = rb->ndof;
+  const InstState* st = bp.state + b;
+  const double* Q0b = bp.Q0 + (size_t)b * ndof * T;
+  const double* Qc = bp.Qcur + (size_t)b * n * T;
+  if (Q_out) {
+    double* Qo = Q_out + (size_t)b * ndof * T;
+    for (int idx = lane; idx < ndof * T; idx += 64) Qo[idx] = Q0b[idx];  // parameter rows (optas/solver.py:151-153)
+    __syncthreads();
+    for (int idx = lane; idx < n * T; idx += 64) Qo[(size_t)rb->opt_index[idx / T] * T + idx % T] = Qc[idx];
+  }
+  if (dQ_out) {
+    double* dQo = dQ_out + (size_t)b * ndof * (T - 1);
+    for (int idx = lane; idx < ndof * (T - 1); idx += 64) dQo[idx] = 0.0;
+    __syncthreads();
+    for (int idx = lane; idx < n * (T - 2); idx += 64) {
+      const int j = idx / (T - 2), t = 1 + idx % (T - 2);
+      dQo[(size_t)rb->opt_index[j] * (T - 1) + t] = (Qc[(size_t)j * T + t + 1] - Qc[(size_t)j * T + t]) / sp.dt;
+    }
+  }
+  if (lane == 0) {
+    if (cost_out) cost_out[b] = st->f;
+    if (iters_out) iters_out[b] = st->evals;
+    if (status_out) status_out[b] = st->status;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Evaluation kernels (parity / seed scoring entry points)
+__global__ void k_eval_fk(const RobotDev* __restrict__ rb, int nq, const double* __restrict__ q, double* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nq) return;
+  double frames[GTO_MAX_FRAMES * 12];
+  fk_frames(rb, q + (size_t)i * rb->ndof, frames);
+  for (int f = 0; f < rb->n_frames; ++f) {
+    double* o = out + ((size_t)i * rb->n_frames + f) * 16;
+    for (int k = 0; k < 12; ++k) o[k] = frames[12 * f + k];
+    o[12] = o[13] = o[14] = 0.0;
+    o[15] = 1.0;
+  }
+}
+
+__global__ void k_eval_kin(const RobotDev* __restrict__ rb, int nq, const double* __restrict__ q, double* __restrict__ vis) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nq) return;
+  kin_eval(rb, q + (size_t)i * rb->ndof, vis + (size_t)i * rb->n_links * 12, nullptr, nullptr);
+}
+
+// thread per (configuration, sorted point); outputs in the caller's original point order via perm
+__global__ void k_eval_points(const RobotDev* __restrict__ rb, const double* __restrict__ px, const double* __restrict__ py,
+                              const double* __restrict__ pz, const int32_t* __restrict__ plink,
+                              const int32_t* __restrict__ perm, const SceneDev* __restrict__ scene, int nq,
+                              const double* __restrict__ vis, const double* __restrict__ base, int use_obs,
+                              double* xyz_out, int32_t* off_out, double* val_out, double* grad_out) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  const int iq = blockIdx.y;
+  const int P = rb->n_points;
+  if (p >= P) return;
+  const double* V = vis + ((size_t)iq * rb->n_links + plink[p]) * 12;
+  const double x0 = px[p], x1 = py[p], x2 = pz[p];
+  const double X0 = V[0] * x0 + V[1] * x1 + V[2] * x2 + V[3] + base[3 * iq];
+  const double X1 = V[4] * x0 + V[5] * x1 + V[6] * x2 + V[7] + base[3 * iq + 1];
+  const double X2 = V[8] * x0 + V[9] * x1 + V[10] * x2 + V[11] + base[3 * iq + 2];
+  const size_t o = (size_t)iq * P + perm[p];
+  if (xyz_out) {
+    xyz_out[3 * o] = X0;
+    xyz_out[3 * o + 1] = X1;
+    xyz_out[3 * o + 2] = X2;
+  }
+  if (!scene) return;
+  const SceneDev sc = *scene;
+  const float* field = use_obs ? sc.c_obs : sc.c_all;
+  const int ix = voxel_axis(X0, sc.ox, sc.res, sc.rinv, sc.nx);
+  const int iy = voxel_axis(X1, sc.oy, sc.res, sc.rinv, sc.ny);
+  const int iz = voxel_axis(X2, sc.oz, sc.res, sc.rinv, sc.nz);
+  const int off = iz + sc.nz * (iy + sc.ny * ix);
+  if (off_out) off_out[o] = off;
+  if (val_out) val_out[o] = (double)field[off];
+  if (grad_out) {
+    const int ixp = min(ix + 1, sc.nx - 1), ixm = max(ix - 1, 0);
+    const int iyp = min(iy + 1, sc.ny - 1), iym = max(iy - 1, 0);
+    const int izp = min(iz + 1, sc.nz - 1), izm = max(iz - 1, 0);
+    grad_out[3 * o] = ((double)field[iz + sc.nz * (iy + sc.ny * ixp)] - (double)field[iz + sc.nz * (iy + sc.ny * ixm)]) * sc.inv2r;
+    grad_out[3 * o + 1] = ((double)field[iz + sc.nz * (iyp + sc.ny * ix)] - (double)field[iz + sc.nz * (iym + sc.ny * ix)]) * sc.inv2r;
+    grad_out[3 * o + 2] = ((double)field[izp + sc.nz * (iy + sc.ny * ix)] - (double)field[izm + sc.nz * (iy + sc.ny * ix)]) * sc.inv2r;
+  }
+}
+
+// compute_plan_cost (gto/gto_models.py:204-215): block per (plan, waypoint), plain sum of c_obs
+__global__ __launch_bounds__(256) void k_plan_cost(const RobotDev* __restrict__ rb, const double* __restrict__ px,
+                                                   const double* __restrict__ py, const double* __restrict__ pz,
+                                                   const int32_t* __restrict__ plink, const SceneDev* __restrict__ scene,
+                                                   int T, const double* __restrict__ plans, const double* __restrict__ base,
+                                                   double* __restrict__ partial /*[n][T]*/) {
+  const int t = blockIdx.x, i = blockIdx.y, tid = threadIdx.x;
+  __shared__ double s_vis[GTO_MAX_LINKS * 12];
+  __shared__ double s_red[4];
+  if (tid == 0) {
+    double q[GTO_MAX_DOF];
+    for (int j = 0; j < rb->ndof; ++j) q[j] = plans[((size_t)i * rb->ndof + j) * T + t];
+    kin_eval(rb, q, s_vis, nullptr, nullptr);
+  }
+  __syncthreads();
+  const SceneDev sc = *scene;
+  double acc = 0.0;
+  for (int p = tid; p < rb->n_points; p += 256) {
+    const double* V = s_vis + 12 * plink[p];
+    const double x0 = px[p], x1 = py[p], x2 = pz[p];
+    const int ix = voxel_axis(V[0] * x0 + V[1] * x1 + V[2] * x2 + V[3] + base[0], sc.ox, sc.res, sc.rinv, sc.nx);
+    const int iy = voxel_axis(V[4] * x0 + V[5] * x1 + V[6] * x2 + V[7] + base[1], sc.oy, sc.res, sc.rinv, sc.ny);
+    const int iz = voxel_axis(V[8] * x0 + V[9] * x1 + V[10] * x2 + V[11] + base[2], sc.oz, sc.res, sc.rinv, sc.nz);
+    acc += (double)sc.c_obs[iz + sc.nz * (iy + sc.ny * ix)];
+  }
+  acc = wave_sum(acc);
+  if ((tid & 63) == 0) s_red[tid >> 6] = acc;
+  __syncthreads();
+  if (tid == 0) partial[(size_t)i * T + t] = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+}

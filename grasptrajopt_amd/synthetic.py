@@ -1,0 +1,132 @@
+"""Seeded synthetic problem instances for benchmarking and parity tests.
+
+No SceneReplica data is available (reference .gitignore:1), so scenes are a table slab plus a few
+random boxes/spheres voxelised on a grid that covers the arm's reach box; the signed distance is
+mapped to the reference's cost exactly as DepthPointCloud.get_sdf_cost does
+(mesh_to_sdf/depth_point_cloud.py:84-89, float32 arithmetic), and ``c_obs`` is the same field with
+the target object removed (examples/pybullet_gto_planning.py:181-190).
+This is input generation (host, numpy); it is not part of the solve path.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Callable, Optional, Tuple
+
+import numpy as np
+
+
+@dataclass
+class Scene:
+    c_all: np.ndarray    # (N0*N1*N2,) float32, C order (x slowest)
+    c_obs: np.ndarray
+    shape: Tuple[int, int, int]
+    origin: np.ndarray   # (3,)
+    res: float
+    objects: list
+
+
+def sdf_cost_map(signed_dist: np.ndarray, epsilon: float = 0.02, w_inside: float = 1.0) -> np.ndarray:
+    """mesh_to_sdf/depth_point_cloud.py:84-89 on float32 arrays (inside <=> negative distance)."""
+    d = signed_dist.astype(np.float32)
+    cost = np.zeros_like(d)
+    inside = d < 0
+    cost[inside] = np.float32(w_inside) * (-d[inside] + np.float32(epsilon) / np.float32(2))
+    idx = (d > 0) & (d < np.float32(epsilon))
+    cost[idx] = np.square(d[idx] - np.float32(epsilon)) / np.float32(2 * epsilon)
+    return cost
+
+
+def _box_sdf(p, c, h):
+    q = np.abs(p - c) - h
+    return np.linalg.norm(np.maximum(q, 0.0), axis=-1) + np.minimum(q.max(axis=-1), 0.0)
+
+
+def _sphere_sdf(p, c, r):
+    return np.linalg.norm(p - c, axis=-1) - r
+
+
+def make_scene(seed: int, n: int = 128, res: float = 0.0175,
+               origin=(-0.4, -1.12, -0.4), table_z: float = -0.03) -> Scene:
+    """Table slab below ``table_z`` + K in [3,8] random boxes/spheres standing on it."""
+    rng = np.random.default_rng(1000 + seed)
+    origin = np.asarray(origin, dtype=np.float64)
+    ax = [origin[a] + res * np.arange(n) for a in range(3)]
+    k = int(rng.integers(3, 9))
+    objects = []
+    for i in range(k):
+        cx, cy = rng.uniform(0.3, 0.8), rng.uniform(-0.5, 0.5)
+        if rng.random() < 0.6:
+            h = rng.uniform([0.03, 0.03, 0.04], [0.08, 0.08, 0.15])
+            objects.append(("box", np.array([cx, cy, table_z + h[2]]), h))
+        else:
+            r = rng.uniform(0.03, 0.07)
+            objects.append(("sphere", np.array([cx, cy, table_z + r]), r))
+    target = int(rng.integers(0, k))
+
+    def field(skip: Optional[int]) -> np.ndarray:
+        out = np.empty((n, n, n), dtype=np.float32)
+        Y, Z = np.meshgrid(ax[1], ax[2], indexing="ij")
+        for ix in range(n):  # one x-slab at a time keeps memory small
+            p = np.stack([np.full_like(Y, ax[0][ix]), Y, Z], axis=-1)
+            d = p[..., 2] - table_z  # half-space z < table_z
+            for j, (kind, c, s) in enumerate(objects):
+                if j == skip:
+                    continue
+                d = np.minimum(d, _box_sdf(p, c, s) if kind == "box" else _sphere_sdf(p, c, s))
+            out[ix] = d.astype(np.float32)
+        return out
+
+    c_all = sdf_cost_map(field(None)).reshape(-1)
+    c_obs = sdf_cost_map(field(target)).reshape(-1)
+    return Scene(c_all=c_all, c_obs=c_obs, shape=(n, n, n), origin=origin, res=res,
+                 objects=[(kd, c.tolist(), (s.tolist() if kd == "box" else float(s))) for kd, c, s in objects]
+                 + [("target", target)])
+
+
+def standoff_pose(offset: float, axis: str) -> np.ndarray:
+    """optas/spatialmath.py:160-183 standoff()."""
+    S = np.eye(4)
+    S["xyz".index(axis), 3] = offset
+    return S
+
+
+def interpolate_waypoints(waypoints: np.ndarray, n: int, m: int) -> np.ndarray:
+    """gto/utils.py:63-82 for the planner's two-waypoint call: clamped cubic through the two
+    configurations, sampled at linspace(0,1,n+2)[1:-1].  Returns (n, m)."""
+    w = np.asarray(waypoints, dtype=np.float64)
+    if w.shape[0] != 2:
+        raise NotImplementedError("only the two-waypoint call made by GTOPlanner is supported")
+    s = np.arange(1, n + 1, dtype=np.float64) / (n + 1)
+    h = s * s * (3.0 - 2.0 * s)
+    return w[0][None, :] + (w[1] - w[0])[None, :] * h[:, None]
+
+
+def make_goals(desc, fk: Callable[[np.ndarray], np.ndarray], link_ee: str, n_goals: int, seed: int,
+               xlim=(0.25, 0.75), ylim=(-0.5, 0.5), zlim=(0.08, 0.7)):
+    """Sample in-limit configurations q* whose end-effector lies in a box above the table;
+    goal pose RT = FK(q*).  ``fk(q) -> (nq, n_frames, 4, 4)``.  Returns (RT (n,4,4), q* (n,ndof))."""
+    rng = np.random.default_rng(5000 + seed)
+    lo = np.maximum(desc.lower, -3.0)
+    hi = np.minimum(desc.upper, 3.0)
+    fe = desc.frame_index(link_ee)
+    RTs, qs = [], []
+    while len(RTs) < n_goals:
+        q = rng.uniform(lo, hi, size=(4 * n_goals, desc.ndof))
+        q[:, desc.param_index] = 0.0
+        T = fk(q)[:, fe]
+        p = T[:, :3, 3]
+        ok = ((p[:, 0] > xlim[0]) & (p[:, 0] < xlim[1]) & (p[:, 1] > ylim[0]) & (p[:, 1] < ylim[1])
+              & (p[:, 2] > zlim[0]) & (p[:, 2] < zlim[1]))
+        for i in np.nonzero(ok)[0]:
+            if len(RTs) < n_goals:
+                RTs.append(T[i])
+                qs.append(q[i])
+    return np.stack(RTs), np.stack(qs)
+
+
+def make_seed(qc: np.ndarray, q_goal: np.ndarray, T: int, param_index) -> np.ndarray:
+    """Seed trajectory as GTOPlanner.plan builds it (gto/gto_planner.py:155-158): interpolate
+    qc -> q_goal, parameter joints held at qc.  Returns (ndof, T)."""
+    data = interpolate_waypoints(np.stack([qc, q_goal]), T, qc.shape[0])
+    data[:, param_index] = np.asarray(qc)[param_index]
+    return data.T.copy()

@@ -1,0 +1,254 @@
+"""GPU: parity of the HIP path (through the C ABI) with the CPU oracle and the golden fixtures.
+
+Tolerances (stated here once):
+  * integer work (voxel offsets, arg-min goal, iteration counts, status): bit-exact;
+  * nearest-voxel cost values: exact (same float32 promoted to float64);
+  * FK / points / gradients: 1e-12 absolute (FP64 on both sides; libm vs ocml sin/cos and FMA
+    contraction differ by a few ulp);
+  * Gauss-Newton blocks and objective terms: 1e-10 relative (different summation order);
+  * solved trajectories after the same number of iterations: 1e-6 rad (north_star / SURVEY.md 8d).
+"""
+import numpy as np
+import pytest
+
+from conftest import golden
+from helpers import Problem, cfg_of, point_cloud_robot
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def capi():
+    import __graft_entry__ as g
+    g.build()
+    from grasptrajopt_amd import _capi
+    return _capi
+
+
+def make_pair(capi, oracle_mod, prob, **opt_kw):
+    opts = oracle_mod.reference_opts(**opt_kw)
+    h = capi.SolverHandle(prob.desc, prob.cfg["link_ee"], prob.cfg["link_gripper"], opts, device=0)
+    o = oracle_mod.Oracle(prob.desc, prob.cfg["link_ee"], prob.cfg["link_gripper"], opts)
+    prob.finish(h.eval_fk)
+    h.set_scene(*prob.scene_args())
+    o.set_scene(*prob.scene_args())
+    return h, o
+
+
+# ------------------------------------------------------------------------------------------ FK
+@pytest.mark.parametrize("robot", ["panda", "fetch"])
+def test_fk_matches_golden_and_oracle(capi, oracle_mod, robot):
+    g = golden(f"fk_{robot}.npz")
+    cfg = cfg_of(robot)
+    from grasptrajopt_amd.robot_desc import load_builtin
+    d = load_builtin(robot)
+    h = capi.SolverHandle(d, cfg["link_ee"], cfg["link_gripper"], device=0)
+    frames = h.eval_fk(g["q"])
+    names = [str(s) for s in g["link_names"]]
+    for j, fn in enumerate(d.frame_names):
+        np.testing.assert_allclose(frames[:, j], g["frames"][:, names.index(fn)], rtol=0, atol=1e-13, err_msg=fn)
+    o = oracle_mod.Oracle(d, cfg["link_ee"], cfg["link_gripper"])
+    np.testing.assert_allclose(frames, o.eval_fk(g["q"]), rtol=0, atol=1e-13)
+    # world surface points = visual_tf @ p (gto/gto_models.py:104-121) against the golden visual_tf
+    xyz, _, _, _ = h.eval_points(0, g["q"][:4], [0.1, -0.2, 0.3], want_field=False)
+    for i in range(4):
+        for l in range(d.n_links):
+            V = g["visual"][i, l]
+            p = d.points[d.point_link == l]
+            ref = p @ V[:3, :3].T + V[:3, 3] + np.array([0.1, -0.2, 0.3])
+            np.testing.assert_allclose(xyz[i][d.point_link == l], ref, rtol=0, atol=1e-13)
+    h.close()
+
+
+# ------------------------------------------------------------------------------------------ field lookups
+def test_field_lookup_against_reference_golden(capi, oracle_mod):
+    """Voxel offsets (bit-exact), values (exact) and sdf_callback Jacobians on the reference's own
+    golden vectors, incl. points exactly on voxel faces and outside the grid."""
+    s = golden("sdf_callback.npz")
+    d = point_cloud_robot(s["points"])
+    h = capi.SolverHandle(d, "root", "root", device=0)
+    h.set_scene(0, s["data"], None, s["shape"], s["origin"], float(s["res"]))
+    xyz, off, val, grad = h.eval_points(0, np.zeros((1, 1)), [0, 0, 0])
+    np.testing.assert_array_equal(xyz[0], s["points"])
+    np.testing.assert_array_equal(val[0], s["value"])
+    np.testing.assert_allclose(grad[0], s["jac"], rtol=2e-15, atol=0)
+    ref_off = oracle_mod.points_to_offsets(s["points"], s["origin"], float(s["res"]), s["shape"])
+    np.testing.assert_array_equal(off[0], ref_off)
+    h.close()
+
+    g = golden("grid.npz")
+    d = point_cloud_robot(g["query"])
+    h = capi.SolverHandle(d, "root", "root", device=0)
+    F = int(g["field_size"])
+    h.set_scene(5, np.arange(F, dtype=np.float32) % 1000, None, g["field_shape"], g["origin"].ravel(), 0.05)
+    _, off, _, _ = h.eval_points(5, np.zeros((1, 1)), [0, 0, 0])
+    np.testing.assert_array_equal(off[0], g["offsets"])  # gto/gto_models.py:190-201 executed by the reference
+    h.close()
+
+
+def test_points_offsets_values_vs_oracle(capi, oracle_mod):
+    prob = Problem("panda", B=3, scene_seed=2, n=40, res=0.03, base=(0.02, -0.01, 0.03))  # small grid: many clipped points
+    h, o = make_pair(capi, oracle_mod, prob)
+    q = np.concatenate([prob.Q0[0].T[::7], prob.Q0[1].T[::9]])
+    for use_obs in (False, True):
+        xg, og, vg, gg = h.eval_points(0, q, prob.base[0], use_obs=use_obs)
+        xo, oo, vo, go = o.eval_points(0, q, prob.base[0], use_obs=use_obs)
+        np.testing.assert_allclose(xg, xo, rtol=0, atol=1e-13)
+        np.testing.assert_array_equal(og, oo)
+        np.testing.assert_array_equal(vg, vo)
+        np.testing.assert_allclose(gg, go, rtol=1e-15, atol=0)
+    h.close()
+
+
+# ------------------------------------------------------------------------------------------ objective pieces
+@pytest.mark.parametrize("robot,n_goals,standoff", [("panda", 1, True), ("panda", 5, True), ("panda", 3, False),
+                                                     ("fetch", 2, True)])
+def test_objective_terms_vs_oracle(capi, oracle_mod, robot, n_goals, standoff):
+    prob = Problem(robot, B=5, scene_seed=3, n_goals=n_goals, use_standoff=standoff, base=(0.01, 0.0, -0.02))
+    h, o = make_pair(capi, oracle_mod, prob)
+    rng = np.random.default_rng(0)
+    Q = prob.Q0.copy()
+    oi = prob.desc.opt_index
+    Q[:, oi, 2:] += 0.05 * rng.standard_normal(Q[:, oi, 2:].shape)
+    a = h.eval_objective(0, prob.goals, n_goals, prob.S, prob.base, Q)
+    b = o.eval_objective(0, prob.goals, n_goals, prob.S, prob.base, Q)
+    np.testing.assert_allclose(a[0], b[0], rtol=1e-10, atol=1e-14)  # f_goal (closed form in moments vs point sums)
+    np.testing.assert_allclose(a[1], b[1], rtol=1e-12, atol=1e-14)  # f_obs
+    np.testing.assert_allclose(a[2], b[2], rtol=1e-12, atol=1e-14)  # f_vel
+    np.testing.assert_array_equal(a[3], b[3])                       # arg-min goal
+    h.close()
+
+
+@pytest.mark.parametrize("robot", ["panda", "fetch"])
+def test_obstacle_normal_equations_vs_oracle(capi, oracle_mod, robot):
+    prob = Problem(robot, B=4, scene_seed=1, base=(0.0, 0.02, 0.01))
+    h, o = make_pair(capi, oracle_mod, prob)
+    # push the seeds towards the table so many points carry cost and gradient
+    Q = prob.Q0.copy()
+    oi = prob.desc.opt_index
+    Q[:, oi[1], 2:] += 0.35
+    A, b, ss = h.eval_obstacle_normal_eq(0, prob.base, Q)
+    Ao, bo, sso = o.eval_obstacle_normal_eq(0, prob.base, Q)
+    assert np.abs(bo).max() > 1e-3 and sso.max() > 1e-4, "test problem exercises no obstacle terms"
+    sc = np.abs(Ao).max()
+    np.testing.assert_allclose(A[:, 2:], Ao[:, 2:], rtol=1e-9, atol=1e-11 * sc)
+    np.testing.assert_allclose(b[:, 2:], bo[:, 2:], rtol=1e-9, atol=1e-11 * np.abs(bo).max())
+    np.testing.assert_allclose(ss, sso, rtol=1e-12, atol=1e-16)
+    h.close()
+
+
+def test_plan_cost_vs_oracle(capi, oracle_mod):
+    prob = Problem("panda", B=6, scene_seed=1)
+    h, o = make_pair(capi, oracle_mod, prob)
+    Q = prob.Q0.copy()
+    Q[:, prob.desc.opt_index[1], :] += 0.3
+    cg, dg = h.plan_cost(0, Q, prob.base[0])
+    co, do = o.plan_cost(0, Q, prob.base[0])
+    assert co.max() > 0
+    np.testing.assert_allclose(cg, co, rtol=1e-12)
+    np.testing.assert_allclose(dg, do, rtol=1e-14)
+    h.close()
+
+
+# ------------------------------------------------------------------------------------------ the solve
+@pytest.mark.parametrize("max_iter", [0, 1, 2, 5])
+def test_solver_iterates_match_oracle_step_by_step(capi, oracle_mod, max_iter):
+    prob = Problem("panda", B=5, scene_seed=3)
+    h, o = make_pair(capi, oracle_mod, prob, max_iter=max_iter)
+    Qg, dQg, fg, itg, stg = h.solve_batch(*prob.solve_args())
+    Qo, dQo, fo, ito, sto = o.solve_batch(*prob.solve_args())
+    np.testing.assert_array_equal(itg, ito)
+    np.testing.assert_array_equal(stg, sto)
+    np.testing.assert_allclose(Qg, Qo, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(dQg, dQo, rtol=0, atol=1e-8)
+    np.testing.assert_allclose(fg, fo, rtol=1e-9)
+    h.close()
+
+
+@pytest.mark.parametrize("robot,n_goals,standoff,grad_mode,scene_seed",
+                         [("panda", 1, True, 0, 1), ("panda", 1, True, 0, 3), ("panda", 4, True, 0, 3),
+                          ("panda", 1, False, 0, 2), ("panda", 1, True, 1, 3), ("fetch", 1, True, 0, 1)])
+def test_full_solve_matches_oracle(capi, oracle_mod, robot, n_goals, standoff, grad_mode, scene_seed):
+    prob = Problem(robot, B=6, scene_seed=scene_seed, n_goals=n_goals, use_standoff=standoff)
+    h, o = make_pair(capi, oracle_mod, prob, max_iter=60, grad_mode=grad_mode)
+    Qg, dQg, fg, itg, stg = h.solve_batch(*prob.solve_args())
+    Qo, dQo, fo, ito, sto = o.solve_batch(*prob.solve_args())
+    np.testing.assert_array_equal(itg, ito)
+    np.testing.assert_array_equal(stg, sto)
+    np.testing.assert_allclose(Qg, Qo, rtol=0, atol=1e-6)  # north_star tolerance
+    np.testing.assert_allclose(fg, fo, rtol=1e-7)
+    # structural invariants shared with the reference's stored plans
+    d = prob.desc
+    oi = d.opt_index
+    assert np.abs(Qg[:, :, 1] - Qg[:, :, 0]).max() == 0.0
+    np.testing.assert_array_equal(Qg[:, oi, 0], prob.qc[:, oi])
+    assert (Qg[:, oi] >= d.lower[oi][None, :, None]).all() and (Qg[:, oi] <= d.upper[oi][None, :, None]).all()
+    np.testing.assert_array_equal(Qg[:, d.param_index], prob.Q0[:, d.param_index])
+    dt = 10.0 / 49
+    np.testing.assert_allclose(Qg[:, :, :-1] + dt * dQg, Qg[:, :, 1:], atol=1e-15)  # Euler dynamics
+    h.close()
+
+
+def test_ragged_batches_and_scene_table(capi, oracle_mod):
+    """B not a multiple of 8, several scenes, per-instance goal counts, then the empty batch."""
+    prob = Problem("panda", B=11, scene_seed=1, n_goals=3)
+    h, o = make_pair(capi, oracle_mod, prob, max_iter=8)
+    prob2 = Problem("panda", B=1, scene_seed=2)
+    for s in (h, o):
+        s.set_scene(9, prob2.scene.c_all, None, prob2.scene.shape, prob2.scene.origin, prob2.scene.res)
+    sid = np.array([0, 9] * 5 + [0], dtype=np.int32)
+    ng = np.array([1, 2, 3] * 3 + [3, 1], dtype=np.int32)
+    args = (sid, prob.qc, prob.goals, ng, prob.S, prob.base, prob.Q0)
+    Qg, _, fg, itg, stg = h.solve_batch(*args)
+    Qo, _, fo, ito, sto = o.solve_batch(*args)
+    np.testing.assert_array_equal(itg, ito)
+    np.testing.assert_allclose(Qg, Qo, rtol=0, atol=1e-7)
+    np.testing.assert_allclose(fg, fo, rtol=1e-8)
+    # empty batch is a no-op
+    out = h.solve_batch(np.zeros(0, np.int32), np.zeros((0, 9)), np.zeros((0, 1, 16)), np.zeros(0, np.int32), None,
+                        np.zeros((0, 3)), np.zeros((0, 9, 50)))
+    assert out[0].shape == (0, 9, 50)
+    # unknown scene / bad goal count are reported, not ignored
+    with pytest.raises(capi.GTOError, match="scene"):
+        h.solve_batch(np.full(11, 4, np.int32), *args[1:])
+    with pytest.raises(capi.GTOError, match="n_goals"):
+        h.solve_batch(sid, prob.qc, prob.goals, np.full(11, 7, np.int32), prob.S, prob.base, prob.Q0)
+    h.drop_scene(9)
+    with pytest.raises(capi.GTOError, match="scene"):
+        h.solve_batch(*args)
+    h.close()
+
+
+def test_full_size_properties(capi, oracle_mod):
+    """BASELINE.json configs[1] sizes (Panda, ~5k surface points, 128^3 field, 64 goals, T=50):
+    too slow for the scalar oracle end-to-end, so checked through size-independent properties."""
+    prob = Problem("panda_5k", B=64, scene_seed=3, n=128, res=0.0175)
+    opts = oracle_mod.reference_opts(max_iter=40)
+    h = capi.SolverHandle(prob.desc, prob.cfg["link_ee"], prob.cfg["link_gripper"], opts, device=0)
+    prob.finish(h.eval_fk)
+    h.set_scene(*prob.scene_args())
+    Q, dQ, f, it, st = h.solve_batch(*prob.solve_args())
+    d = prob.desc
+    oi = d.opt_index
+    assert (Q[:, oi] >= d.lower[oi][None, :, None]).all() and (Q[:, oi] <= d.upper[oi][None, :, None]).all()
+    assert np.abs(Q[:, :, 1] - Q[:, :, 0]).max() == 0.0
+    np.testing.assert_array_equal(Q[:, oi, 0], prob.qc[:, oi])
+    # reported cost == objective re-evaluated at the returned trajectory; never above the seed's
+    fg, fo, fv, _ = h.eval_objective(0, prob.goals, 1, prob.S, prob.base, Q)
+    np.testing.assert_allclose(fg + fo + fv, f, rtol=1e-10)
+    seed = prob.Q0.copy()
+    seed[:, :, :2] = prob.qc[:, :, None]
+    seed[:, oi] = np.clip(seed[:, oi], d.lower[oi][None, :, None], d.upper[oi][None, :, None])
+    sg, so, sv, _ = h.eval_objective(0, prob.goals, 1, prob.S, prob.base, seed)
+    assert (f <= (sg + so + sv) * (1 + 1e-12)).all()
+    # restarting from the solution never raises the objective
+    Q2, _, f2, it2, _ = h.solve_batch(0, prob.qc, prob.goals, 1, prob.S, prob.base, Q)
+    assert (f2 <= f * (1 + 1e-9)).all()
+    # a sample of instances against the oracle (same algorithm, FP64)
+    o = oracle_mod.Oracle(prob.desc, prob.cfg["link_ee"], prob.cfg["link_gripper"], opts)
+    o.set_scene(*prob.scene_args())
+    sel = [0, 17, 63]
+    Qo, _, fo_, ito, _ = o.solve_batch(0, prob.qc[sel], prob.goals[sel], 1, prob.S, prob.base[sel], prob.Q0[sel])
+    np.testing.assert_array_equal(it[sel], ito)
+    np.testing.assert_allclose(Q[sel], Qo, rtol=0, atol=1e-6)
+    h.close()
