@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""bench.py — throughput of the GTO inner solve on MI355X (BASELINE.json metric).
+
+One "step" = one pass of the hot path over one batch: solving B independent (scene, goal-grasp)
+trajectory problems of BASELINE.json configs[1] (Panda 7-DoF, T=50 waypoints, ~5k surface points,
+128^3 float32 cost field, 64 candidate goal grasps of one scene) with the batched Gauss-Newton/LM
+solver behind the C ABI (gto_solve_batch_device: inputs already resident in HBM).
+N GPUs = N ranks, each solving its own scene x 64 grasps (weak scaling, no data-path collective).
+
+Prints ONE JSON line (rank 0).  Extra objects:
+  roofline      dominant kernel (k_obstacle_gram), algorithmic field-gather bytes / HIP-event time
+  cpu_baseline  the CPU oracle (same algorithm, FP64, OpenMP over instances) on a bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="goal grasps (instances) per GPU per step")
+    ap.add_argument("--max-iter", type=int, default=100, help="iteration cap (reference IPOPT cap: 100)")
+    ap.add_argument("--robot", default="panda_5k")
+    ap.add_argument("--grid", type=int, default=128)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=16, help="instances timed on the host cores")
+    ap.add_argument("--traffic", type=float, default=None,
+                    help="HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes (see profiles/)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"[bench] WORLD_SIZE={world} != --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the GTO solve path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import __graft_entry__ as g
+    if not os.path.exists(g.HIP_LIB):
+        g.build()
+    from grasptrajopt_amd import _capi, synthetic as syn
+    from grasptrajopt_amd.parallel import shard_range
+    from grasptrajopt_amd.robot_desc import load_builtin
+
+    cfg = json.load(open(os.path.join(ROOT, "grasptrajopt_amd", "data", "panda_cfg.json")))
+    desc = load_builtin(args.robot)
+    opts = _capi.default_opts()
+    opts.max_iter = args.max_iter
+    h = _capi.SolverHandle(desc, cfg["link_ee"], cfg["link_gripper"], opts, device=local_rank, n_gripper_points=100)
+    T, ndof, B = opts.T, desc.ndof, args.batch
+
+    # this rank's shard of the global problem list: scene = global rank id, 64 grasps each
+    lo, hi = shard_range(world * B, rank, world)
+    assert hi - lo == B
+    scene_seed = lo // B
+    res = 2.24 / args.grid  # covers the 2.24 m reach box (0.0175 m at 128^3)
+    sc = syn.make_scene(scene_seed, n=args.grid, res=res)
+    h.set_scene(0, sc.c_all, sc.c_obs, sc.shape, sc.origin, sc.res)
+    RT, qg = syn.make_goals(desc, h.eval_fk, cfg["link_ee"], B, seed=scene_seed)
+    qc = np.tile(np.array(cfg["default_pose"]), (B, 1))
+    Q0 = np.stack([syn.make_seed(qc[b], qg[b], T, desc.param_index) for b in range(B)])
+    S = np.tile(syn.standoff_pose(-0.1, cfg["axis_standoff"]).reshape(1, 16), (B, 1))
+    base = np.zeros((B, 3))
+
+    t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(dt).to(dev)
+    d_sid = torch.zeros(B, dtype=torch.int32, device=dev)
+    d_qc, d_goals = t(qc, torch.float64), t(RT.reshape(B, 1, 16), torch.float64)
+    d_ng = torch.ones(B, dtype=torch.int32, device=dev)
+    d_S, d_base, d_Q0 = t(S, torch.float64), t(base, torch.float64), t(Q0, torch.float64)
+    d_Q = torch.empty((B, ndof, T), dtype=torch.float64, device=dev)
+    d_dQ = torch.empty((B, ndof, T - 1), dtype=torch.float64, device=dev)
+    d_cost = torch.empty(B, dtype=torch.float64, device=dev)
+    d_it = torch.empty(B, dtype=torch.int32, device=dev)
+    d_st = torch.empty(B, dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+
+    def step():
+        h.solve_batch_device(B, 1, d_sid.data_ptr(), d_qc.data_ptr(), d_goals.data_ptr(), d_ng.data_ptr(),
+                             d_S.data_ptr(), d_base.data_ptr(), d_Q0.data_ptr(), d_Q.data_ptr(), d_dQ.data_ptr(),
+                             d_cost.data_ptr(), d_it.data_ptr(), d_st.data_ptr(), stream)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    h.set_profiling(True)  # HIP events around every launch of the dominant kernel, on the launch stream
+    kern_ms, kern_launches = 0.0, 0
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        ms, nl = h.last_kernel_time()
+        kern_ms += ms
+        kern_launches += nl
+    barrier()
+    elapsed = time.perf_counter() - t0
+    h.set_profiling(False)
+
+    iters = d_it.cpu().numpy().astype(np.int64)
+    status = d_st.cpu().numpy()
+    cost = d_cost.cpu().numpy()
+    Qsol = d_Q.cpu().numpy()
+    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    it_sum = torch.tensor([float(iters.sum())], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        dist.all_reduce(it_sum, op=dist.ReduceOp.SUM)
+    elapsed = float(el.item())
+    total_traj = world * B * args.steps
+    value = total_traj / elapsed
+    iters_per_s = float(it_sum.item()) * args.steps / elapsed
+
+    if rank == 0:
+        # quality gate on this rank's batch
+        oi = desc.opt_index
+        viol = float(np.maximum(desc.lower[oi][None, :, None] - Qsol[:, oi], Qsol[:, oi] - desc.upper[oi][None, :, None]).max())
+        fe = desc.frame_index(cfg["link_ee"])
+        Tf = h.eval_fk(Qsol[:, :, -1])[:, fe]
+        err_pos = np.linalg.norm(Tf[:, :3, 3] - RT[:, :3, 3], axis=1)
+        cosang = (np.einsum("bij,bij->b", Tf[:, :3, :3], RT[:, :3, :3]) - 1.0) / 2.0
+        err_rot = np.degrees(np.arccos(np.clip(cosang, -1, 1)))
+        seed_cost, _ = h.plan_cost(0, np.clip(Q0, None, None), [0, 0, 0])
+        sol_cost, _ = h.plan_cost(0, Qsol, [0, 0, 0])
+
+        # roofline of the dominant kernel: algorithmic bytes (7 float32 gathers per
+        # surface point and free waypoint) / HIP-event time of its launches in the timed region
+        P = desc.n_points
+        bytes_per_inst_launch = (T - 2) * P * 28
+        evals = float((iters + 1).sum()) * args.steps  # each instance is evaluated iters+1 times per solve
+        alg_bytes = evals * bytes_per_inst_launch
+        avg_launch_us = 1e3 * kern_ms / max(kern_launches, 1)
+        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+        roofline = {"bound": "hbm", "kernel": "k_obstacle_gram", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": args.traffic,
+                    "alg_bytes_per_launch": round(alg_bytes / max(kern_launches, 1)),
+                    "avg_launch_us": round(avg_launch_us, 2), "launches": kern_launches,
+                    "kernel_time_frac_of_step": round(kern_ms * 1e-3 / elapsed, 3)}
+
+        cpu_baseline = None
+        if not args.no_cpu_baseline:
+            from oracle import oracle
+            oracle.build()
+            o = oracle.Oracle(desc, cfg["link_ee"], cfg["link_gripper"], opts, n_gripper_points=100)
+            o.set_scene(0, sc.c_all, sc.c_obs, sc.shape, sc.origin, sc.res)
+            ns = min(args.cpu_sample, B)
+            cores = o.num_threads()
+            tc = time.perf_counter()
+            Qo, _, fo, ito, _ = o.solve_batch(0, qc[:ns], RT[:ns].reshape(ns, 1, 16), 1, S[:ns], base[:ns], Q0[:ns],
+                                              n_threads=cores)
+            tcpu = time.perf_counter() - tc
+            cpu_baseline = {"value": round(ns / tcpu, 4), "unit": "trajectories/s", "cores": cores, "kind": "port",
+                            "sample": f"first {ns} of the {B} instances of this workload, {tcpu:.1f} s, OpenMP over instances",
+                            "iters_per_s": round(float(ito.sum()) / tcpu, 2),
+                            "max_abs_dQ_vs_gpu": float(np.abs(Qo - Qsol[:ns]).max())}
+
+        out = {
+            "metric": "grasp trajectories/sec", "value": round(value, 2), "unit": "trajectories/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: Panda 7-DoF, 1 scene x 64 goal grasps per GPU, T=50, "
+                                   f"{P} surface points, {args.grid}^3 f32 SDF cost field",
+                       "batch_per_gpu": B, "T": int(T), "surface_points": int(P), "grid": args.grid,
+                       "max_iter": args.max_iter, "parallelism": f"instances sharded over {world} GPU(s), no collective"},
+            "sqp_iters_per_s": round(iters_per_s, 1),
+            "iters_mean": round(float(iters.mean()), 2), "iters_max": int(iters.max()),
+            "status_counts": {str(k): int((status == k).sum()) for k in np.unique(status)},
+            "quality": {"max_joint_limit_violation": viol, "goal_err_pos_max_m": round(float(err_pos.max()), 5),
+                        "goal_err_rot_max_deg": round(float(err_rot.max()), 3),
+                        "goal_ok_frac": round(float(((err_pos < 0.01) & (err_rot < 5)).mean()), 3),
+                        "plan_cost_le_seed_frac": round(float((sol_cost <= seed_cost + 1e-12).mean()), 3),
+                        "f_mean": round(float(cost.mean()), 5)},
+            "reference_published": "0.098 trajectories/s (Panda tabletop, IPOPT on unknown CPU; BASELINE.md section 1)",
+            "roofline": roofline, "cpu_baseline": cpu_baseline,
+        }
+        print(json.dumps(out))
+    h.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

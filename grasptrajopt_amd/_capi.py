@@ -233,6 +233,9 @@ class SolverHandle:
         d, T = self.desc, self.T
         qc = _f64(qc).reshape(-1, d.ndof)
         B = qc.shape[0]
+        if B == 0:  # empty batch: nothing to solve
+            return (np.empty((0, d.ndof, T)), np.empty((0, d.ndof, T - 1)), np.empty(0),
+                    np.empty(0, dtype=np.int32), np.empty(0, dtype=np.int32))
         goals = _f64(goals).reshape(B, -1, 16)
         n_max = goals.shape[1]
         n_goals = _i32(np.broadcast_to(np.asarray(n_goals), (B,)))

@@ -34,7 +34,9 @@ struct gto_handle {
   SceneDev* d_scenes = nullptr;
   size_t d_scenes_cap = 0;
   // solve workspace (grown on demand)
-  DevBuf state, Qcur, Qtry, vis, screw, blocks, goalblk, ssfixed;
+  DevBuf state, Qcur, Qtry, vis, screw, blocks, goalblk, ssfixed, ndone;
+  int32_t* h_ndone = nullptr;  // pinned
+  int check_every = 8;
   // staging for the host-pointer entry points
   DevBuf in[8], out[8];
   // profiling of the dominant kernel
@@ -264,7 +266,8 @@ void gto_destroy(gto_handle* h) {
   (void)hipFree(h->d_plink);
   (void)hipFree(h->d_perm);
   (void)hipFree(h->d_chunks);
-  DevBuf* bufs[] = {&h->state, &h->Qcur, &h->Qtry, &h->vis, &h->screw, &h->blocks, &h->goalblk, &h->ssfixed};
+  DevBuf* bufs[] = {&h->state, &h->Qcur, &h->Qtry, &h->vis, &h->screw, &h->blocks, &h->goalblk, &h->ssfixed, &h->ndone};
+  if (h->h_ndone) (void)hipHostFree(h->h_ndone);
   for (DevBuf* b : bufs) (void)hipFree(b->p);
   for (auto& b : h->in) (void)hipFree(b.p);
   for (auto& b : h->out) (void)hipFree(b.p);
@@ -397,6 +400,8 @@ static int ensure_workspace(gto_handle* h, int B) {
   if ((rc = ensure(h, h->blocks, (size_t)2 * B * T * BLK_STRIDE * sizeof(double)))) return rc;
   if ((rc = ensure(h, h->goalblk, (size_t)2 * B * 2 * BLK_STRIDE * sizeof(double)))) return rc;
   if ((rc = ensure(h, h->ssfixed, (size_t)B * 2 * sizeof(double)))) return rc;
+  if ((rc = ensure(h, h->ndone, 64))) return rc;
+  if (!h->h_ndone) HIPCHK(h, hipHostMalloc((void**)&h->h_ndone, 64));
   return GTO_OK;
 }
 
@@ -418,6 +423,7 @@ static BatchPtrs make_ptrs(gto_handle* h, const int32_t* scene_id, const double*
   bp.blocks = (double*)h->blocks.p;
   bp.goalblk = (double*)h->goalblk.p;
   bp.ss_fixed = (double*)h->ssfixed.p;
+  bp.n_done = (int32_t*)h->ndone.p;
   return bp;
 }
 
@@ -472,6 +478,7 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
   h->last_launches = 0;
   h->last_ms = 0.0;
 
+  HIPCHK(h, hipMemsetAsync(bp.n_done, 0, sizeof(int32_t), st));
   hipLaunchKernelGGL(k_lm_init, dim3(B), dim3(64), 0, st, h->d_rb, bp, sp, B, 0);
   if ((rc = launch_obstacle(h, st, bp, sp, B, 0, 2, 1, false))) return rc;
   // one round = evaluate the trial trajectory (obstacle kernel) + accept/solve/new trial (step kernel);
@@ -479,6 +486,12 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
   for (int k = 0; k <= sp.max_iter; ++k) {
     if ((rc = launch_obstacle(h, st, bp, sp, B, 2, T - 2, 0, h->profiling))) return rc;
     hipLaunchKernelGGL(k_lm_step, dim3(B), dim3(64), h->lm_lds, st, h->d_rb, bp, sp, B);
+    // early exit: every few rounds look at the finished-instance counter (one 4-byte read-back)
+    if (h->check_every > 0 && (k % h->check_every) == h->check_every - 1 && k < sp.max_iter) {
+      HIPCHK(h, hipMemcpyAsync(h->h_ndone, bp.n_done, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+      HIPCHK(h, hipStreamSynchronize(st));
+      if (*h->h_ndone >= B) break;
+    }
   }
   hipLaunchKernelGGL(k_lm_finalize, dim3(B), dim3(64), 0, st, h->d_rb, bp, sp, B, Q_out, dQ_out, cost_out, iters_out,
                      status_out);
@@ -645,6 +658,7 @@ static int eval_common(gto_handle* h, int B, int n_max, const int32_t* scene_id,
   SolveParams sp = make_params(h, n_max, standoff != nullptr);
   BatchPtrs bp = make_ptrs(h, (const int32_t*)d_sid, (const double*)d_qc, (const double*)d_goals, (const int32_t*)d_ng,
                            (const double*)d_so, (const double*)d_base, (const double*)d_Q0);
+  HIPCHK(h, hipMemsetAsync(bp.n_done, 0, sizeof(int32_t), h->stream));
   hipLaunchKernelGGL(k_lm_init, dim3(B), dim3(64), 0, h->stream, h->d_rb, bp, sp, B, 1 /* raw: evaluate Q as given */);
   if ((rc = launch_obstacle(h, h->stream, bp, sp, B, 0, 2, 1, false))) return rc;
   if ((rc = launch_obstacle(h, h->stream, bp, sp, B, 2, (int)T - 2, 0, false))) return rc;

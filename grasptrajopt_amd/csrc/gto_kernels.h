@@ -47,6 +47,7 @@ struct BatchPtrs {
   double* blocks;    // [2][B][T][BLK_STRIDE]
   double* goalblk;   // [2][B][2][BLK_STRIDE]
   double* ss_fixed;  // [B][2]  sum c^2 of the two pinned waypoints
+  int32_t* n_done;   // [1]     instances that have finished
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -621,6 +622,7 @@ __global__ __launch_bounds__(64) void k_lm_step(const RobotDev* __restrict__ rb,
       st->done = 1;
       st->status = status;
       if (accept) st->argmin_cur = st->argmin_try;
+      atomicAdd(bp.n_done, 1);
     }
     return;
   }
@@ -721,6 +723,7 @@ __global__ __launch_bounds__(64) void k_lm_step(const RobotDev* __restrict__ rb,
       st->done = 1;
       st->status = GTO_STATUS_NUMERICAL;
       if (accept) st->argmin_cur = st->argmin_try;
+      atomicAdd(bp.n_done, 1);
     }
     return;
   }
@@ -763,6 +766,7 @@ __global__ __launch_bounds__(64) void k_lm_step(const RobotDev* __restrict__ rb,
       st->done = 1;
       st->status = GTO_STATUS_CONVERGED;
       if (accept) st->argmin_cur = st->argmin_try;
+      atomicAdd(bp.n_done, 1);
     }
     return;
   }

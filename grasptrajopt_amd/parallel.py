@@ -1,0 +1,95 @@
+"""Multi-GPU layer: one process per GPU, instances sharded statically, no data-path collective.
+
+Every (scene, goal-set) instance is an independent problem (gto/gto_planner.py:185-245 shares
+nothing across calls), so a node's 8 GPUs each solve a contiguous block of the instance list,
+grouped by scene so that a scene's cost field is uploaded to exactly one GPU.
+The only communication is an optional all_gather of the solved trajectories (~3.6 KB per
+instance) over RCCL/xGMI (`backend="nccl"` on ROCm) or gloo on CPU-only test boxes.
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, Optional, Sequence, Tuple
+
+import numpy as np
+
+
+def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous block partition [lo, hi) of n_items over `world` ranks (sizes differ by <= 1)."""
+    if not (0 <= rank < world):
+        raise ValueError(f"rank {rank} outside world of size {world}")
+    base, rem = divmod(n_items, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def shard_by_scene(scene_id: Sequence[int], world: int) -> np.ndarray:
+    """Assign instances to ranks so that all instances of one scene land on the same rank and the
+    per-rank instance counts are balanced greedily (largest scene first). Returns rank per instance."""
+    scene_id = np.asarray(scene_id)
+    scenes, counts = np.unique(scene_id, return_counts=True)
+    load = np.zeros(world, dtype=np.int64)
+    owner: Dict[int, int] = {}
+    for s, c in sorted(zip(scenes.tolist(), counts.tolist()), key=lambda sc: (-sc[1], sc[0])):
+        r = int(np.argmin(load))
+        owner[s] = r
+        load[r] += c
+    return np.array([owner[int(s)] for s in scene_id], dtype=np.int32)
+
+
+def solve_sharded(solve_fn: Callable[..., tuple], scene_id, qc, goals, n_goals, standoff, base_pos, Q0,
+                  rank: int, world: int, group=None, gather: bool = True, assignment: Optional[np.ndarray] = None):
+    """Solve this rank's shard with `solve_fn` (SolverHandle.solve_batch signature) and, if `gather`,
+    all_gather the results so every rank returns the full batch in the original order.
+
+    The caller is responsible for having uploaded the scenes its shard refers to on this rank.
+    """
+    scene_id = np.asarray(scene_id, dtype=np.int32)
+    B = scene_id.shape[0]
+    qc = np.asarray(qc, dtype=np.float64).reshape(B, -1)
+    goals = np.asarray(goals, dtype=np.float64).reshape(B, -1, 16)
+    n_goals = np.broadcast_to(np.asarray(n_goals, dtype=np.int32), (B,))
+    base_pos = np.broadcast_to(np.asarray(base_pos, dtype=np.float64).reshape(-1, 3), (B, 3))
+    Q0 = np.asarray(Q0, dtype=np.float64)
+    so = None if standoff is None else np.broadcast_to(np.asarray(standoff, dtype=np.float64).reshape(-1, 16), (B, 16))
+    if assignment is None:
+        lo, hi = shard_range(B, rank, world)
+        mine = np.arange(lo, hi)
+    else:
+        mine = np.nonzero(np.asarray(assignment) == rank)[0]
+    ndof, T = Q0.shape[1], Q0.shape[2]
+    if len(mine):
+        Q, dQ, cost, iters, status = solve_fn(scene_id[mine], qc[mine], goals[mine], n_goals[mine],
+                                              None if so is None else so[mine], base_pos[mine], Q0[mine])
+    else:
+        Q, dQ = np.empty((0, ndof, T)), np.empty((0, ndof, T - 1))
+        cost, iters, status = np.empty(0), np.empty(0, np.int32), np.empty(0, np.int32)
+    if not gather or world == 1:
+        return mine, Q, dQ, cost, iters, status
+
+    import torch
+    import torch.distributed as dist
+    backend = dist.get_backend(group)
+    dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+    # fixed-size payload per rank (pad to the largest shard) so a plain all_gather suffices
+    counts = [len(np.nonzero(np.asarray(assignment) == r)[0]) if assignment is not None
+              else shard_range(B, r, world)[1] - shard_range(B, r, world)[0] for r in range(world)]
+    mx = max(counts)
+    width = ndof * T + ndof * (T - 1) + 3
+    payload = np.zeros((mx, width))
+    n = len(mine)
+    payload[:n, : ndof * T] = Q.reshape(n, -1)
+    payload[:n, ndof * T: ndof * T + ndof * (T - 1)] = dQ.reshape(n, -1)
+    payload[:n, -3], payload[:n, -2], payload[:n, -1] = cost, iters, status
+    send = torch.from_numpy(payload).to(dev)
+    recv = [torch.empty_like(send) for _ in range(world)]
+    dist.all_gather(recv, send, group=group)
+    Qa, dQa = np.empty((B, ndof, T)), np.empty((B, ndof, T - 1))
+    ca, ia, sa = np.empty(B), np.empty(B, np.int32), np.empty(B, np.int32)
+    for r in range(world):
+        idx = (np.nonzero(np.asarray(assignment) == r)[0] if assignment is not None
+               else np.arange(*shard_range(B, r, world)))
+        blk = recv[r].cpu().numpy()[: len(idx)]
+        Qa[idx] = blk[:, : ndof * T].reshape(-1, ndof, T)
+        dQa[idx] = blk[:, ndof * T: ndof * T + ndof * (T - 1)].reshape(-1, ndof, T - 1)
+        ca[idx], ia[idx], sa[idx] = blk[:, -3], blk[:, -2].astype(np.int32), blk[:, -1].astype(np.int32)
+    return np.arange(B), Qa, dQa, ca, ia, sa

@@ -119,19 +119,28 @@ def test_objective_terms_vs_oracle(capi, oracle_mod, robot, n_goals, standoff):
     h.close()
 
 
-@pytest.mark.parametrize("robot", ["panda", "fetch"])
-def test_obstacle_normal_equations_vs_oracle(capi, oracle_mod, robot):
+@pytest.mark.parametrize("robot,dense", [("panda", True), ("fetch", True), ("panda", False), ("fetch", False)])
+def test_obstacle_normal_equations_vs_oracle(capi, oracle_mod, robot, dense):
     prob = Problem(robot, B=4, scene_seed=1, base=(0.0, 0.02, 0.01))
     h, o = make_pair(capi, oracle_mod, prob)
-    # push the seeds towards the table so many points carry cost and gradient
     Q = prob.Q0.copy()
     oi = prob.desc.opt_index
-    Q[:, oi[1], 2:] += 0.35
+    if dense:
+        # a dense random field: every surface point carries a cost value and a gradient
+        rng = np.random.default_rng(5)
+        sc = prob.scene
+        ca = (0.05 * rng.random(sc.c_all.size)).astype(np.float32)
+        co = (0.05 * rng.random(sc.c_all.size)).astype(np.float32)
+        for s in (h, o):
+            s.set_scene(0, ca, co, sc.shape, sc.origin, sc.res)
+    else:
+        # push the seeds into the table / objects of the synthetic scene
+        Q[:, oi[1], 2:] += 1.0
+        Q[:, oi] = np.clip(Q[:, oi], prob.desc.lower[oi][None, :, None], prob.desc.upper[oi][None, :, None])
     A, b, ss = h.eval_obstacle_normal_eq(0, prob.base, Q)
     Ao, bo, sso = o.eval_obstacle_normal_eq(0, prob.base, Q)
     assert np.abs(bo).max() > 1e-3 and sso.max() > 1e-4, "test problem exercises no obstacle terms"
-    sc = np.abs(Ao).max()
-    np.testing.assert_allclose(A[:, 2:], Ao[:, 2:], rtol=1e-9, atol=1e-11 * sc)
+    np.testing.assert_allclose(A[:, 2:], Ao[:, 2:], rtol=1e-9, atol=1e-11 * np.abs(Ao).max())
     np.testing.assert_allclose(b[:, 2:], bo[:, 2:], rtol=1e-9, atol=1e-11 * np.abs(bo).max())
     np.testing.assert_allclose(ss, sso, rtol=1e-12, atol=1e-16)
     h.close()
@@ -141,7 +150,7 @@ def test_plan_cost_vs_oracle(capi, oracle_mod):
     prob = Problem("panda", B=6, scene_seed=1)
     h, o = make_pair(capi, oracle_mod, prob)
     Q = prob.Q0.copy()
-    Q[:, prob.desc.opt_index[1], :] += 0.3
+    Q[:, prob.desc.opt_index[1], :] += 1.0
     cg, dg = h.plan_cost(0, Q, prob.base[0])
     co, do = o.plan_cost(0, Q, prob.base[0])
     assert co.max() > 0

@@ -1,0 +1,67 @@
+"""CPU: the N>1 sharding path with world_size 2 on gloo (the solver callable is the CPU oracle here;
+on GPU ranks it is SolverHandle.solve_batch)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+from grasptrajopt_amd.parallel import shard_by_scene, shard_range
+
+
+def test_shard_range_partitions_everything():
+    for n in (0, 1, 7, 64, 65, 16384):
+        for w in (1, 2, 3, 8):
+            spans = [shard_range(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard_range(4, 2, 2)
+
+
+def test_shard_by_scene_keeps_scenes_together():
+    rng = np.random.default_rng(0)
+    sid = rng.integers(0, 37, size=500)
+    a = shard_by_scene(sid, 8)
+    for s in np.unique(sid):
+        assert len(set(a[sid == s])) == 1
+    load = np.bincount(a, minlength=8)
+    assert load.max() - load.min() <= np.bincount(sid).max()
+
+
+def _worker(rank, world, port, tmp):
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import torch.distributed as dist
+    from helpers import Problem
+    from grasptrajopt_amd.parallel import solve_sharded
+    from oracle import oracle
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    prob = Problem("panda", B=5, scene_seed=1, n=32, res=0.07)
+    o = oracle.Oracle(prob.desc, prob.cfg["link_ee"], prob.cfg["link_gripper"], oracle.reference_opts(max_iter=4))
+    prob.finish(o.eval_fk)
+    o.set_scene(*prob.scene_args())
+    solve = lambda *a: o.solve_batch(*a, n_threads=1)
+    idx, Q, dQ, cost, iters, status = solve_sharded(solve, np.zeros(5, np.int32), prob.qc, prob.goals, 1, prob.S,
+                                                    prob.base, prob.Q0, rank, world)
+    np.savez(os.path.join(tmp, f"r{rank}.npz"), idx=idx, Q=Q, cost=cost, iters=iters)
+    if rank == 0:
+        Qs, _, cs, its, _ = o.solve_batch(0, prob.qc, prob.goals, 1, prob.S, prob.base, prob.Q0, n_threads=1)
+        np.savez(os.path.join(tmp, "single.npz"), Q=Qs, cost=cs, iters=its)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_sharded_solve_equals_single_process(tmp_path, oracle_mod):
+    port = 29500 + os.getpid() % 2000
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    single = np.load(tmp_path / "single.npz")
+    for r in range(2):
+        z = np.load(tmp_path / f"r{r}.npz")
+        assert z["idx"].tolist() == list(range(5))
+        np.testing.assert_array_equal(z["Q"], single["Q"])      # same code on every rank: bit-identical
+        np.testing.assert_array_equal(z["cost"], single["cost"])
+        np.testing.assert_array_equal(z["iters"], single["iters"])
