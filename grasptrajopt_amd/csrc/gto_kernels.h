@@ -180,19 +180,19 @@ __global__ __launch_bounds__(256) void k_obstacle_gram(const RobotDev* __restric
   for (int i = 0; i < GTO_GRAM; ++i) acc[i] = 0.0;
   int cur_link = -1;
 
-  auto flush = [&](int link) {
-#pragma unroll
-    for (int i = 0; i < GTO_GRAM; ++i) {
-      double v = wave_sum(acc[i]);
-      if (lane == i) atomicAdd(&s_gram[link * GTO_GRAM + i], v);
-      acc[i] = 0.0;
-    }
-  };
+#define GTO_FLUSH(link)                                                   \
+  do {                                                                    \
+    _Pragma("unroll") for (int i_ = 0; i_ < GTO_GRAM; ++i_) {             \
+      double v_ = wave_sum(acc[i_]);                                      \
+      if (lane == i_) atomicAdd(&s_gram[(link)*GTO_GRAM + i_], v_);       \
+      acc[i_] = 0.0;                                                      \
+    }                                                                     \
+  } while (0)
 
   for (int c = c0; c < c1; ++c) {
     const Chunk ch = chunks[c];
     if (ch.link != cur_link) {
-      if (cur_link >= 0) flush(cur_link);
+      if (cur_link >= 0) GTO_FLUSH(cur_link);
       cur_link = ch.link;
     }
     if (lane < ch.count) {
@@ -241,7 +241,8 @@ __global__ __launch_bounds__(256) void k_obstacle_gram(const RobotDev* __restric
       }
     }
   }
-  if (cur_link >= 0) flush(cur_link);
+  if (cur_link >= 0) GTO_FLUSH(cur_link);
+#undef GTO_FLUSH
   __syncthreads();
 
   // projection of the per-link wrench Grams onto the joint screws:
