@@ -105,7 +105,7 @@ static int validate_opts(const gto_solver_opts* o, std::string& why) {
 
 static size_t lm_lds_bytes(int T) {
   size_t m = (size_t)T - 2;
-  size_t dbl = m * 64 + 4 * m * 8 + 8 * (size_t)T + 64 + 8 + 48 + 2 * GTO_MAX_OPT * 6;
+  size_t dbl = m * 128 + 4 * m * 8 + 8 * (size_t)T + 48 + 2 * GTO_MAX_OPT * 6 + GTO_MAX_DOF + GTO_MAX_FRAMES * 12;
   return dbl * sizeof(double) + m * 8 * sizeof(int) + 64;
 }
 
@@ -210,7 +210,41 @@ int gto_create(const gto_robot_desc* d, const gto_solver_opts* opts, int device,
     perm[i] = i;
     if (d->point_link[i] < 0 || d->point_link[i] >= d->n_links) { delete h; return fail(nullptr, GTO_ERR_INVALID_ARG, "point_link out of range"); }
   }
-  std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return d->point_link[a] < d->point_link[b]; });
+  // sort by link, and inside a link along a Morton (Z-order) curve of the link-local coordinates, so
+  // that the 64 lanes of a chunk (and consecutive chunks) gather from neighbouring voxels/cache lines
+  std::vector<uint32_t> morton(P, 0);
+  {
+    std::vector<double> lo(3 * d->n_links, 1e300), hi(3 * d->n_links, -1e300);
+    for (int i = 0; i < P; ++i)
+      for (int a = 0; a < 3; ++a) {
+        lo[3 * d->point_link[i] + a] = std::min(lo[3 * d->point_link[i] + a], d->points[3 * i + a]);
+        hi[3 * d->point_link[i] + a] = std::max(hi[3 * d->point_link[i] + a], d->points[3 * i + a]);
+      }
+    auto spread = [](uint32_t v) {  // 10 bits -> every third bit
+      v &= 0x3ff;
+      v = (v | (v << 16)) & 0x30000ff;
+      v = (v | (v << 8)) & 0x300f00f;
+      v = (v | (v << 4)) & 0x30c30c3;
+      v = (v | (v << 2)) & 0x9249249;
+      return v;
+    };
+    for (int i = 0; i < P; ++i) {
+      const int l = d->point_link[i];
+      double ext = 1e-12;
+      for (int a = 0; a < 3; ++a) ext = std::max(ext, hi[3 * l + a] - lo[3 * l + a]);
+      uint32_t code = 0;
+      for (int a = 0; a < 3; ++a) {
+        double u = (d->points[3 * i + a] - lo[3 * l + a]) / ext;  // isotropic cells
+        uint32_t q = (uint32_t)std::min(1023.0, std::max(0.0, u * 1023.0));
+        code |= spread(q) << a;
+      }
+      morton[i] = code;
+    }
+  }
+  std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) {
+    if (d->point_link[a] != d->point_link[b]) return d->point_link[a] < d->point_link[b];
+    return morton[a] < morton[b];
+  });
   std::vector<double> px(P), py(P), pz(P);
   std::vector<int32_t> plink(P);
   for (int i = 0; i < P; ++i) {
@@ -256,6 +290,8 @@ void gto_destroy(gto_handle* h) {
     if (s.valid) {
       if (s.c_obs != s.c_all) (void)hipFree((void*)s.c_obs);
       (void)hipFree((void*)s.c_all);
+      if (s.r_obs != s.r_all) (void)hipFree((void*)s.r_obs);
+      (void)hipFree((void*)s.r_all);
     }
   }
   (void)hipFree(h->d_scenes);
@@ -317,6 +353,8 @@ int gto_set_scene(gto_handle* h, int32_t id, const float* c_all, const float* c_
   if (s.valid) {
     if (s.c_obs != s.c_all) HIPCHK(h, hipFree((void*)s.c_obs));
     HIPCHK(h, hipFree((void*)s.c_all));
+    if (s.r_obs != s.r_all) HIPCHK(h, hipFree((void*)s.r_obs));
+    HIPCHK(h, hipFree((void*)s.r_all));
     s.valid = 0;
   }
   float *da = nullptr, *dob = nullptr;
@@ -328,8 +366,23 @@ int gto_set_scene(gto_handle* h, int32_t id, const float* c_all, const float* c_
   } else {
     dob = da;
   }
+  // gather-friendly voxel records (one-time, outside the timed solve)
+  VoxelRec *ra = nullptr, *rob = nullptr;
+  HIPCHK(h, hipMalloc((void**)&ra, nvox * sizeof(VoxelRec)));
+  const unsigned nblk = (unsigned)((nvox + 255) / 256);
+  hipLaunchKernelGGL(k_build_records, dim3(nblk), dim3(256), 0, h->stream, da, ra, shape[0], shape[1], shape[2]);
+  if (dob != da) {
+    HIPCHK(h, hipMalloc((void**)&rob, nvox * sizeof(VoxelRec)));
+    hipLaunchKernelGGL(k_build_records, dim3(nblk), dim3(256), 0, h->stream, dob, rob, shape[0], shape[1], shape[2]);
+  } else {
+    rob = ra;
+  }
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, hipGetLastError());
   s.c_all = da;
   s.c_obs = dob;
+  s.r_all = ra;
+  s.r_obs = rob;
   s.nx = shape[0];
   s.ny = shape[1];
   s.nz = shape[2];
@@ -351,6 +404,8 @@ int gto_drop_scene(gto_handle* h, int32_t id) {
   SceneDev& s = h->scenes[id];
   if (s.c_obs != s.c_all) HIPCHK(h, hipFree((void*)s.c_obs));
   HIPCHK(h, hipFree((void*)s.c_all));
+  if (s.r_obs != s.r_all) HIPCHK(h, hipFree((void*)s.r_obs));
+  HIPCHK(h, hipFree((void*)s.r_all));
   memset(&s, 0, sizeof s);
   return sync_scene_table(h);
 }
@@ -390,13 +445,11 @@ static SolveParams make_params(const gto_handle* h, int n_max, bool use_standoff
 
 static int ensure_workspace(gto_handle* h, int B) {
   const RobotDev& rb = h->rb;
-  const size_t T = h->opts.T, n = rb.n_opt, L = rb.n_links;
+  const size_t T = h->opts.T, n = rb.n_opt;
   int rc;
   if ((rc = ensure(h, h->state, (size_t)B * sizeof(InstState)))) return rc;
   if ((rc = ensure(h, h->Qcur, (size_t)B * n * T * sizeof(double)))) return rc;
   if ((rc = ensure(h, h->Qtry, (size_t)B * n * T * sizeof(double)))) return rc;
-  if ((rc = ensure(h, h->vis, (size_t)B * T * L * 12 * sizeof(double)))) return rc;
-  if ((rc = ensure(h, h->screw, (size_t)B * T * n * 6 * sizeof(double)))) return rc;
   if ((rc = ensure(h, h->blocks, (size_t)2 * B * T * BLK_STRIDE * sizeof(double)))) return rc;
   if ((rc = ensure(h, h->goalblk, (size_t)2 * B * 2 * BLK_STRIDE * sizeof(double)))) return rc;
   if ((rc = ensure(h, h->ssfixed, (size_t)B * 2 * sizeof(double)))) return rc;
@@ -418,8 +471,6 @@ static BatchPtrs make_ptrs(gto_handle* h, const int32_t* scene_id, const double*
   bp.state = (InstState*)h->state.p;
   bp.Qcur = (double*)h->Qcur.p;
   bp.Qtry = (double*)h->Qtry.p;
-  bp.vis = (double*)h->vis.p;
-  bp.screw = (double*)h->screw.p;
   bp.blocks = (double*)h->blocks.p;
   bp.goalblk = (double*)h->goalblk.p;
   bp.ss_fixed = (double*)h->ssfixed.p;

@@ -37,9 +37,20 @@ struct RobotDev {
   double grip_count, grip_mu[3], grip_M[9];
 };
 
+// One voxel of the gather-friendly field layout built at gto_set_scene: the nearest-voxel cost and the
+// three central differences c[i+e_a] - c[i-e_a] (clipped neighbours, exact in FP64), 32 B, so the hot
+// loop fetches ONE record (two 16-B loads, one cache line) instead of seven scattered floats.
+struct __attribute__((aligned(32))) VoxelRec {
+  double dx, dy, dz;
+  float c;
+  float pad;
+};
+
 struct SceneDev {
   const float* c_all;
   const float* c_obs;
+  const VoxelRec* r_all;
+  const VoxelRec* r_obs;
   int32_t nx, ny, nz, valid;
   double ox, oy, oz, res, rinv, inv2r;
 };

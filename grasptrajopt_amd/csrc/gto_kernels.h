@@ -42,8 +42,6 @@ struct BatchPtrs {
   InstState* state;  // [B]
   double* Qcur;      // [B][n][T]
   double* Qtry;      // [B][n][T]
-  double* vis;       // [B][T][L][12]
-  double* screw;     // [B][T][n][6]
   double* blocks;    // [2][B][T][BLK_STRIDE]
   double* goalblk;   // [2][B][2][BLK_STRIDE]
   double* ss_fixed;  // [B][2]  sum c^2 of the two pinned waypoints
@@ -75,6 +73,145 @@ __device__ inline int voxel_axis(double x, double o, double res, double rinv, in
   k = (k >= 0.0) ? k : 0.0;  // NaN -> 0 like fmax(.,0)
   k = (k > hi) ? hi : k;
   return (int)k;
+}
+// Hot-loop form: u = y*rinv + cadd with cadd = (base - o)*rinv folded per workgroup (one FMA instead
+// of add/sub/mul); any evaluation order is fine away from voxel faces, and within 1e-9 of a face the
+// reference's own order (y + base - o) / res decides, so the index stays bit-identical.
+__device__ inline int voxel_axis_fast(double y, double cadd, double base, double o, double res, double rinv, int n) {
+  const double u = fma(y, rinv, cadd);
+  double k = floor(u);
+  const double fr = u - k;
+  if (fabs(fr - 0.5) > 0.5 - 1e-9) k = floor(((y + base) - o) / res);
+  int ki = (int)k;  // v_cvt_i32_f64 saturates, NaN -> 0
+  return min(max(ki, 0), n - 1);
+}
+
+// ---- cross-lane sums without LDS traffic (gfx950: v_permlane32_swap / v_permlane16_swap / DPP)
+typedef unsigned gto_uint2 __attribute__((ext_vector_type(2)));
+// lanes 0-31 <- a summed over the two wave halves, lanes 32-63 <- b summed over the two halves
+__device__ inline double swap32_add(double a, double b) {
+  const unsigned alo = __double2loint(a), ahi = __double2hiint(a), blo = __double2loint(b), bhi = __double2hiint(b);
+  const gto_uint2 l = __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
+  const gto_uint2 h = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
+  return __hiloint2double(h.x, l.x) + __hiloint2double(h.y, l.y);
+}
+// rows (16 lanes) 0,2 <- a.row0+a.row1, a.row2+a.row3 ; rows 1,3 <- b.row0+b.row1, b.row2+b.row3
+__device__ inline double swap16_add(double a, double b) {
+  const unsigned alo = __double2loint(a), ahi = __double2hiint(a), blo = __double2loint(b), bhi = __double2hiint(b);
+  const gto_uint2 l = __builtin_amdgcn_permlane16_swap(alo, blo, false, false);
+  const gto_uint2 h = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
+  return __hiloint2double(h.x, l.x) + __hiloint2double(h.y, l.y);
+}
+template <int CTRL>
+__device__ inline double dpp_add(double v) {
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  const int lo2 = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
+  const int hi2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+  return v + __hiloint2double(hi2, lo2);
+}
+// sum over each 16-lane row, result in every lane of the row
+__device__ inline double row_sum16(double v) {
+  v = dpp_add<0xB1>(v);   // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E>(v);   // quad_perm [2,3,0,1]
+  v = dpp_add<0x141>(v);  // row_half_mirror
+  v = dpp_add<0x140>(v);  // row_mirror
+  return v;
+}
+// Transpose-reduce of four per-lane values over the 64 lanes of a wave:
+// afterwards row 0 holds sum(a), row 1 sum(c), row 2 sum(b), row 3 sum(d) in all of its lanes.
+__device__ inline double wave_sum4(double a, double b, double c, double d) {
+  return row_sum16(swap16_add(swap32_add(a, b), swap32_add(c, d)));
+}
+
+// Forward kinematics of ONE configuration by a whole workgroup (optas/models.py:826-868, prefix
+// shared): s_q [ndof] in LDS -> s_fr [n_frames][12] global frame transforms in LDS.
+// Must be called by every thread of the block (contains barriers).
+__device__ inline void fk_block(const RobotDev* rb, const double* s_q, double* s_fr, int tid) {
+  const int F = rb->n_frames;
+  if (tid < F) {  // local transform L_i = origin_i @ joint_motion_i(q)
+    const int jt = rb->joint_type[tid];
+    const double* O = rb->origin[tid];
+    double* L = s_fr + 12 * tid;
+    if (jt == GTO_JOINT_REVOLUTE) {
+      // Rodrigues about the unit axis u: R = cos*I + sin*[u]x + (1-cos) u u^T (optas/spatialmath.py:90-100)
+      const double th = s_q[rb->q_index[tid]];
+      const double sn = sin(th), cs = cos(th), c1 = 1.0 - cs;
+      const double u0 = rb->axis_unit[tid][0], u1 = rb->axis_unit[tid][1], u2 = rb->axis_unit[tid][2];
+      const double R00 = cs + c1 * u0 * u0, R01 = c1 * u0 * u1 - sn * u2, R02 = c1 * u0 * u2 + sn * u1;
+      const double R10 = c1 * u1 * u0 + sn * u2, R11 = cs + c1 * u1 * u1, R12 = c1 * u1 * u2 - sn * u0;
+      const double R20 = c1 * u2 * u0 - sn * u1, R21 = c1 * u2 * u1 + sn * u0, R22 = cs + c1 * u2 * u2;
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const double o0 = O[4 * r], o1 = O[4 * r + 1], o2 = O[4 * r + 2];
+        L[4 * r] = o0 * R00 + o1 * R10 + o2 * R20;
+        L[4 * r + 1] = o0 * R01 + o1 * R11 + o2 * R21;
+        L[4 * r + 2] = o0 * R02 + o1 * R12 + o2 * R22;
+        L[4 * r + 3] = O[4 * r + 3];
+      }
+    } else if (jt == GTO_JOINT_PRISMATIC) {
+      const double qi = s_q[rb->q_index[tid]];
+      const double t0 = qi * rb->axis_unit[tid][0], t1 = qi * rb->axis_unit[tid][1], t2 = qi * rb->axis_unit[tid][2];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const double o0 = O[4 * r], o1 = O[4 * r + 1], o2 = O[4 * r + 2];
+        L[4 * r] = o0;
+        L[4 * r + 1] = o1;
+        L[4 * r + 2] = o2;
+        L[4 * r + 3] = o0 * t0 + o1 * t1 + o2 * t2 + O[4 * r + 3];
+      }
+    } else {
+      for (int k = 0; k < 12; ++k) L[k] = O[k];
+    }
+  }
+  __syncthreads();
+  // chain T_i = T_parent @ L_i in place; lane r (<3) carries row r, so no cross-lane traffic
+  if (tid < 3) {
+    for (int i = 0; i < F; ++i) {
+      const int p = rb->parent[i];
+      if (p < 0) continue;  // root: T = L
+      const double* P = s_fr + 12 * p + 4 * tid;
+      const double* L = s_fr + 12 * i;
+      const double p0 = P[0], p1 = P[1], p2 = P[2], p3 = P[3];
+      const double t0 = p0 * L[0] + p1 * L[4] + p2 * L[8];
+      const double t1 = p0 * L[1] + p1 * L[5] + p2 * L[9];
+      const double t2 = p0 * L[2] + p1 * L[6] + p2 * L[10];
+      const double t3 = p0 * L[3] + p1 * L[7] + p2 * L[11] + p3;
+      __builtin_amdgcn_wave_barrier();  // every row has read L_i before any row overwrites it
+      double* O = s_fr + 12 * i + 4 * tid;
+      O[0] = t0;
+      O[1] = t1;
+      O[2] = t2;
+      O[3] = t3;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  __syncthreads();
+}
+
+// world screw of optimised joint j from the frame that carries it: (a ; o x a) revolute, (0 ; a) prismatic
+__device__ inline void screw_of_frame(const RobotDev* rb, int i, const double* F, double* s) {
+  const double* u = rb->axis_unit[i];
+  double a[3], o[3];
+  for (int r = 0; r < 3; ++r) {
+    a[r] = F[4 * r] * u[0] + F[4 * r + 1] * u[1] + F[4 * r + 2] * u[2];
+    o[r] = F[4 * r + 3];
+  }
+  if (rb->joint_type[i] == GTO_JOINT_PRISMATIC) {
+    s[0] = s[1] = s[2] = 0.0;
+    s[3] = a[0];
+    s[4] = a[1];
+    s[5] = a[2];
+  } else {
+    double oxa[3];
+    cross3(o, a, oxa);
+    s[0] = a[0];
+    s[1] = a[1];
+    s[2] = a[2];
+    s[3] = oxa[0];
+    s[4] = oxa[1];
+    s[5] = oxa[2];
+  }
 }
 
 // Kinematics of one configuration: visual transforms of the collision links, world screws of the
@@ -133,10 +270,40 @@ __device__ inline void load_full_q(const RobotDev* rb, const double* Q0b, const 
 }
 
 // ------------------------------------------------------------------------------------------------
+// One-time per scene (gto_set_scene): voxel records {dx, dy, dz, c}.  Differences are formed in FP64
+// from the float32 field with clipped neighbours exactly as gto/sdf_callback.py:90-114 indexes them;
+// the division by 2*res stays in the solve kernel so the arithmetic order matches the oracle.
+__global__ void k_build_records(const float* __restrict__ c, VoxelRec* __restrict__ rec, int nx, int ny, int nz) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long nvox = (long)nx * ny * nz;
+  if (i >= nvox) return;
+  const int iz = (int)(i % nz), iy = (int)((i / nz) % ny), ix = (int)(i / ((long)nz * ny));
+  const int ixp = min(ix + 1, nx - 1), ixm = max(ix - 1, 0);
+  const int iyp = min(iy + 1, ny - 1), iym = max(iy - 1, 0);
+  const int izp = min(iz + 1, nz - 1), izm = max(iz - 1, 0);
+  auto at = [&](int x, int y, int z) { return (double)c[(long)z + (long)nz * ((long)y + (long)ny * x)]; };
+  VoxelRec r;
+  r.dx = at(ixp, iy, iz) - at(ixm, iy, iz);
+  r.dy = at(ix, iyp, iz) - at(ix, iym, iz);
+  r.dz = at(ix, iy, izp) - at(ix, iy, izm);
+  r.c = c[i];
+  r.pad = 0.f;
+  rec[i] = r;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Dominant kernel.  grid.x = 8 * ceil(B/8) * nT  (XCD-aware: all waypoints of one instance, hence all
 // gathers into one scene's field, are issued from the same XCD and share its 4 MiB L2).
 // t_begin/nT select the waypoint range (the two pinned waypoints are evaluated once at init).
-__global__ __launch_bounds__(256) void k_obstacle_gram(const RobotDev* __restrict__ rb, const double* __restrict__ px,
+//   prologue  forward kinematics of this (instance, waypoint) by the workgroup itself -> visual
+//             transforms of the collision links and joint screws staged in LDS
+//   main loop one link-uniform chunk of 64 Morton-sorted surface points per wave step
+//   epilogue  per-link 6x6 wrench Grams -> J^T J (n x n), J^T r (n), sum c^2
+#define GTO_LIST_CAP 80  // entries of 8 doubles per wave: a full chunk (64) always fits after a drain
+#ifndef GTO_OBS_MIN_WAVES
+#define GTO_OBS_MIN_WAVES 4  // waves per SIMD the register allocator must leave room for
+#endif
+__global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const RobotDev* __restrict__ rb, const double* __restrict__ px,
                                                        const double* __restrict__ py, const double* __restrict__ pz,
                                                        const Chunk* __restrict__ chunks, const SceneDev* __restrict__ scenes,
                                                        BatchPtrs bp, SolveParams sp, int B, int t_begin, int nT,
@@ -150,139 +317,224 @@ __global__ __launch_bounds__(256) void k_obstacle_gram(const RobotDev* __restric
   const InstState* st = bp.state + b;
   if (st->done) return;
 
+  __shared__ double s_q[GTO_MAX_DOF];
+  __shared__ double s_fr[GTO_MAX_FRAMES * 12];
   __shared__ double s_vis[GTO_MAX_LINKS * 12];
   __shared__ double s_screw[GTO_MAX_OPT * 6];
   __shared__ double s_gram[GTO_MAX_LINKS * GTO_GRAM];
-  __shared__ double s_u[GTO_MAX_LINKS * GTO_MAX_OPT * 6];
+  __shared__ double s_list[4 * GTO_LIST_CAP * 8];  // per-wave wrench lists; reused as s_u in the epilogue
   __shared__ double s_out[BLK_STRIDE];
+  double* s_u = s_list;  // [L][GTO_MAX_OPT][6] <= 1536 doubles
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int L = rb->n_links, n = rb->n_opt, T = sp.T;
-  const double* visg = bp.vis + ((size_t)b * T + t) * L * 12;
-  const double* scrg = bp.screw + ((size_t)b * T + t) * n * 6;
-  for (int i = tid; i < L * 12; i += 256) s_vis[i] = visg[i];
-  for (int i = tid; i < n * 6; i += 256) s_screw[i] = scrg[i];
+  const int L = rb->n_links, n = rb->n_opt, T = sp.T, ndof = rb->ndof;
+
+  // ---- prologue: q_t (parameter rows from Q0, optimised rows from the trial), FK, visual tf, screws
+  if (tid < ndof) s_q[tid] = bp.Q0[((size_t)b * ndof + tid) * T + t];
   for (int i = tid; i < L * GTO_GRAM; i += 256) s_gram[i] = 0.0;
   if (tid < BLK_STRIDE) s_out[tid] = 0.0;
+  __syncthreads();
+  if (tid < n) s_q[rb->opt_index[tid]] = bp.Qtry[((size_t)b * n + tid) * T + t];
+  __syncthreads();
+  fk_block(rb, s_q, s_fr, tid);
+  if (tid < L * 12) {  // visual_tf = link_tf @ visual origin (gto/gto_models.py:92-100)
+    const int l = tid / 12, e = tid % 12, r = e >> 2, c = e & 3;
+    const double* Fr = s_fr + 12 * rb->link_frame[l] + 4 * r;
+    const double* Vo = rb->vis_origin[l];
+    double v = Fr[0] * Vo[c] + Fr[1] * Vo[4 + c] + Fr[2] * Vo[8 + c];
+    if (c == 3) v += Fr[3];
+    s_vis[tid] = v;
+  }
+  if (tid >= 192 && tid < 192 + rb->n_frames) {
+    const int i = tid - 192, j = rb->opt_of_frame[i];
+    if (j >= 0) screw_of_frame(rb, i, s_fr + 12 * i, s_screw + 6 * j);
+  }
   __syncthreads();
 
   const SceneDev sc = scenes[bp.scene_id[b]];
   const float* __restrict__ field = (t < sp.ts) ? sc.c_all : sc.c_obs;  // gto/gto_planner.py:117-131
+  const VoxelRec* __restrict__ rec = (t < sp.ts) ? sc.r_all : sc.r_obs;
   const double bx = bp.base_pos[3 * b], by = bp.base_pos[3 * b + 1], bz = bp.base_pos[3 * b + 2];
+  const double cx = (bx - sc.ox) * sc.rinv, cy = (by - sc.oy) * sc.rinv, cz = (bz - sc.oz) * sc.rinv;
   const bool need_grad = !fixed_mode && sp.grad_mode == GTO_GRAD_CENTRAL_DIFF;
-  const int nyz = sc.ny * sc.nz;
+  const int nz = sc.nz;
 
-  // contiguous chunk range per wave: few link changes -> few wave reductions
+  // contiguous chunk range per wave (points are sorted by link): a wave sees few link changes
   const int C = rb->n_chunks;
   const int c0 = (int)(((long)C * wave) / 4), c1 = (int)(((long)C * (wave + 1)) / 4);
-  double acc[GTO_GRAM];
-#pragma unroll
-  for (int i = 0; i < GTO_GRAM; ++i) acc[i] = 0.0;
-  int cur_link = -1;
 
-#define GTO_FLUSH(link)                                                   \
-  do {                                                                    \
-    _Pragma("unroll") for (int i_ = 0; i_ < GTO_GRAM; ++i_) {             \
-      double v_ = wave_sum(acc[i_]);                                      \
-      if (lane == i_) atomicAdd(&s_gram[(link)*GTO_GRAM + i_], v_);       \
-      acc[i_] = 0.0;                                                      \
-    }                                                                     \
+  // Sparse Gram accumulation.  Most surface points are in free space (zero gradient): a lane whose
+  // point has a non-zero gradient appends its wrench (y x w, w) and cost c to a small per-wave LDS
+  // list; the list is folded into the per-link 6x6 Gram by the wave with ONE accumulator per lane
+  // (lane k < 28 owns Gram entry k for even list slots, lane 28+k for odd slots), so the hot loop
+  // carries no 28-wide per-lane accumulator, needs no cross-lane reduction and its cost follows the
+  // number of points that actually touch the obstacle band.
+  double* lst = s_list + wave * (GTO_LIST_CAP * 8);
+  const int grp = lane < 28 ? 0 : (lane < 56 ? 1 : -1);
+  const int kk = lane - 28 * (grp > 0 ? 1 : 0);  // Gram entry owned by this lane (valid when grp >= 0)
+  int oi = 0, oj = 0;                            // list-entry components multiplied by this lane
+  if (grp >= 0) {
+    if (kk < 21) {
+      int q = 0;
+      for (int i = 0; i < 6; ++i)
+        for (int j = i; j < 6; ++j) {
+          if (q == kk) {
+            oi = i;
+            oj = j;
+          }
+          ++q;
+        }
+    } else {
+      oi = 6;  // cost value c
+      oj = kk - 21;
+    }
+  }
+  double gacc = 0.0;  // this lane's Gram entry of the current link
+  double ss = 0.0;    // sum of c^2 over this lane's points (all links)
+  int cnt = 0, cur_link = -1;
+
+#define GTO_DRAIN()                                                                          \
+  do {                                                                                       \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                                   \
+    __builtin_amdgcn_wave_barrier();                                                         \
+    if (grp >= 0 && kk < 27)                                                                 \
+      for (int e_ = grp; e_ < cnt; e_ += 2) gacc = fma(lst[e_ * 8 + oi], lst[e_ * 8 + oj], gacc); \
+    __builtin_amdgcn_wave_barrier();                                                         \
+    cnt = 0;                                                                                 \
+  } while (0)
+#define GTO_FLUSH(link)                                                                      \
+  do {                                                                                       \
+    if (cnt) GTO_DRAIN();                                                                    \
+    if (grp >= 0 && kk < 27 && gacc != 0.0) atomicAdd(&s_gram[(link)*GTO_GRAM + kk], gacc);  \
+    gacc = 0.0;                                                                              \
   } while (0)
 
+  // software prefetch: the next chunk's descriptor and point coordinates are requested before the
+  // current chunk is processed, so two memory round trips (points, voxel records) overlap
+  Chunk ch = {0, 0, 0, 0};
+  double x0 = 0.0, x1 = 0.0, x2 = 0.0;
+  if (c0 < c1) {
+    ch = chunks[c0];
+    if (lane < ch.count) {
+      x0 = px[ch.start + lane];
+      x1 = py[ch.start + lane];
+      x2 = pz[ch.start + lane];
+    }
+  }
+#pragma unroll 1
   for (int c = c0; c < c1; ++c) {
-    const Chunk ch = chunks[c];
+    Chunk nch = {0, 0, 0, 0};
+    double n0 = 0.0, n1 = 0.0, n2 = 0.0;
+    if (c + 1 < c1) {
+      nch = chunks[c + 1];
+      if (lane < nch.count) {
+        n0 = px[nch.start + lane];
+        n1 = py[nch.start + lane];
+        n2 = pz[nch.start + lane];
+      }
+    }
     if (ch.link != cur_link) {
       if (cur_link >= 0) GTO_FLUSH(cur_link);
       cur_link = ch.link;
     }
-    if (lane < ch.count) {
-      const int p = ch.start + lane;
+    {
+      // lanes past the end of the chunk carry x = 0 and have their cost and gradient zeroed
+      const bool valid = lane < ch.count;
       const double* V = s_vis + 12 * ch.link;
-      const double x0 = px[p], x1 = py[p], x2 = pz[p];
-      // point in the robot-base frame and in the field frame (gto/gto_planner.py:114-116)
+      // point in the robot-base frame (gto/gto_planner.py:114-116); the field frame adds base_position
       const double y0 = V[0] * x0 + V[1] * x1 + V[2] * x2 + V[3];
       const double y1 = V[4] * x0 + V[5] * x1 + V[6] * x2 + V[7];
       const double y2 = V[8] * x0 + V[9] * x1 + V[10] * x2 + V[11];
-      const int ix = voxel_axis(y0 + bx, sc.ox, sc.res, sc.rinv, sc.nx);
-      const int iy = voxel_axis(y1 + by, sc.oy, sc.res, sc.rinv, sc.ny);
-      const int iz = voxel_axis(y2 + bz, sc.oz, sc.res, sc.rinv, sc.nz);
-      const int off = iz + sc.nz * (iy + sc.ny * ix);
-      const double cval = (double)field[off];
-      acc[27] += cval * cval;
-      if (need_grad) {
-        // central differences with clipped neighbours, divisor stays 2*res (gto/sdf_callback.py:90-114)
-        const int ixp = min(ix + 1, sc.nx - 1), ixm = max(ix - 1, 0);
-        const int iyp = min(iy + 1, sc.ny - 1), iym = max(iy - 1, 0);
-        const int izp = min(iz + 1, sc.nz - 1), izm = max(iz - 1, 0);
-        const int rowyz = iz + sc.nz * iy, rowx = sc.nz * (iy + sc.ny * ix);
-        const float fxp = field[rowyz + nyz * ixp], fxm = field[rowyz + nyz * ixm];
-        const float fyp = field[iz + sc.nz * (iyp + sc.ny * ix)], fym = field[iz + sc.nz * (iym + sc.ny * ix)];
-        const float fzp = field[izp + rowx], fzm = field[izm + rowx];
-        const double w0 = ((double)fxp - (double)fxm) * sc.inv2r;
-        const double w1 = ((double)fyp - (double)fym) * sc.inv2r;
-        const double w2 = ((double)fzp - (double)fzm) * sc.inv2r;
-        if (w0 != 0.0 || w1 != 0.0 || w2 != 0.0) {
-          // wrench of the gradient about the base-frame origin: (y x w, w)
-          double om[6];
-          om[0] = y1 * w2 - y2 * w1;
-          om[1] = y2 * w0 - y0 * w2;
-          om[2] = y0 * w1 - y1 * w0;
-          om[3] = w0;
-          om[4] = w1;
-          om[5] = w2;
-          int q = 0;
-#pragma unroll
-          for (int i = 0; i < 6; ++i)
-#pragma unroll
-            for (int j = i; j < 6; ++j) acc[q++] += om[i] * om[j];
-#pragma unroll
-          for (int i = 0; i < 6; ++i) acc[21 + i] += cval * om[i];
+      const int ix = voxel_axis_fast(y0, cx, bx, sc.ox, sc.res, sc.rinv, sc.nx);
+      const int iy = voxel_axis_fast(y1, cy, by, sc.oy, sc.res, sc.rinv, sc.ny);
+      const int iz = voxel_axis_fast(y2, cz, bz, sc.oz, sc.res, sc.rinv, sc.nz);
+      const int off = iz + nz * (iy + sc.ny * ix);
+      if (!need_grad) {
+        const double cval = valid ? (double)field[off] : 0.0;
+        ss = fma(cval, cval, ss);
+      } else {
+        // one 32-B voxel record: cost + central differences (gto/sdf_callback.py:90-114); the divisor
+        // stays 2*res also at clipped borders
+        const double4 lo4 = *reinterpret_cast<const double4*>(&rec[off]);  // two 16-B loads, one line
+        const double cval = valid ? (double)__builtin_bit_cast(float, (unsigned)__double2loint(lo4.w)) : 0.0;
+        ss = fma(cval, cval, ss);
+        const double w0 = lo4.x * sc.inv2r;
+        const double w1 = lo4.y * sc.inv2r;
+        const double w2 = lo4.z * sc.inv2r;
+        const bool act = valid && (w0 != 0.0 || w1 != 0.0 || w2 != 0.0);
+        const unsigned long long am = __ballot(act);
+        if (am) {  // wave-uniform
+          if (act) {
+            // wrench of the gradient about the base-frame origin: (y x w, w), then the cost value
+            double* e = lst + (cnt + __popcll(am & ((1ull << lane) - 1ull))) * 8;
+            e[0] = y1 * w2 - y2 * w1;
+            e[1] = y2 * w0 - y0 * w2;
+            e[2] = y0 * w1 - y1 * w0;
+            e[3] = w0;
+            e[4] = w1;
+            e[5] = w2;
+            e[6] = cval;
+          }
+          cnt += __popcll(am);
+          if (cnt > GTO_LIST_CAP - 64) GTO_DRAIN();
         }
       }
     }
+    ch = nch;
+    x0 = n0;
+    x1 = n1;
+    x2 = n2;
   }
   if (cur_link >= 0) GTO_FLUSH(cur_link);
 #undef GTO_FLUSH
+#undef GTO_DRAIN
+  ss = wave_sum(ss);
+  if (lane == 0) atomicAdd(&s_out[BLK_SS], ss);
   __syncthreads();
 
   // projection of the per-link wrench Grams onto the joint screws:
   //   JtJ[i][j] = sum_l [i,j in anc(l)] s_i^T W_l s_j ,  Jtr[i] = sum_l [i in anc(l)] s_i . v_l
-  for (int idx = tid; idx < L * n; idx += 256) {
-    const int l = idx / n, j = idx % n;
-    const double* W = s_gram + l * GTO_GRAM;
-    const double* s = s_screw + 6 * j;
-    const bool on = (rb->link_anc[l] >> j) & 1u;
-    for (int r = 0; r < 6; ++r) {
-      double u = 0.0;
-      if (on)
-        for (int c = 0; c < 6; ++c) u += W[sym6(r, c)] * s[c];
-      s_u[(l * GTO_MAX_OPT + j) * 6 + r] = u;
+  if (!fixed_mode) {
+    for (int idx = tid; idx < L * n; idx += 256) {
+      const int l = idx / n, j = idx % n;
+      const double* W = s_gram + l * GTO_GRAM;
+      const double* sj = s_screw + 6 * j;
+      const bool on = (rb->link_anc[l] >> j) & 1u;
+      for (int r = 0; r < 6; ++r) {
+        double u = 0.0;
+        if (on)
+          for (int c = 0; c < 6; ++c) u += W[sym6(r, c)] * sj[c];
+        s_u[(l * GTO_MAX_OPT + j) * 6 + r] = u;
+      }
     }
-  }
-  __syncthreads();
-  for (int idx = tid; idx < L * 73; idx += 256) {
-    const int l = idx / 73, item = idx % 73;
-    const uint32_t anc = rb->link_anc[l];
-    if (item < 64) {
-      const int i = item >> 3, j = item & 7;
-      if (i < n && j < n && ((anc >> i) & 1u) && ((anc >> j) & 1u)) {
+    __syncthreads();
+    // one thread per output entry, links summed in order (deterministic, no atomics)
+    if (tid < 64) {
+      const int i = tid >> 3, j = tid & 7;
+      double v = 0.0;
+      if (i < n && j < n) {
         const double* si = s_screw + 6 * i;
-        const double* u = s_u + (l * GTO_MAX_OPT + j) * 6;
-        double v = 0.0;
-        for (int r = 0; r < 6; ++r) v += si[r] * u[r];
-        atomicAdd(&s_out[BLK_JTJ + item], v);
+        for (int l = 0; l < L; ++l) {
+          const uint32_t anc = rb->link_anc[l];
+          if (((anc >> i) & 1u) && ((anc >> j) & 1u)) {
+            const double* u = s_u + (l * GTO_MAX_OPT + j) * 6;
+            v += si[0] * u[0] + si[1] * u[1] + si[2] * u[2] + si[3] * u[3] + si[4] * u[4] + si[5] * u[5];
+          }
+        }
       }
-    } else if (item < 72) {
-      const int i = item - 64;
-      if (i < n && ((anc >> i) & 1u)) {
+      s_out[BLK_JTJ + tid] = v;
+    } else if (tid < 72) {
+      const int i = tid - 64;
+      double v = 0.0;
+      if (i < n) {
         const double* si = s_screw + 6 * i;
-        const double* vv = s_gram + l * GTO_GRAM + 21;
-        double v = 0.0;
-        for (int r = 0; r < 6; ++r) v += si[r] * vv[r];
-        atomicAdd(&s_out[BLK_JTR + i], v);
+        for (int l = 0; l < L; ++l)
+          if ((rb->link_anc[l] >> i) & 1u) {
+            const double* vv = s_gram + l * GTO_GRAM + 21;
+            v += si[0] * vv[0] + si[1] * vv[1] + si[2] * vv[2] + si[3] * vv[3] + si[4] * vv[4] + si[5] * vv[5];
+          }
       }
-    } else {
-      atomicAdd(&s_out[BLK_SS], s_gram[l * GTO_GRAM + 27]);
+      s_out[BLK_JTR + i] = v;
     }
   }
   __syncthreads();
@@ -462,30 +714,33 @@ __device__ inline GoalOut goal_terms_wave(const RobotDev* rb, const SolveParams&
   return out;
 }
 
-// Kinematics of the trial trajectory + goal terms + velocity term; one wavefront per instance.
-// Writes vis / screw for the obstacle kernel and fgoal_try / fvel_try / goal blocks (trial slot).
-__device__ inline void trial_kinematics_wave(const RobotDev* rb, const BatchPtrs& bp, const SolveParams& sp, int B,
-                                             int b, int lane, int trial, InstState* st, double* s_gaff, double* s_gscr) {
-  const int T = sp.T, n = rb->n_opt, L = rb->n_links;
-  const double* Q0b = bp.Q0 + (size_t)b * rb->ndof * T;
+// Goal terms + velocity term of the trial trajectory; one wavefront per instance.  Forward kinematics
+// is needed at two waypoints only (final and standoff); the obstacle kernel does its own.
+// s_q [GTO_MAX_DOF], s_fr [GTO_MAX_FRAMES*12], s_gaff [48], s_gscr [2*GTO_MAX_OPT*6] are LDS scratch.
+__device__ inline void trial_goal_terms_wave(const RobotDev* rb, const BatchPtrs& bp, const SolveParams& sp, int B,
+                                             int b, int lane, int trial, InstState* st, double* s_q, double* s_fr,
+                                             double* s_gaff, double* s_gscr) {
+  const int T = sp.T, n = rb->n_opt, ndof = rb->ndof;
+  const double* Q0b = bp.Q0 + (size_t)b * ndof * T;
   const double* Qt = bp.Qtry + (size_t)b * n * T;
-  for (int t = lane; t < T; t += 64) {
-    double q[GTO_MAX_DOF], ge[24];
-    load_full_q(rb, Q0b, Qt, T, t, q);
-    double* vis = bp.vis + ((size_t)b * T + t) * L * 12;
-    double* scr = bp.screw + ((size_t)b * T + t) * n * 6;
-    const bool isg = (t == T - 1), iss = (sp.use_standoff && t == sp.ts);
-    kin_eval(rb, q, vis, scr, (isg || iss) ? ge : nullptr);
-    if (isg) {
-      for (int k = 0; k < 24; ++k) s_gaff[k] = ge[k];
-      for (int k = 0; k < n * 6; ++k) s_gscr[k] = scr[k];
+  for (int which = 0; which < 2; ++which) {
+    if (which == 1 && !sp.use_standoff) break;
+    const int t = which == 0 ? T - 1 : sp.ts;
+    if (lane < ndof) s_q[lane] = Q0b[(size_t)lane * T + t];
+    __syncthreads();
+    if (lane < n) s_q[rb->opt_index[lane]] = Qt[(size_t)lane * T + t];
+    __syncthreads();
+    fk_block(rb, s_q, s_fr, lane);
+    if (lane < 12) {
+      s_gaff[24 * which + lane] = s_fr[12 * rb->frame_gripper + lane];
+      s_gaff[24 * which + 12 + lane] = s_fr[12 * rb->frame_ee + lane];
     }
-    if (iss) {
-      for (int k = 0; k < 24; ++k) s_gaff[24 + k] = ge[k];
-      for (int k = 0; k < n * 6; ++k) s_gscr[GTO_MAX_OPT * 6 + k] = scr[k];
+    if (lane >= 32 && lane < 32 + rb->n_frames) {
+      const int i = lane - 32, j = rb->opt_of_frame[i];
+      if (j >= 0) screw_of_frame(rb, i, s_fr + 12 * i, s_gscr + which * GTO_MAX_OPT * 6 + 6 * j);
     }
+    __syncthreads();
   }
-  __syncthreads();
   double* gblk = bp.goalblk + ((size_t)trial * B + b) * 2 * BLK_STRIDE;
   GoalOut go = goal_terms_wave(rb, sp, bp.goals + (size_t)b * sp.n_max * 16, bp.n_goals[b],
                                bp.standoff ? bp.standoff + (size_t)b * 16 : nullptr, s_gaff, s_gscr, gblk, lane);
@@ -509,6 +764,8 @@ __global__ __launch_bounds__(64) void k_lm_init(const RobotDev* __restrict__ rb,
   const int b = blockIdx.x, lane = threadIdx.x;
   __shared__ double s_gaff[48];
   __shared__ double s_gscr[2 * GTO_MAX_OPT * 6];
+  __shared__ double s_q[GTO_MAX_DOF];
+  __shared__ double s_fr[GTO_MAX_FRAMES * 12];
   const int T = sp.T, n = rb->n_opt;
   InstState* st = bp.state + b;
   if (lane == 0) {
@@ -538,11 +795,25 @@ __global__ __launch_bounds__(64) void k_lm_init(const RobotDev* __restrict__ rb,
     Qc[idx] = v;
   }
   __syncthreads();
-  trial_kinematics_wave(rb, bp, sp, B, b, lane, 1, st, s_gaff, s_gscr);
+  trial_goal_terms_wave(rb, bp, sp, B, b, lane, 1, st, s_q, s_fr, s_gaff, s_gscr);
 }
 
-// dynamic LDS layout of k_lm_step (doubles): Z [m][64] | bfull [m][8] | rhs/y [m][8] | e [m][8] |
-// x [m][8] | Q [8][T] | tile [64] | zv [8] | gaff [48] | gscr [96];  act flags reuse the e array sign.
+// 1/x to full double precision: hardware seed + two Newton steps (no IEEE division sequence)
+__device__ inline double fast_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return r;
+}
+
+// dynamic LDS layout of k_lm_step (doubles): Z [m][64] | A [m][64] | bfull [m][8] | y [m][8] | e [m][8] |
+// x [m][8] | Q [8][T] | gaff [48] | gscr [96] | q [32] | frames [32*12] ; then int act [m][8].
+__device__ inline size_t lm_step_lds_doubles(int T) {
+  const size_t m = (size_t)T - 2;
+  return m * 128 + 4 * m * 8 + 8 * (size_t)T + 48 + 2 * GTO_MAX_OPT * 6 + GTO_MAX_DOF + GTO_MAX_FRAMES * 12;
+}
+
+// One wavefront per instance.  Lane (r,c) = (lane>>3, lane&7) owns entry (r,c) of the 8x8 blocks.
 __global__ __launch_bounds__(64) void k_lm_step(const RobotDev* __restrict__ rb, BatchPtrs bp, SolveParams sp, int B) {
   const int b = blockIdx.x, lane = threadIdx.x;
   InstState* st = bp.state + b;
@@ -550,16 +821,17 @@ __global__ __launch_bounds__(64) void k_lm_step(const RobotDev* __restrict__ rb,
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int T = sp.T, n = rb->n_opt, m = T - 2;
   double* s_Z = smem;
-  double* s_b = s_Z + (size_t)m * 64;
+  double* s_A = s_Z + (size_t)m * 64;
+  double* s_b = s_A + (size_t)m * 64;
   double* s_y = s_b + m * 8;
   double* s_e = s_y + m * 8;
   double* s_x = s_e + m * 8;
   double* s_Q = s_x + m * 8;
-  double* s_tile = s_Q + 8 * T;
-  double* s_zv = s_tile + 64;
-  double* s_gaff = s_zv + 8;
+  double* s_gaff = s_Q + 8 * T;
   double* s_gscr = s_gaff + 48;
-  int* s_act = (int*)(s_gscr + 2 * GTO_MAX_OPT * 6);  // [m][8]
+  double* s_q = s_gscr + 2 * GTO_MAX_OPT * 6;
+  double* s_fr = s_q + GTO_MAX_DOF;
+  int* s_act = (int*)(s_fr + GTO_MAX_FRAMES * 12);  // [m][8]
 
   const int r = lane >> 3, c = lane & 7;
   const int trial = 1 - st->slot;
@@ -584,8 +856,8 @@ __global__ __launch_bounds__(64) void k_lm_step(const RobotDev* __restrict__ rb,
   } else if (f_try < f && st->pred > 0.0) {
     accept = true;
     const double df = f - f_try, rho = df / st->pred;
-    const double s = 2.0 * rho - 1.0;
-    double fac = 1.0 - s * s * s;
+    const double sg = 2.0 * rho - 1.0;
+    double fac = 1.0 - sg * sg * sg;
     fac = fmax(fac, 1.0 / 3.0);
     lambda = fmax(lambda * fac, 1e-12);
     nu = 2.0;
@@ -604,9 +876,18 @@ __global__ __launch_bounds__(64) void k_lm_step(const RobotDev* __restrict__ rb,
   double* Qc = bp.Qcur + (size_t)b * n * T;
   double* Qt = bp.Qtry + (size_t)b * n * T;
   if (accept) {
-    for (int idx = lane; idx < n * T; idx += 64) Qc[idx] = Qt[idx];
     f = f_try;
     slot = trial;
+  }
+  // current iterate into LDS (rows >= n are padding); on accept it is the trial
+  {
+    const double* src = accept ? Qt : Qc;
+    for (int idx = lane; idx < 8 * T; idx += 64) {
+      const int j = idx / T;
+      const double v = (j < n) ? src[idx] : 0.0;
+      s_Q[idx] = v;
+      if (accept && j < n) Qc[idx] = v;
+    }
   }
   if (!done && k >= sp.max_iter) {
     status = GTO_STATUS_MAX_ITER;
@@ -629,27 +910,25 @@ __global__ __launch_bounds__(64) void k_lm_step(const RobotDev* __restrict__ rb,
   }
 
   // ---- P2: normal equations at the current iterate (A = J^T J, b = J^T r; f = sum r^2)
-  for (int idx = lane; idx < 8 * T; idx += 64) {
-    const int j = idx / T;
-    s_Q[idx] = (j < n) ? Qc[(size_t)j * T + idx % T] : 0.0;
-  }
-  __syncthreads();
   const double* oblk = bp.blocks + ((size_t)slot * B + b) * T * BLK_STRIDE;
   const double* gblk = bp.goalblk + ((size_t)slot * B + b) * 2 * BLK_STRIDE;
   const double alpha = sp.alpha;
-  // undamped diagonal block entry A_t[r][c]
-  auto A_entry = [&](int t, int rr, int cc) -> double {
-    if (rr >= n || cc >= n) return 0.0;
-    double v = sp.w_obstacle * oblk[(size_t)t * BLK_STRIDE + BLK_JTJ + rr * 8 + cc];
-    if (t == T - 1) v += gblk[BLK_JTJ + rr * 8 + cc];
-    if (sp.use_standoff && t == sp.ts) v += gblk[BLK_STRIDE + BLK_JTJ + rr * 8 + cc];
-    if (rr == cc) v += (t < T - 1) ? 2.0 * alpha : alpha;
-    return v;
-  };
+  const bool inb = (r < n) && (c < n);
+  // undamped diagonal blocks, one coalesced 512 B read per waypoint
+  for (int s = 0; s < m; ++s) {
+    const int t = s + 2;
+    double v = inb ? sp.w_obstacle * oblk[(size_t)t * BLK_STRIDE + BLK_JTJ + lane] : 0.0;
+    if (inb && r == c) v += (t < T - 1) ? 2.0 * alpha : alpha;
+    s_A[(size_t)s * 64 + lane] = v;
+  }
+  if (inb) {
+    s_A[(size_t)(T - 3) * 64 + lane] += gblk[BLK_JTJ + lane];
+    if (sp.use_standoff) s_A[(size_t)(sp.ts - 2) * 64 + lane] += gblk[BLK_STRIDE + BLK_JTJ + lane];
+  }
   for (int idx = lane; idx < m * 8; idx += 64) {
     const int s = idx >> 3, i = idx & 7, t = s + 2;
     double bv = 0.0;
-    int act = 1;
+    int act = 1;  // padded rows count as frozen
     if (i < n) {
       bv = sp.w_obstacle * oblk[(size_t)t * BLK_STRIDE + BLK_JTR + i];
       if (t == T - 1) bv += gblk[BLK_JTR + i];
@@ -661,59 +940,73 @@ __global__ __launch_bounds__(64) void k_lm_step(const RobotDev* __restrict__ rb,
       act = (qt <= rb->lower[i] && bv > 0.0) || (qt >= rb->upper[i] && bv < 0.0);
     }
     s_b[idx] = bv;
-    s_act[idx] = act;  // padded rows count as frozen
+    s_act[idx] = act;
   }
   __syncthreads();
+  // damped / frozen system; remember which blocks are purely diagonal
+  unsigned long long dense_mask = 0ull;
   for (int s = 0; s < m; ++s) {
-    const int t = s + 2;
-    double v = A_entry(t, r, c);
+    double v = s_A[(size_t)s * 64 + lane];
     const int ar = s_act[s * 8 + r], ac = s_act[s * 8 + c];
     if (ar || ac) v = (r == c) ? 1.0 : 0.0;
     else if (r == c) v *= (1.0 + lambda);
     s_Z[(size_t)s * 64 + lane] = v;
+    if (__any(r != c && v != 0.0)) dense_mask |= 1ull << s;
   }
   for (int idx = lane; idx < m * 8; idx += 64) {
-    const int s = idx >> 3, i = idx & 7;
+    const int s = idx >> 3;
     const int a0 = s_act[idx];
     const int a1 = (s < m - 1) ? s_act[idx + 8] : 1;
     s_e[idx] = (a0 || a1) ? 0.0 : -alpha;
     s_y[idx] = a0 ? 0.0 : -s_b[idx];  // right-hand side
-    (void)i;
   }
   __syncthreads();
 
-  // ---- P3: block-tridiagonal solve, inverse-based Schur recursion (one 8x8 block per step,
-  // lane (r,c) owns entry (r,c); Gauss-Jordan without pivoting: the blocks are SPD)
+  // ---- P3: block-tridiagonal solve by the inverse-based Schur recursion
+  //   S_s = D_s - E_{s-1} Z_{s-1} E_{s-1},  Z_s = S_s^{-1},  z_s = rhs_s - E_{s-1} y_{s-1},  y_s = Z_s z_s
+  // Diagonal blocks (free-space waypoints: only the velocity term) stay diagonal until the first
+  // dense block and are inverted element-wise; dense blocks use Gauss-Jordan without pivoting (SPD),
+  // with the pivot row/column moved by cross-lane shuffles (no LDS round trip, no barrier).
   int fail = 0;
   double Zprev = 0.0;
+  bool zdiag = true;
   for (int s = 0; s < m; ++s) {
     double S = s_Z[(size_t)s * 64 + lane];
     if (s > 0) {
       S -= s_e[(s - 1) * 8 + r] * s_e[(s - 1) * 8 + c] * Zprev;
-      // z_s = rhs_s - e_{s-1} o y_{s-1}
       if (lane < 8) s_y[s * 8 + lane] -= s_e[(s - 1) * 8 + lane] * s_x[(s - 1) * 8 + lane];
     }
+    const bool dense = ((dense_mask >> s) & 1ull) || !zdiag;
+    if (!dense) {
+      if (r == c) {
+        if (!(S > 0.0)) fail = 1;
+        S = fast_rcp(S);
+      } else {
+        S = 0.0;
+      }
+    } else {
+      zdiag = false;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      s_tile[lane] = S;
-      __syncthreads();
-      const double pjj = s_tile[j * 9], prj = s_tile[r * 8 + j], pjc = s_tile[j * 8 + c];
-      __syncthreads();
-      if (!(pjj > 0.0)) fail = 1;
-      const double piv = 1.0 / pjj;
-      if (r == j && c == j) S = piv;
-      else if (r == j) S = pjc * piv;
-      else if (c == j) S = -prj * piv;
-      else S = S - prj * pjc * piv;
+      for (int j = 0; j < 8; ++j) {
+        const double pjj = __shfl(S, j * 9, 64);
+        const double prj = __shfl(S, (lane & 56) | j, 64);
+        const double pjc = __shfl(S, j * 8 + c, 64);
+        if (!(pjj > 0.0)) fail = 1;
+        const double piv = fast_rcp(pjj);
+        if (r == j && c == j) S = piv;
+        else if (r == j) S = pjc * piv;
+        else if (c == j) S = -prj * piv;
+        else S = fma(-prj * piv, pjc, S);
+      }
     }
-    s_Z[(size_t)s * 64 + lane] = S;  // Z_s = S_s^{-1}
+    s_Z[(size_t)s * 64 + lane] = S;  // Z_s
     Zprev = S;
-    // y_s = Z_s z_s  (kept in s_x as scratch during the forward sweep)
+    __syncthreads();  // z_s visible
     double pr = S * s_y[s * 8 + c];
     pr += __shfl_xor(pr, 1, 64);
     pr += __shfl_xor(pr, 2, 64);
     pr += __shfl_xor(pr, 4, 64);
-    if (c == 0) s_x[s * 8 + r] = pr;
+    if (c == 0) s_x[s * 8 + r] = pr;  // y_s (s_x doubles as y during the forward sweep)
     __syncthreads();
   }
   if (__any(fail)) {
@@ -774,9 +1067,8 @@ __global__ __launch_bounds__(64) void k_lm_step(const RobotDev* __restrict__ rb,
   // ---- P5: predicted decrease of the undamped model: -(2 b.s + s^T A s)
   double acc = 0.0;
   for (int s = 0; s < m; ++s) {
-    const int t = s + 2;
     const double sr = s_x[s * 8 + r], scv = s_x[s * 8 + c];
-    double v = A_entry(t, r, c) * sr * scv;
+    double v = s_A[(size_t)s * 64 + lane] * sr * scv;
     if (c == 0) {
       v += 2.0 * s_b[s * 8 + r] * sr;
       if (s < m - 1) v += 2.0 * (-alpha) * sr * s_x[(s + 1) * 8 + r];
@@ -796,8 +1088,8 @@ __global__ __launch_bounds__(64) void k_lm_step(const RobotDev* __restrict__ rb,
     if (accept) st->argmin_cur = st->argmin_try;
   }
   __syncthreads();
-  // ---- P6: kinematics + goal terms of the new trial
-  trial_kinematics_wave(rb, bp, sp, B, b, lane, 1 - slot, st, s_gaff, s_gscr);
+  // ---- P6: goal terms of the new trial (the obstacle kernel evaluates the rest)
+  trial_goal_terms_wave(rb, bp, sp, B, b, lane, 1 - slot, st, s_q, s_fr, s_gaff, s_gscr);
 }
 
 __global__ __launch_bounds__(64) void k_lm_finalize(const RobotDev* __restrict__ rb, BatchPtrs bp, SolveParams sp, int B,
