@@ -257,10 +257,20 @@ int gto_create(const gto_robot_desc* d, const gto_solver_opts* opts, int device,
   for (int i = 0; i < P;) {
     int l = plink[i], j = i;
     while (j < P && plink[j] == l && j - i < GTO_WAVE) ++j;
-    chunks.push_back(Chunk{l, i, j - i, 0});
+    // bounding sphere: centre = mean of the chunk's points, radius = farthest point (+ a hair)
+    double cx = 0, cy = 0, cz = 0;
+    for (int k = i; k < j; ++k) { cx += px[k]; cy += py[k]; cz += pz[k]; }
+    cx /= (j - i); cy /= (j - i); cz /= (j - i);
+    double r2 = 0;
+    for (int k = i; k < j; ++k) {
+      double dx = px[k] - cx, dy = py[k] - cy, dz = pz[k] - cz;
+      r2 = std::max(r2, dx * dx + dy * dy + dz * dz);
+    }
+    chunks.push_back(Chunk{l, i, j - i, 0, cx, cy, cz, std::sqrt(r2) * (1.0 + 1e-9) + 1e-12});
     i = j;
   }
   rb.n_chunks = (int)chunks.size();
+  if (rb.n_chunks > GTO_MAX_ACTIVE) { delete h; return fail(nullptr, GTO_ERR_UNSUPPORTED, "too many surface points (max 65536)"); }
 
   if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return fail(nullptr, GTO_ERR_HIP, "hipStreamCreate failed"); }
   auto up = [&](void** dst, const void* src, size_t bytes) -> bool {
@@ -292,6 +302,8 @@ void gto_destroy(gto_handle* h) {
       (void)hipFree((void*)s.c_all);
       if (s.r_obs != s.r_all) (void)hipFree((void*)s.r_obs);
       (void)hipFree((void*)s.r_all);
+      if (s.d_obs != s.d_all) (void)hipFree((void*)s.d_obs);
+      (void)hipFree((void*)s.d_all);
     }
   }
   (void)hipFree(h->d_scenes);
@@ -355,6 +367,8 @@ int gto_set_scene(gto_handle* h, int32_t id, const float* c_all, const float* c_
     HIPCHK(h, hipFree((void*)s.c_all));
     if (s.r_obs != s.r_all) HIPCHK(h, hipFree((void*)s.r_obs));
     HIPCHK(h, hipFree((void*)s.r_all));
+    if (s.d_obs != s.d_all) HIPCHK(h, hipFree((void*)s.d_obs));
+    HIPCHK(h, hipFree((void*)s.d_all));
     s.valid = 0;
   }
   float *da = nullptr, *dob = nullptr;
@@ -377,12 +391,37 @@ int gto_set_scene(gto_handle* h, int32_t id, const float* c_all, const float* c_
   } else {
     rob = ra;
   }
+  // broad-phase distance fields
+  auto build_dist = [&](const VoxelRec* rec, uint8_t** out) -> int {
+    uint8_t *d0 = nullptr, *d1 = nullptr;
+    HIPCHK(h, hipMalloc((void**)&d0, nvox));
+    HIPCHK(h, hipMalloc((void**)&d1, nvox));
+    hipLaunchKernelGGL(k_dist_init, dim3(nblk), dim3(256), 0, h->stream, rec, d0, (long)nvox);
+    for (int it = 0; it < GTO_DIST_CAP; ++it) {
+      hipLaunchKernelGGL(k_dist_relax, dim3(nblk), dim3(256), 0, h->stream, d0, d1, shape[0], shape[1], shape[2]);
+      std::swap(d0, d1);
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipFree(d1));
+    *out = d0;
+    return GTO_OK;
+  };
+  uint8_t *dista = nullptr, *distb = nullptr;
+  int rcd = build_dist(ra, &dista);
+  if (rcd) return rcd;
+  if (rob != ra) {
+    if ((rcd = build_dist(rob, &distb))) return rcd;
+  } else {
+    distb = dista;
+  }
   HIPCHK(h, hipStreamSynchronize(h->stream));
   HIPCHK(h, hipGetLastError());
   s.c_all = da;
   s.c_obs = dob;
   s.r_all = ra;
   s.r_obs = rob;
+  s.d_all = dista;
+  s.d_obs = distb;
   s.nx = shape[0];
   s.ny = shape[1];
   s.nz = shape[2];
@@ -406,6 +445,8 @@ int gto_drop_scene(gto_handle* h, int32_t id) {
   HIPCHK(h, hipFree((void*)s.c_all));
   if (s.r_obs != s.r_all) HIPCHK(h, hipFree((void*)s.r_obs));
   HIPCHK(h, hipFree((void*)s.r_all));
+  if (s.d_obs != s.d_all) HIPCHK(h, hipFree((void*)s.d_obs));
+  HIPCHK(h, hipFree((void*)s.d_all));
   memset(&s, 0, sizeof s);
   return sync_scene_table(h);
 }

@@ -51,12 +51,17 @@ struct SceneDev {
   const float* c_obs;
   const VoxelRec* r_all;
   const VoxelRec* r_obs;
+  // Chebyshev distance (in voxels, capped) from every voxel to the nearest voxel whose record is
+  // non-zero: lets a whole chunk of surface points be culled with one lookup (broad phase)
+  const uint8_t* d_all;
+  const uint8_t* d_obs;
   int32_t nx, ny, nz, valid;
   double ox, oy, oz, res, rinv, inv2r;
 };
 
 struct Chunk {
   int32_t link, start, count, pad;
+  double cx, cy, cz, r;  // bounding sphere of the chunk's points in the link's visual-mesh frame
 };
 
 // ---------------------------------------------------------------- 3x4 affine helpers (row-major)

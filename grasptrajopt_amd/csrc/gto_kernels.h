@@ -291,6 +291,33 @@ __global__ void k_build_records(const float* __restrict__ c, VoxelRec* __restric
   rec[i] = r;
 }
 
+#define GTO_DIST_CAP 48  // voxels; beyond this the distance saturates
+
+// Broad-phase support (one-time per scene): Chebyshev distance to the nearest non-zero record by
+// iterated 3x3x3 min-plus-one relaxation (exact for the L-infinity metric after GTO_DIST_CAP sweeps).
+__global__ void k_dist_init(const VoxelRec* __restrict__ rec, uint8_t* __restrict__ d, long nvox) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nvox) return;
+  const VoxelRec r = rec[i];
+  d[i] = (r.c != 0.f || r.dx != 0.0 || r.dy != 0.0 || r.dz != 0.0) ? 0 : GTO_DIST_CAP;
+}
+__global__ void k_dist_relax(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int nx, int ny, int nz) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long nvox = (long)nx * ny * nz;
+  if (i >= nvox) return;
+  const int iz = (int)(i % nz), iy = (int)((i / nz) % ny), ix = (int)(i / ((long)nz * ny));
+  int best = in[i];
+  for (int dx = -1; dx <= 1; ++dx)
+    for (int dy = -1; dy <= 1; ++dy)
+      for (int dz = -1; dz <= 1; ++dz) {
+        const int x = ix + dx, y = iy + dy, z = iz + dz;
+        if (x < 0 || y < 0 || z < 0 || x >= nx || y >= ny || z >= nz) continue;
+        const int v = in[(long)z + (long)nz * ((long)y + (long)ny * x)] + 1;
+        best = v < best ? v : best;
+      }
+  out[i] = (uint8_t)(best > GTO_DIST_CAP ? GTO_DIST_CAP : best);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Dominant kernel.  grid.x = 8 * ceil(B/8) * nT  (XCD-aware: all waypoints of one instance, hence all
 // gathers into one scene's field, are issued from the same XCD and share its 4 MiB L2).
@@ -299,6 +326,7 @@ __global__ void k_build_records(const float* __restrict__ c, VoxelRec* __restric
 //             transforms of the collision links and joint screws staged in LDS
 //   main loop one link-uniform chunk of 64 Morton-sorted surface points per wave step
 //   epilogue  per-link 6x6 wrench Grams -> J^T J (n x n), J^T r (n), sum c^2
+#define GTO_MAX_ACTIVE 1024  // chunks per robot the broad phase can list (64 K surface points)
 #define GTO_LIST_CAP 80  // entries of 8 doubles per wave: a full chunk (64) always fits after a drain
 #ifndef GTO_OBS_MIN_WAVES
 #define GTO_OBS_MIN_WAVES 4  // waves per SIMD the register allocator must leave room for
@@ -323,6 +351,9 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
   __shared__ double s_screw[GTO_MAX_OPT * 6];
   __shared__ double s_gram[GTO_MAX_LINKS * GTO_GRAM];
   __shared__ double s_list[4 * GTO_LIST_CAP * 8];  // per-wave wrench lists; reused as s_u in the epilogue
+  __shared__ int s_active[GTO_MAX_ACTIVE];  // broad phase: chunks that may touch a non-zero voxel
+  __shared__ int s_wcount[4];
+  __shared__ int s_nactive;
   __shared__ double s_out[BLK_STRIDE];
   double* s_u = s_list;  // [L][GTO_MAX_OPT][6] <= 1536 doubles
 
@@ -359,9 +390,46 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
   const bool need_grad = !fixed_mode && sp.grad_mode == GTO_GRAD_CENTRAL_DIFF;
   const int nz = sc.nz;
 
-  // contiguous chunk range per wave (points are sorted by link): a wave sees few link changes
+  // ---- broad phase: one thread per chunk transforms the chunk's bounding-sphere centre and looks up
+  // the Chebyshev distance to the nearest non-zero voxel; a chunk whose sphere (radius R voxels, +1
+  // for the floor of the centre) cannot reach one contributes exact zeros and is skipped.  The list
+  // of surviving chunks keeps the link order (ballot prefix), so a wave still sees few link changes.
   const int C = rb->n_chunks;
-  const int c0 = (int)(((long)C * wave) / 4), c1 = (int)(((long)C * (wave + 1)) / 4);
+  const uint8_t* __restrict__ dist = (t < sp.ts) ? sc.d_all : sc.d_obs;
+  if (tid == 0) s_nactive = 0;
+  __syncthreads();
+  for (int base_c = 0; base_c < C; base_c += 256) {
+    const int ci = base_c + tid;
+    bool keep = false;
+    if (ci < C) {
+      const Chunk cc = chunks[ci];
+      const double* V = s_vis + 12 * cc.link;
+      const double u0 = (V[0] * cc.cx + V[1] * cc.cy + V[2] * cc.cz + V[3] + bx - sc.ox) * sc.rinv;
+      const double u1 = (V[4] * cc.cx + V[5] * cc.cy + V[6] * cc.cz + V[7] + by - sc.oy) * sc.rinv;
+      const double u2 = (V[8] * cc.cx + V[9] * cc.cy + V[10] * cc.cz + V[11] + bz - sc.oz) * sc.rinv;
+      const int R = (int)ceil(cc.r * sc.rinv) + 2;  // sphere radius in voxels, + centre floor + index rounding
+      const int k0 = (int)floor(u0), k1 = (int)floor(u1), k2 = (int)floor(u2);
+      keep = true;
+      // only spheres that lie inside the grid (no clipped indices) and are closer than the cap can be culled
+      if (R < GTO_DIST_CAP && k0 - R >= 0 && k1 - R >= 0 && k2 - R >= 0 && k0 + R < sc.nx && k1 + R < sc.ny && k2 + R < sc.nz)
+        keep = (int)dist[k2 + nz * (k1 + sc.ny * k0)] <= R;
+    }
+    const unsigned long long bm = __ballot(keep);
+    if (lane == 0) s_wcount[wave] = __popcll(bm);
+    __syncthreads();
+    int woff = s_nactive;
+    for (int w = 0; w < wave; ++w) woff += s_wcount[w];
+    if (keep) {
+      const int pos = woff + __popcll(bm & ((1ull << lane) - 1ull));
+      if (pos < GTO_MAX_ACTIVE) s_active[pos] = ci;
+    }
+    __syncthreads();
+    if (tid == 0) s_nactive = min(s_nactive + s_wcount[0] + s_wcount[1] + s_wcount[2] + s_wcount[3], GTO_MAX_ACTIVE);
+    __syncthreads();
+  }
+  const int NA = s_nactive;
+  // contiguous range of surviving chunks per wave
+  const int c0 = (int)(((long)NA * wave) / 4), c1 = (int)(((long)NA * (wave + 1)) / 4);
 
   // Sparse Gram accumulation.  Most surface points are in free space (zero gradient): a lane whose
   // point has a non-zero gradient appends its wrench (y x w, w) and cost c to a small per-wave LDS
@@ -411,10 +479,10 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
 
   // software prefetch: the next chunk's descriptor and point coordinates are requested before the
   // current chunk is processed, so two memory round trips (points, voxel records) overlap
-  Chunk ch = {0, 0, 0, 0};
+  Chunk ch = {0, 0, 0, 0, 0, 0, 0, 0};
   double x0 = 0.0, x1 = 0.0, x2 = 0.0;
   if (c0 < c1) {
-    ch = chunks[c0];
+    ch = chunks[s_active[c0]];
     if (lane < ch.count) {
       x0 = px[ch.start + lane];
       x1 = py[ch.start + lane];
@@ -423,10 +491,10 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
   }
 #pragma unroll 1
   for (int c = c0; c < c1; ++c) {
-    Chunk nch = {0, 0, 0, 0};
+    Chunk nch = {0, 0, 0, 0, 0, 0, 0, 0};
     double n0 = 0.0, n1 = 0.0, n2 = 0.0;
     if (c + 1 < c1) {
-      nch = chunks[c + 1];
+      nch = chunks[s_active[c + 1]];
       if (lane < nch.count) {
         n0 = px[nch.start + lane];
         n1 = py[nch.start + lane];
