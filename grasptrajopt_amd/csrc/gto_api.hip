@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -12,6 +13,7 @@
 #include "gto_kernels.h"
 
 #define GTO_VERSION 1000
+#define GTO_MAX_GROUPS 8
 
 static std::string g_create_error;
 
@@ -37,6 +39,10 @@ struct gto_handle {
   DevBuf state, Qcur, Qtry, vis, screw, blocks, goalblk, ssfixed, ndone;
   int32_t* h_ndone = nullptr;  // pinned
   int check_every = 8;
+  int n_groups = 1;
+  long long* dbg = nullptr;
+  hipStream_t gstream[GTO_MAX_GROUPS] = {nullptr};
+  hipEvent_t ev_fork = nullptr, ev_join[GTO_MAX_GROUPS] = {nullptr};
   // staging for the host-pointer entry points
   DevBuf in[8], out[8];
   // profiling of the dominant kernel
@@ -105,7 +111,7 @@ static int validate_opts(const gto_solver_opts* o, std::string& why) {
 
 static size_t lm_lds_bytes(int T) {
   size_t m = (size_t)T - 2;
-  size_t dbl = m * 128 + 4 * m * 8 + 8 * (size_t)T + 48 + 2 * GTO_MAX_OPT * 6 + GTO_MAX_DOF + GTO_MAX_FRAMES * 12;
+  size_t dbl = m * 128 + 4 * m * 8 + 8 * (size_t)T + 48 + 2 * GTO_MAX_OPT * 6 + 2 * GTO_MAX_DOF + 2 * GTO_MAX_FRAMES * 12;
   return dbl * sizeof(double) + m * 8 * sizeof(int) + 64;
 }
 
@@ -136,6 +142,9 @@ int gto_create(const gto_robot_desc* d, const gto_solver_opts* opts, int device,
     (void)hipGetDevice(&h->device);
   }
   h->opts = *opts;
+  if (const char* e = getenv("GTO_GROUPS")) h->n_groups = std::max(1, std::min(GTO_MAX_GROUPS, atoi(e)));
+  if (const char* e = getenv("GTO_CHECK_EVERY")) h->check_every = atoi(e);
+  if (getenv("GTO_DEBUG_TIMING")) { (void)hipMalloc((void**)&h->dbg, 16 * sizeof(long long)); (void)hipMemset(h->dbg, 0, 16 * sizeof(long long)); }
   RobotDev& rb = h->rb;
   memset(&rb, 0, sizeof rb);
   rb.n_frames = d->n_frames;
@@ -316,6 +325,11 @@ void gto_destroy(gto_handle* h) {
   (void)hipFree(h->d_chunks);
   DevBuf* bufs[] = {&h->state, &h->Qcur, &h->Qtry, &h->vis, &h->screw, &h->blocks, &h->goalblk, &h->ssfixed, &h->ndone};
   if (h->h_ndone) (void)hipHostFree(h->h_ndone);
+  for (int g = 0; g < GTO_MAX_GROUPS; ++g) {
+    if (h->gstream[g]) (void)hipStreamDestroy(h->gstream[g]);
+    if (h->ev_join[g]) (void)hipEventDestroy(h->ev_join[g]);
+  }
+  if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   for (DevBuf* b : bufs) (void)hipFree(b->p);
   for (auto& b : h->in) (void)hipFree(b.p);
   for (auto& b : h->out) (void)hipFree(b.p);
@@ -465,6 +479,15 @@ int gto_last_kernel_time(gto_handle* h, double* total_ms, int32_t* launches) {
 }
 
 // -------------------------------------------------------------------------------------------------
+static int ensure_group_streams(gto_handle* h, int G) {
+  if (!h->ev_fork) HIPCHK(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+  for (int g = 0; g < G; ++g) {
+    if (!h->gstream[g]) HIPCHK(h, hipStreamCreateWithFlags(&h->gstream[g], hipStreamNonBlocking));
+    if (!h->ev_join[g]) HIPCHK(h, hipEventCreateWithFlags(&h->ev_join[g], hipEventDisableTiming));
+  }
+  return GTO_OK;
+}
+
 static SolveParams make_params(const gto_handle* h, int n_max, bool use_standoff) {
   const gto_solver_opts& o = h->opts;
   SolveParams sp;
@@ -516,6 +539,7 @@ static BatchPtrs make_ptrs(gto_handle* h, const int32_t* scene_id, const double*
   bp.goalblk = (double*)h->goalblk.p;
   bp.ss_fixed = (double*)h->ssfixed.p;
   bp.n_done = (int32_t*)h->ndone.p;
+  bp.dbg = h->dbg;
   return bp;
 }
 
@@ -570,24 +594,92 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
   h->last_launches = 0;
   h->last_ms = 0.0;
 
-  HIPCHK(h, hipMemsetAsync(bp.n_done, 0, sizeof(int32_t), st));
-  hipLaunchKernelGGL(k_lm_init, dim3(B), dim3(64), 0, st, h->d_rb, bp, sp, B, 0);
-  if ((rc = launch_obstacle(h, st, bp, sp, B, 0, 2, 1, false))) return rc;
+  // The batch is split into up to GTO_MAX_GROUPS independent groups, each with its own HIP stream: the
+  // step kernel of one group (latency-bound, few workgroups) overlaps the obstacle kernel of the
+  // others (throughput-bound), so neither phase leaves the GPU idle.  Groups share nothing.
+  int G = h->n_groups;
+  while (G > 1 && B / G < 8) --G;
+  if ((rc = ensure_group_streams(h, G))) return rc;
+  struct Group {
+    int off, n;
+    BatchPtrs bp;
+    hipStream_t st;
+    bool live;
+  } grp[GTO_MAX_GROUPS];
+  const size_t ndof = h->rb.ndof, nopt = h->rb.n_opt;
+  HIPCHK(h, hipMemsetAsync(bp.n_done, 0, GTO_MAX_GROUPS * sizeof(int32_t), st));
+  if (G > 1) HIPCHK(h, hipEventRecord(h->ev_fork, st));
+  for (int g = 0; g < G; ++g) {
+    Group& gr = grp[g];
+    gr.off = (int)(((long)B * g) / G);
+    gr.n = (int)(((long)B * (g + 1)) / G) - gr.off;
+    gr.st = (G == 1) ? st : h->gstream[g];
+    gr.live = true;
+    const size_t o = gr.off;
+    gr.bp = bp;
+    gr.bp.scene_id += o;
+    gr.bp.qc += o * ndof;
+    gr.bp.goals += o * n_max * 16;
+    gr.bp.n_goals += o;
+    if (gr.bp.standoff) gr.bp.standoff += o * 16;
+    gr.bp.base_pos += o * 3;
+    gr.bp.Q0 += o * ndof * T;
+    gr.bp.state += o;
+    gr.bp.Qcur += o * nopt * T;
+    gr.bp.Qtry += o * nopt * T;
+    gr.bp.blocks += 2 * o * T * BLK_STRIDE;  // the two slots of a group are contiguous: [2][n][T][..]
+    gr.bp.goalblk += 2 * o * 2 * BLK_STRIDE;
+    gr.bp.ss_fixed += o * 2;
+    gr.bp.n_done += g;
+    if (G > 1) HIPCHK(h, hipStreamWaitEvent(gr.st, h->ev_fork, 0));
+    hipLaunchKernelGGL(k_lm_init, dim3(gr.n), dim3(64), 0, gr.st, h->d_rb, gr.bp, sp, gr.n, 0);
+    if ((rc = launch_obstacle(h, gr.st, gr.bp, sp, gr.n, 0, 2, 1, false))) return rc;
+  }
   // one round = evaluate the trial trajectory (obstacle kernel) + accept/solve/new trial (step kernel);
   // instances that are done exit both kernels immediately
-  for (int k = 0; k <= sp.max_iter; ++k) {
-    if ((rc = launch_obstacle(h, st, bp, sp, B, 2, T - 2, 0, h->profiling))) return rc;
-    hipLaunchKernelGGL(k_lm_step, dim3(B), dim3(64), h->lm_lds, st, h->d_rb, bp, sp, B);
-    // early exit: every few rounds look at the finished-instance counter (one 4-byte read-back)
+  int n_live = G;
+  for (int k = 0; k <= sp.max_iter && n_live > 0; ++k) {
+    for (int g = 0; g < G; ++g) {
+      Group& gr = grp[g];
+      if (!gr.live) continue;
+      if ((rc = launch_obstacle(h, gr.st, gr.bp, sp, gr.n, 2, T - 2, 0, h->profiling))) return rc;
+      hipLaunchKernelGGL(k_lm_step, dim3(gr.n), dim3(64), h->lm_lds, gr.st, h->d_rb, gr.bp, sp, gr.n);
+    }
+    // early exit: every few rounds look at the finished-instance counters (4-byte read-backs)
     if (h->check_every > 0 && (k % h->check_every) == h->check_every - 1 && k < sp.max_iter) {
-      HIPCHK(h, hipMemcpyAsync(h->h_ndone, bp.n_done, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-      HIPCHK(h, hipStreamSynchronize(st));
-      if (*h->h_ndone >= B) break;
+      for (int g = 0; g < G; ++g)
+        if (grp[g].live)
+          HIPCHK(h, hipMemcpyAsync(h->h_ndone + g, grp[g].bp.n_done, sizeof(int32_t), hipMemcpyDeviceToHost, grp[g].st));
+      for (int g = 0; g < G; ++g) {
+        if (!grp[g].live) continue;
+        HIPCHK(h, hipStreamSynchronize(grp[g].st));
+        if (h->h_ndone[g] >= grp[g].n) {
+          grp[g].live = false;
+          --n_live;
+        }
+      }
     }
   }
-  hipLaunchKernelGGL(k_lm_finalize, dim3(B), dim3(64), 0, st, h->d_rb, bp, sp, B, Q_out, dQ_out, cost_out, iters_out,
-                     status_out);
+  for (int g = 0; g < G; ++g) {
+    Group& gr = grp[g];
+    const size_t o = gr.off;
+    hipLaunchKernelGGL(k_lm_finalize, dim3(gr.n), dim3(64), 0, gr.st, h->d_rb, gr.bp, sp, gr.n,
+                       Q_out ? Q_out + o * ndof * T : nullptr, dQ_out ? dQ_out + o * ndof * (T - 1) : nullptr,
+                       cost_out ? cost_out + o : nullptr, iters_out ? iters_out + o : nullptr,
+                       status_out ? status_out + o : nullptr);
+    if (G > 1) {
+      HIPCHK(h, hipEventRecord(h->ev_join[g], gr.st));
+      HIPCHK(h, hipStreamWaitEvent(st, h->ev_join[g], 0));
+    }
+  }
   HIPCHK(h, hipGetLastError());
+  if (h->dbg) {
+    HIPCHK(h, hipStreamSynchronize(st));
+    long long t[16];
+    HIPCHK(h, hipMemcpy(t, h->dbg, sizeof t, hipMemcpyDeviceToHost));
+    fprintf(stderr, "[gto dbg] step-kernel phases (cycles) P0+P1 %lld | P2 %lld | diag %lld | dense %lld | back %lld | P4 %lld | P5 %lld | P6 %lld | s_dense %lld\n",
+            t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3], t[5] - t[4], t[6] - t[5], t[7] - t[6], t[8] - t[7], t[9]);
+  }
   if (h->profiling) {
     HIPCHK(h, hipStreamSynchronize(st));
     double tot = 0.0;

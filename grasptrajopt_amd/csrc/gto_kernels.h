@@ -46,6 +46,7 @@ struct BatchPtrs {
   double* goalblk;   // [2][B][2][BLK_STRIDE]
   double* ss_fixed;  // [B][2]  sum c^2 of the two pinned waypoints
   int32_t* n_done;   // [1]     instances that have finished
+  long long* dbg;    // optional: phase timestamps of instance 0's step kernel (GTO_DEBUG_TIMING)
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -182,6 +183,72 @@ __device__ inline void fk_block(const RobotDev* rb, const double* s_q, double* s
       O[1] = t1;
       O[2] = t2;
       O[3] = t3;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  __syncthreads();
+}
+
+// Forward kinematics of TWO configurations at once by one wavefront: lanes 0-31 work on s_q[0..],
+// s_fr[0..], lanes 32-63 on s_q[GTO_MAX_DOF..], s_fr[GTO_MAX_FRAMES*12..] (same math as fk_block).
+__device__ inline void fk_pair_wave(const RobotDev* rb, const double* s_q2, double* s_fr2, int lane) {
+  const int half = lane >> 5, l = lane & 31;
+  const double* s_q = s_q2 + half * GTO_MAX_DOF;
+  double* s_fr = s_fr2 + half * GTO_MAX_FRAMES * 12;
+  const int F = rb->n_frames;
+  if (l < F) {
+    const int jt = rb->joint_type[l];
+    const double* O = rb->origin[l];
+    double* Lo = s_fr + 12 * l;
+    if (jt == GTO_JOINT_REVOLUTE) {
+      const double th = s_q[rb->q_index[l]];
+      const double sn = sin(th), cs = cos(th), c1 = 1.0 - cs;
+      const double u0 = rb->axis_unit[l][0], u1 = rb->axis_unit[l][1], u2 = rb->axis_unit[l][2];
+      const double R00 = cs + c1 * u0 * u0, R01 = c1 * u0 * u1 - sn * u2, R02 = c1 * u0 * u2 + sn * u1;
+      const double R10 = c1 * u1 * u0 + sn * u2, R11 = cs + c1 * u1 * u1, R12 = c1 * u1 * u2 - sn * u0;
+      const double R20 = c1 * u2 * u0 - sn * u1, R21 = c1 * u2 * u1 + sn * u0, R22 = cs + c1 * u2 * u2;
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const double o0 = O[4 * r], o1 = O[4 * r + 1], o2 = O[4 * r + 2];
+        Lo[4 * r] = o0 * R00 + o1 * R10 + o2 * R20;
+        Lo[4 * r + 1] = o0 * R01 + o1 * R11 + o2 * R21;
+        Lo[4 * r + 2] = o0 * R02 + o1 * R12 + o2 * R22;
+        Lo[4 * r + 3] = O[4 * r + 3];
+      }
+    } else if (jt == GTO_JOINT_PRISMATIC) {
+      const double qi = s_q[rb->q_index[l]];
+      const double t0 = qi * rb->axis_unit[l][0], t1 = qi * rb->axis_unit[l][1], t2 = qi * rb->axis_unit[l][2];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const double o0 = O[4 * r], o1 = O[4 * r + 1], o2 = O[4 * r + 2];
+        Lo[4 * r] = o0;
+        Lo[4 * r + 1] = o1;
+        Lo[4 * r + 2] = o2;
+        Lo[4 * r + 3] = o0 * t0 + o1 * t1 + o2 * t2 + O[4 * r + 3];
+      }
+    } else {
+      for (int k = 0; k < 12; ++k) Lo[k] = O[k];
+    }
+  }
+  __syncthreads();
+  if (l < 3) {
+    for (int i = 0; i < F; ++i) {
+      const int p = rb->parent[i];
+      if (p < 0) continue;
+      const double* P = s_fr + 12 * p + 4 * l;
+      const double* Lm = s_fr + 12 * i;
+      const double p0 = P[0], p1 = P[1], p2 = P[2], p3 = P[3];
+      const double t0 = p0 * Lm[0] + p1 * Lm[4] + p2 * Lm[8];
+      const double t1 = p0 * Lm[1] + p1 * Lm[5] + p2 * Lm[9];
+      const double t2 = p0 * Lm[2] + p1 * Lm[6] + p2 * Lm[10];
+      const double t3 = p0 * Lm[3] + p1 * Lm[7] + p2 * Lm[11] + p3;
+      __builtin_amdgcn_wave_barrier();
+      double* Oo = s_fr + 12 * i + 4 * l;
+      Oo[0] = t0;
+      Oo[1] = t1;
+      Oo[2] = t2;
+      Oo[3] = t3;
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
     }
@@ -749,33 +816,40 @@ __device__ inline GoalOut goal_terms_wave(const RobotDev* rb, const SolveParams&
   out.f_goal = best;
   out.argmin = besti;
   if (goalblk_out) {
+    // Gauss-Newton blocks of the arg-min goal: lanes 0-31 the final waypoint, lanes 32-63 the standoff
     const int n = rb->n_opt;
     const uint32_t anc = rb->frame_anc[rb->frame_gripper];
-    for (int which = 0; which < 2; ++which) {
-      double* blk = goalblk_out + which * BLK_STRIDE;
-      if (which == 1 && !sp.use_standoff) {
-        for (int i = lane; i < BLK_STRIDE; i += 64) blk[i] = 0.0;
-        continue;
-      }
+    const int which = lane >> 5, l = lane & 31;
+    double* blk = goalblk_out + which * BLK_STRIDE;
+    if (which == 1 && !sp.use_standoff) {
+      for (int i = l; i < BLK_STRIDE; i += 32) blk[i] = 0.0;
+    } else {
       double Y[12], W21[21], v6[6];
       goal_target(s_gaff + 24 * which, goals + 16 * besti, which ? standoff : nullptr, Y);
       goal_gram_moments(rb, s_gaff + 24 * which, Y, W21, v6);
       const double* S = s_gscr + which * GTO_MAX_OPT * 6;
-      const int i = lane >> 3, j = lane & 7;
-      double v = 0.0;
-      if (i < n && j < n && ((anc >> i) & 1u) && ((anc >> j) & 1u)) {
-        for (int r = 0; r < 6; ++r) {
-          double u = 0.0;
-          for (int c = 0; c < 6; ++c) u += W21[sym6(r, c)] * S[6 * j + c];
-          v += S[6 * i + r] * u;
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2) {
+        const int e = l + 32 * h2, i = e >> 3, j = e & 7;
+        double v = 0.0;
+        if (i < n && j < n && ((anc >> i) & 1u) && ((anc >> j) & 1u)) {
+#pragma unroll
+          for (int r = 0; r < 6; ++r) {
+            double u = 0.0;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) u += W21[sym6(r, c)] * S[6 * j + c];
+            v += S[6 * i + r] * u;
+          }
         }
+        blk[BLK_JTJ + e] = v;
       }
-      blk[BLK_JTJ + lane] = v;
-      if (lane < 8) {
+      if (l < 8) {
         double g = 0.0;
-        if (lane < n && ((anc >> lane) & 1u))
-          for (int r = 0; r < 6; ++r) g += S[6 * lane + r] * v6[r];
-        blk[BLK_JTR + lane] = g;
+        if (l < n && ((anc >> l) & 1u)) {
+#pragma unroll
+          for (int r = 0; r < 6; ++r) g += S[6 * l + r] * v6[r];
+        }
+        blk[BLK_JTR + l] = g;
       }
     }
   }
@@ -791,21 +865,24 @@ __device__ inline void trial_goal_terms_wave(const RobotDev* rb, const BatchPtrs
   const int T = sp.T, n = rb->n_opt, ndof = rb->ndof;
   const double* Q0b = bp.Q0 + (size_t)b * ndof * T;
   const double* Qt = bp.Qtry + (size_t)b * n * T;
-  for (int which = 0; which < 2; ++which) {
-    if (which == 1 && !sp.use_standoff) break;
+  {
+    // both waypoints at once: lanes 0-31 the final waypoint, lanes 32-63 the standoff waypoint
+    const int which = lane >> 5, l = lane & 31;
     const int t = which == 0 ? T - 1 : sp.ts;
-    if (lane < ndof) s_q[lane] = Q0b[(size_t)lane * T + t];
+    if (l < ndof) s_q[which * GTO_MAX_DOF + l] = Q0b[(size_t)l * T + t];
     __syncthreads();
-    if (lane < n) s_q[rb->opt_index[lane]] = Qt[(size_t)lane * T + t];
+    if (l < n) s_q[which * GTO_MAX_DOF + rb->opt_index[l]] = Qt[(size_t)l * T + t];
     __syncthreads();
-    fk_block(rb, s_q, s_fr, lane);
-    if (lane < 12) {
-      s_gaff[24 * which + lane] = s_fr[12 * rb->frame_gripper + lane];
-      s_gaff[24 * which + 12 + lane] = s_fr[12 * rb->frame_ee + lane];
+    fk_pair_wave(rb, s_q, s_fr, lane);
+    const double* fr = s_fr + which * GTO_MAX_FRAMES * 12;
+    if (l < 12) {
+      s_gaff[24 * which + l] = fr[12 * rb->frame_gripper + l];
+      s_gaff[24 * which + 12 + l] = fr[12 * rb->frame_ee + l];
     }
-    if (lane >= 32 && lane < 32 + rb->n_frames) {
-      const int i = lane - 32, j = rb->opt_of_frame[i];
-      if (j >= 0) screw_of_frame(rb, i, s_fr + 12 * i, s_gscr + which * GTO_MAX_OPT * 6 + 6 * j);
+    if (l >= 12 && l < 12 + n) {  // screw of optimised joint j = l - 12
+      const int j = l - 12;
+      for (int i = 0; i < rb->n_frames; ++i)
+        if (rb->opt_of_frame[i] == j) screw_of_frame(rb, i, fr + 12 * i, s_gscr + which * GTO_MAX_OPT * 6 + 6 * j);
     }
     __syncthreads();
   }
@@ -832,8 +909,8 @@ __global__ __launch_bounds__(64) void k_lm_init(const RobotDev* __restrict__ rb,
   const int b = blockIdx.x, lane = threadIdx.x;
   __shared__ double s_gaff[48];
   __shared__ double s_gscr[2 * GTO_MAX_OPT * 6];
-  __shared__ double s_q[GTO_MAX_DOF];
-  __shared__ double s_fr[GTO_MAX_FRAMES * 12];
+  __shared__ double s_q[2 * GTO_MAX_DOF];
+  __shared__ double s_fr[2 * GTO_MAX_FRAMES * 12];
   const int T = sp.T, n = rb->n_opt;
   InstState* st = bp.state + b;
   if (lane == 0) {
@@ -898,12 +975,13 @@ __global__ __launch_bounds__(64) void k_lm_step(const RobotDev* __restrict__ rb,
   double* s_gaff = s_Q + 8 * T;
   double* s_gscr = s_gaff + 48;
   double* s_q = s_gscr + 2 * GTO_MAX_OPT * 6;
-  double* s_fr = s_q + GTO_MAX_DOF;
-  int* s_act = (int*)(s_fr + GTO_MAX_FRAMES * 12);  // [m][8]
+  double* s_fr = s_q + 2 * GTO_MAX_DOF;
+  int* s_act = (int*)(s_fr + 2 * GTO_MAX_FRAMES * 12);  // [m][8]
 
   const int r = lane >> 3, c = lane & 7;
   const int trial = 1 - st->slot;
 
+  if (bp.dbg && b == 0 && lane == 0) bp.dbg[0] = clock64();
   // ---- P0: objective of the trial point
   double fo = 0.0;
   {
@@ -977,18 +1055,32 @@ __global__ __launch_bounds__(64) void k_lm_step(const RobotDev* __restrict__ rb,
     return;
   }
 
+  if (bp.dbg && b == 0 && lane == 0) bp.dbg[1] = clock64();
   // ---- P2: normal equations at the current iterate (A = J^T J, b = J^T r; f = sum r^2)
   const double* oblk = bp.blocks + ((size_t)slot * B + b) * T * BLK_STRIDE;
   const double* gblk = bp.goalblk + ((size_t)slot * B + b) * 2 * BLK_STRIDE;
   const double alpha = sp.alpha;
   const bool inb = (r < n) && (c < n);
-  // undamped diagonal blocks, one coalesced 512 B read per waypoint
-  for (int s = 0; s < m; ++s) {
-    const int t = s + 2;
-    double v = inb ? sp.w_obstacle * oblk[(size_t)t * BLK_STRIDE + BLK_JTJ + lane] : 0.0;
-    if (inb && r == c) v += (t < T - 1) ? 2.0 * alpha : alpha;
-    s_A[(size_t)s * 64 + lane] = v;
+  // undamped diagonal blocks, one coalesced 512 B read per waypoint; loads are issued eight at a time
+  // so their latencies overlap instead of serialising
+  for (int s0 = 0; s0 < m; s0 += 8) {
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int s = s0 + u;
+      v[u] = (inb && s < m) ? oblk[(size_t)(s + 2) * BLK_STRIDE + BLK_JTJ + lane] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int s = s0 + u, t = s + 2;
+      if (s < m) {
+        double a = sp.w_obstacle * v[u];
+        if (inb && r == c) a += (t < T - 1) ? 2.0 * alpha : alpha;
+        s_A[(size_t)s * 64 + lane] = a;
+      }
+    }
   }
+  __syncthreads();
   if (inb) {
     s_A[(size_t)(T - 3) * 64 + lane] += gblk[BLK_JTJ + lane];
     if (sp.use_standoff) s_A[(size_t)(sp.ts - 2) * 64 + lane] += gblk[BLK_STRIDE + BLK_JTJ + lane];
@@ -1030,52 +1122,62 @@ __global__ __launch_bounds__(64) void k_lm_step(const RobotDev* __restrict__ rb,
   }
   __syncthreads();
 
+  if (bp.dbg && b == 0 && lane == 0) bp.dbg[2] = clock64();
   // ---- P3: block-tridiagonal solve by the inverse-based Schur recursion
   //   S_s = D_s - E_{s-1} Z_{s-1} E_{s-1},  Z_s = S_s^{-1},  z_s = rhs_s - E_{s-1} y_{s-1},  y_s = Z_s z_s
-  // Diagonal blocks (free-space waypoints: only the velocity term) stay diagonal until the first
-  // dense block and are inverted element-wise; dense blocks use Gauss-Jordan without pivoting (SPD),
-  // with the pivot row/column moved by cross-lane shuffles (no LDS round trip, no barrier).
+  //   x_s = y_s - Z_s E_s x_{s+1}
+  // Leading diagonal stretch (free-space waypoints carry only the velocity term, so S stays diagonal
+  // until the first dense block): a scalar recurrence on the diagonal lanes, ~6 dependent FMAs per
+  // waypoint.  Dense blocks: Gauss-Jordan without pivoting (SPD) with the pivot row/column moved by
+  // cross-lane shuffles and the mat-vec reductions done in registers; no LDS round trip, no barrier.
   int fail = 0;
-  double Zprev = 0.0;
-  bool zdiag = true;
-  for (int s = 0; s < m; ++s) {
-    double S = s_Z[(size_t)s * 64 + lane];
-    if (s > 0) {
-      S -= s_e[(s - 1) * 8 + r] * s_e[(s - 1) * 8 + c] * Zprev;
-      if (lane < 8) s_y[s * 8 + lane] -= s_e[(s - 1) * 8 + lane] * s_x[(s - 1) * 8 + lane];
+  const int s_dense = dense_mask ? (__ffsll((long long)dense_mask) - 1) : m;
+  double zp = 0.0, yp = 0.0;
+  if (r == c) {
+    for (int s = 0; s < s_dense; ++s) {
+      const double ep = (s > 0) ? s_e[(s - 1) * 8 + r] : 0.0;
+      const double S = s_Z[(size_t)s * 64 + lane] - ep * ep * zp;
+      if (!(S > 0.0)) fail = 1;
+      const double Zr = fast_rcp(S);
+      const double y = Zr * (s_y[s * 8 + r] - ep * yp);
+      s_Z[(size_t)s * 64 + lane] = Zr;
+      s_x[s * 8 + r] = y;
+      zp = Zr;
+      yp = y;
     }
-    const bool dense = ((dense_mask >> s) & 1ull) || !zdiag;
-    if (!dense) {
-      if (r == c) {
-        if (!(S > 0.0)) fail = 1;
-        S = fast_rcp(S);
-      } else {
-        S = 0.0;
-      }
-    } else {
-      zdiag = false;
+  }
+  __syncthreads();
+  if (bp.dbg && b == 0 && lane == 0) bp.dbg[3] = clock64();
+  double Zprev = (r == c) ? zp : 0.0;
+  double yprev_c = (s_dense > 0) ? s_x[(s_dense - 1) * 8 + c] : 0.0;  // y_{s-1}[c] for lane (r,c)
+  for (int s = s_dense; s < m; ++s) {
+    double S = s_Z[(size_t)s * 64 + lane];
+    double zc = s_y[s * 8 + c];
+    if (s > 0) {
+      const double er = s_e[(s - 1) * 8 + r], ec = s_e[(s - 1) * 8 + c];
+      S -= er * ec * Zprev;
+      zc -= ec * yprev_c;
+    }
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const double pjj = __shfl(S, j * 9, 64);
-        const double prj = __shfl(S, (lane & 56) | j, 64);
-        const double pjc = __shfl(S, j * 8 + c, 64);
-        if (!(pjj > 0.0)) fail = 1;
-        const double piv = fast_rcp(pjj);
-        if (r == j && c == j) S = piv;
-        else if (r == j) S = pjc * piv;
-        else if (c == j) S = -prj * piv;
-        else S = fma(-prj * piv, pjc, S);
-      }
+    for (int j = 0; j < 8; ++j) {
+      const double pjj = __shfl(S, j * 9, 64);
+      const double prj = __shfl(S, (lane & 56) | j, 64);
+      const double pjc = __shfl(S, j * 8 + c, 64);
+      if (!(pjj > 0.0)) fail = 1;
+      const double piv = fast_rcp(pjj);
+      if (r == j && c == j) S = piv;
+      else if (r == j) S = pjc * piv;
+      else if (c == j) S = -prj * piv;
+      else S = fma(-prj * piv, pjc, S);
     }
     s_Z[(size_t)s * 64 + lane] = S;  // Z_s
     Zprev = S;
-    __syncthreads();  // z_s visible
-    double pr = S * s_y[s * 8 + c];
+    double pr = S * zc;  // y_s[r] = sum_c Z[r][c] z[c]
     pr += __shfl_xor(pr, 1, 64);
     pr += __shfl_xor(pr, 2, 64);
     pr += __shfl_xor(pr, 4, 64);
-    if (c == 0) s_x[s * 8 + r] = pr;  // y_s (s_x doubles as y during the forward sweep)
-    __syncthreads();
+    if (c == 0) s_x[s * 8 + r] = pr;
+    yprev_c = __shfl(pr, c << 3, 64);  // transpose: lane (r,c) picks y_s[c] from row c
   }
   if (__any(fail)) {
     if (lane == 0) {
@@ -1089,17 +1191,31 @@ __global__ __launch_bounds__(64) void k_lm_step(const RobotDev* __restrict__ rb,
     }
     return;
   }
-  // backward sweep: x_s = y_s - Z_s (e_s o x_{s+1})
-  for (int s = m - 2; s >= 0; --s) {
-    double pr = s_Z[(size_t)s * 64 + lane] * (s_e[s * 8 + c] * s_x[(s + 1) * 8 + c]);
-    pr += __shfl_xor(pr, 1, 64);
-    pr += __shfl_xor(pr, 2, 64);
-    pr += __shfl_xor(pr, 4, 64);
-    __syncthreads();
-    if (c == 0) s_x[s * 8 + r] -= pr;
-    __syncthreads();
+  __syncthreads();
+  if (bp.dbg && b == 0 && lane == 0) bp.dbg[4] = clock64();
+  // backward sweep; xr = x_{s+1}[r] (row copy), xc = x_{s+1}[c] (column copy) per lane
+  {
+    double xr = s_x[(m - 1) * 8 + r], xc = s_x[(m - 1) * 8 + c];
+    for (int s = m - 2; s >= s_dense; --s) {  // dense blocks
+      double pr = s_Z[(size_t)s * 64 + lane] * (s_e[s * 8 + c] * xc);
+      pr += __shfl_xor(pr, 1, 64);
+      pr += __shfl_xor(pr, 2, 64);
+      pr += __shfl_xor(pr, 4, 64);
+      xr = s_x[s * 8 + r] - pr;
+      if (c == 0) s_x[s * 8 + r] = xr;
+      xc = __shfl(xr, c << 3, 64);
+    }
+    if (r == c) {  // diagonal stretch
+      const int top = (s_dense < m - 1 ? s_dense : m - 1) - 1;
+      for (int s = top; s >= 0; --s) {
+        xr = s_x[s * 8 + r] - s_Z[(size_t)s * 64 + lane] * (s_e[s * 8 + r] * xr);
+        s_x[s * 8 + r] = xr;
+      }
+    }
   }
+  __syncthreads();
 
+  if (bp.dbg && b == 0 && lane == 0) bp.dbg[5] = clock64();
   // ---- P4: projected trial point
   double maxstep = 0.0;
   for (int idx = lane; idx < m * 8; idx += 64) {
@@ -1132,16 +1248,27 @@ __global__ __launch_bounds__(64) void k_lm_step(const RobotDev* __restrict__ rb,
     }
     return;
   }
+  if (bp.dbg && b == 0 && lane == 0) bp.dbg[6] = clock64();
   // ---- P5: predicted decrease of the undamped model: -(2 b.s + s^T A s)
   double acc = 0.0;
-  for (int s = 0; s < m; ++s) {
-    const double sr = s_x[s * 8 + r], scv = s_x[s * 8 + c];
-    double v = s_A[(size_t)s * 64 + lane] * sr * scv;
-    if (c == 0) {
-      v += 2.0 * s_b[s * 8 + r] * sr;
-      if (s < m - 1) v += 2.0 * (-alpha) * sr * s_x[(s + 1) * 8 + r];
+  {
+    double part[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int s0 = 0; s0 < m; s0 += 4) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int s = s0 + u;
+        if (s < m) {
+          const double sr = s_x[s * 8 + r], scv = s_x[s * 8 + c];
+          double v = s_A[(size_t)s * 64 + lane] * sr * scv;
+          if (c == 0) {
+            v += 2.0 * s_b[s * 8 + r] * sr;
+            if (s < m - 1) v += 2.0 * (-alpha) * sr * s_x[(s + 1) * 8 + r];
+          }
+          part[u] += v;
+        }
+      }
     }
-    acc += v;
+    acc = (part[0] + part[1]) + (part[2] + part[3]);
   }
   acc = wave_sum(acc);
   if (lane == 0) {
@@ -1156,8 +1283,11 @@ __global__ __launch_bounds__(64) void k_lm_step(const RobotDev* __restrict__ rb,
     if (accept) st->argmin_cur = st->argmin_try;
   }
   __syncthreads();
+  if (bp.dbg && b == 0 && lane == 0) bp.dbg[7] = clock64();
   // ---- P6: goal terms of the new trial (the obstacle kernel evaluates the rest)
   trial_goal_terms_wave(rb, bp, sp, B, b, lane, 1 - slot, st, s_q, s_fr, s_gaff, s_gscr);
+  if (bp.dbg && b == 0 && lane == 0) bp.dbg[8] = clock64();
+  if (bp.dbg && b == 0 && lane == 0) bp.dbg[9] = s_dense;
 }
 
 __global__ __launch_bounds__(64) void k_lm_finalize(const RobotDev* __restrict__ rb, BatchPtrs bp, SolveParams sp, int B,

@@ -1,0 +1,213 @@
+"""GTORobotModel — the robot-model surface the reference's drivers use (gto/gto_models.py:23-215),
+backed by the flat RobotDesc and the HIP library.  No CasADi, urdf_parser_py, trimesh or sklearn."""
+from __future__ import annotations
+
+import os
+from types import SimpleNamespace
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+from . import _capi
+from .optas_facade import DM
+from .robot_desc import RobotDesc
+from .urdf import Urdf
+
+
+class GTORobotModel:
+    def __init__(self, model_dir: Optional[str] = None, urdf_filename: Optional[str] = None,
+                 urdf_string: Optional[str] = None, xacro_filename: Optional[str] = None,
+                 name: Optional[str] = None, time_derivs: Sequence[int] = (0,), qddlim=None, T=None,
+                 param_joints: Sequence[str] = (), collision_link_names: Optional[Sequence[str]] = None,
+                 points_per_link: int = 100, seed: int = 0, desc: Optional[RobotDesc] = None, device: int = -1):
+        """Same arguments as the reference (gto/gto_models.py:26-46).  ``desc`` short-circuits URDF and
+        mesh parsing with a pre-distilled description (robot_desc.load_builtin)."""
+        if xacro_filename is not None:
+            raise NotImplementedError("xacro input is not supported; pass a URDF")
+        if desc is None:
+            if urdf_filename is not None:
+                urdf = Urdf.from_file(urdf_filename)
+            elif urdf_string is not None:
+                urdf = Urdf.from_string(urdf_string)
+            else:
+                raise AssertionError("You need to supply a urdf, either through filename or as a string")
+            if model_dir is None:
+                model_dir = os.path.dirname(urdf_filename) if urdf_filename else "."
+            desc = RobotDesc.from_urdf(urdf, param_joints=param_joints, collision_link_names=collision_link_names,
+                                       model_dir=model_dir, points_per_link=points_per_link, seed=seed,
+                                       keep_all_frames=len(urdf.links) <= _capi.GTO_MAX_FRAMES)
+        self.desc = desc
+        self.model_dir = model_dir
+        self.name = name or desc.name
+        self.time_derivs = list(time_derivs)
+        self.param_joints = list(param_joints)
+        self.collision_link_names = collision_link_names
+        self.field_margin = 0.4        # gto/gto_models.py:45
+        self.grid_resolution = 0.05    # gto/gto_models.py:46
+        self.device = device
+        self._handles: Dict[tuple, _capi.SolverHandle] = {}
+        # surface_pc_map[name].points / .normals (gto/gto_models.py:62-80)
+        self.surface_pc_map = {
+            ln: SimpleNamespace(points=desc.points[desc.point_link == i], normals=desc.normals[desc.point_link == i])
+            for i, ln in enumerate(desc.link_names)}
+
+    # ------------------------------------------------------------------ optas.RobotModel surface
+    def get_name(self) -> str:
+        return self.name
+
+    @property
+    def ndof(self) -> int:
+        return self.desc.ndof
+
+    @property
+    def link_names(self) -> List[str]:
+        return list(self.desc.frame_names)
+
+    @property
+    def actuated_joint_names(self) -> List[str]:
+        return list(self.desc.actuated_joint_names)
+
+    @property
+    def optimized_joint_indexes(self) -> List[int]:
+        return self.desc.opt_index.tolist()
+
+    @property
+    def parameter_joint_indexes(self) -> List[int]:
+        return self.desc.param_index.tolist()
+
+    @property
+    def optimized_joint_names(self) -> List[str]:
+        return [self.desc.actuated_joint_names[i] for i in self.desc.opt_index]
+
+    @property
+    def parameter_joint_names(self) -> List[str]:
+        return [self.desc.actuated_joint_names[i] for i in self.desc.param_index]
+
+    @property
+    def num_opt_joints(self) -> int:
+        return self.desc.n_opt
+
+    @property
+    def num_param_joints(self) -> int:
+        return int(self.desc.param_index.shape[0])
+
+    @property
+    def lower_actuated_joint_limits(self) -> DM:
+        return DM(self.desc.lower)
+
+    @property
+    def upper_actuated_joint_limits(self) -> DM:
+        return DM(self.desc.upper)
+
+    @property
+    def lower_optimized_joint_limits(self) -> DM:
+        return DM(self.desc.lower[self.desc.opt_index])
+
+    @property
+    def upper_optimized_joint_limits(self) -> DM:
+        return DM(self.desc.upper[self.desc.opt_index])
+
+    def extract_parameter_dimensions(self, values):
+        return np.asarray(values)[self.parameter_joint_indexes, :]
+
+    def extract_optimized_dimensions(self, values):
+        return np.asarray(values)[self.optimized_joint_indexes, :]
+
+    # ------------------------------------------------------------------ HIP handles
+    def solver_handle(self, link_ee: str, link_gripper: str, opts=None) -> _capi.SolverHandle:
+        """One gto_handle per (link_ee, link_gripper, T, standoff_offset); created on first use."""
+        o = opts if opts is not None else _capi.default_opts()
+        key = (link_ee, link_gripper, int(o.T), int(o.standoff_offset))
+        h = self._handles.get(key)
+        if h is None:
+            h = _capi.SolverHandle(self.desc, link_ee, link_gripper, o, device=self.device)
+            self._handles[key] = h
+        return h
+
+    def _util_handle(self) -> _capi.SolverHandle:
+        if self._handles:
+            return next(iter(self._handles.values()))
+        ln = self.desc.link_names[-1]
+        return self.solver_handle(ln, ln)
+
+    # ------------------------------------------------------------------ FK of the surface points
+    def compute_fk_surface_points(self, q_user_input, tf_base=None):
+        """gto/gto_models.py:104-121 -> (points (M,3), normals (M,3)) in the base (or tf_base) frame."""
+        h = self._util_handle()
+        q = np.asarray(q_user_input, dtype=np.float64).reshape(1, self.ndof)
+        xyz, _, _, _ = h.eval_points(0, q, [0, 0, 0], want_field=False)
+        frames = h.eval_fk(q)[0]
+        d = self.desc
+        nrm = np.empty_like(d.normals)
+        for l in range(d.n_links):
+            R = frames[d.link_frame[l]][:3, :3] @ _rpy2r(d.visual_rpy[l])
+            sel = d.point_link == l
+            nrm[sel] = d.normals[sel] @ R.T
+        pts = xyz[0]
+        if tf_base is not None:
+            tf_base = np.asarray(tf_base, dtype=np.float64)
+            pts = pts @ tf_base[:3, :3].T + tf_base[:3, 3]
+            nrm = nrm @ tf_base[:3, :3].T
+        return pts, nrm
+
+    def compute_fk_link_surface_points(self, q_user_input, name, tf_base=None):
+        pts, _ = self.compute_fk_surface_points(q_user_input, tf_base)
+        return pts[self.desc.point_link == self.desc.link_names.index(name)]
+
+    # ------------------------------------------------------------------ voxel grid (gto/gto_models.py:135-201)
+    def _setup_field(self, lo, hi):
+        m, r = self.field_margin, self.grid_resolution
+        self.origin = np.array([lo[0] - m, lo[1] - m, lo[2] - m]).reshape((1, 3))
+        axes = [np.arange(lo[a] - m, hi[a] + m, r) for a in range(3)]
+        wp = np.array(np.meshgrid(*axes, indexing="ij"))
+        self.field_shape = wp.shape[1:]
+        self.workspace_points = wp.reshape((3, -1)).T
+        self.field_size = self.workspace_points.shape[0]
+
+    def setup_workspace_field(self, arm_len, arm_height):
+        self.xlim, self.ylim, self.zlim = [0, arm_len], [-arm_len, arm_len], [0, arm_height + arm_len]
+        self._setup_field([self.xlim[0], self.ylim[0], self.zlim[0]], [self.xlim[1], self.ylim[1], self.zlim[1]])
+
+    def setup_points_field(self, points):
+        points = np.asarray(points)
+        self.workspace_bounds = np.stack((points.min(0), points.max(0)), axis=1)
+        self._setup_field(self.workspace_bounds[:, 0], self.workspace_bounds[:, 1])
+
+    def field_geometry(self):
+        if not hasattr(self, "field_shape"):
+            raise RuntimeError("call setup_points_field() or setup_workspace_field() first")
+        return tuple(int(s) for s in self.field_shape), self.origin.reshape(3).copy(), float(self.grid_resolution)
+
+    def points_to_offsets_numpy(self, points):
+        """gto/gto_models.py:190-201."""
+        idx = (np.asarray(points, dtype=np.float64) - self.origin) / self.grid_resolution
+        for a in range(3):
+            idx[:, a] = np.clip(idx[:, a], 0, self.field_shape[a] - 1).astype(np.int32)
+        off = idx[:, 2] + self.field_shape[2] * (idx[:, 1] + self.field_shape[1] * idx[:, 0])
+        return np.clip(off, 0, self.field_size - 1).astype(np.int32)
+
+    def compute_plan_cost(self, plan, sdf_cost_obstacle, base_position, handle=None):
+        """gto/gto_models.py:204-215 for one plan (ndof, T) -> (cost, dist), evaluated on the GPU."""
+        h = handle or self._util_handle()
+        plan = np.asarray(plan, dtype=np.float64)
+        if plan.shape[1] != h.T:
+            raise NotImplementedError(f"plans must have T={h.T} waypoints on this handle")
+        shape, origin, res = self.field_geometry()
+        h.set_scene(65535, sdf_cost_obstacle, None, shape, origin, res)
+        cost, dist = h.plan_cost(65535, plan[None], base_position)
+        return float(cost[0]), float(dist[0])
+
+    def close(self):
+        for h in self._handles.values():
+            h.close()
+        self._handles.clear()
+
+
+def _rpy2r(rpy):
+    """optas/spatialmath.py:186-211 ('zyx'), host-side, for rotating normals only."""
+    r, p, y = rpy
+    cr, sr, cp, sp_, cy, sy = np.cos(r), np.sin(r), np.cos(p), np.sin(p), np.cos(y), np.sin(y)
+    Rz = np.array([[cy, -sy, 0], [sy, cy, 0], [0, 0, 1.0]])
+    Ry = np.array([[cp, 0, sp_], [0, 1.0, 0], [-sp_, 0, cp]])
+    Rx = np.array([[1.0, 0, 0], [0, cr, -sr], [0, sr, cr]])
+    return Rz @ Ry @ Rx

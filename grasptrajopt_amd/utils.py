@@ -1,0 +1,45 @@
+"""Host-side helpers of the GTO layer (gto/utils.py in the reference)."""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+import yaml
+
+from .synthetic import interpolate_waypoints as _interp2
+
+
+def get_root_dir() -> str:
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+
+
+def load_yaml(file_path):
+    """gto/utils.py:15-21."""
+    if isinstance(file_path, str):
+        with open(file_path) as fh:
+            return yaml.load(fh, Loader=yaml.Loader)
+    return file_path
+
+
+def rotZ(rotz: float) -> np.ndarray:
+    """gto/utils.py:24-33."""
+    c, s = np.cos(rotz), np.sin(rotz)
+    return np.array([[c, -s, 0, 0], [s, c, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1.0]])
+
+
+def interpolate_waypoints(waypoints, n: int, m: int, mode: str = "cubic") -> np.ndarray:
+    """gto/utils.py:63-82: clamped cubic through the waypoints sampled at linspace(0,1,n+2)[1:-1]
+    (endpoints excluded).  The planner only ever passes two waypoints (gto/gto_planner.py:155,203),
+    for which the clamped spline is the closed-form Hermite cubic; more waypoints go through scipy."""
+    w = np.asarray(waypoints, dtype=np.float64)
+    if mode == "cubic" and w.shape[0] == 2:
+        return _interp2(w, n, m)
+    from scipy import interpolate
+    data = np.zeros([n, m])
+    x = np.linspace(0, 1, w.shape[0])
+    t = np.linspace(0, 1, n + 2)
+    for i in range(w.shape[1]):
+        f = (interpolate.interp1d(x, w[:, i], "linear") if mode == "linear"
+             else interpolate.CubicSpline(x, w[:, i], bc_type="clamped"))
+        data[:, i] = f(t[1:-1])
+    return data

@@ -1,0 +1,105 @@
+"""CPU: host logic of the drop-in surface (GTORobotModel grid set-up, builder bookkeeping, seed
+interpolation, URDF/mesh front end) against the reference-generated golden vectors."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import golden
+import grasptrajopt_amd as g
+from grasptrajopt_amd import optas_facade as optas
+from grasptrajopt_amd.utils import interpolate_waypoints
+
+
+@pytest.fixture()
+def panda():
+    return g.GTORobotModel(desc=g.load_builtin("panda"), time_derivs=[0, 1],
+                           param_joints=["panda_finger_joint1", "panda_finger_joint2"])
+
+
+def test_points_field_matches_reference(panda):
+    gd = golden("grid.npz")
+    panda.setup_points_field(gd["cloud"])
+    np.testing.assert_array_equal(panda.origin, gd["origin"])
+    assert tuple(panda.field_shape) == tuple(gd["field_shape"])
+    assert panda.field_size == int(gd["field_size"])
+    np.testing.assert_array_equal(panda.workspace_points, gd["workspace_points"])
+    np.testing.assert_array_equal(panda.points_to_offsets_numpy(gd["query"].copy()), gd["offsets"])
+
+
+def test_robot_model_surface_matches_reference(panda):
+    fk = golden("fk_panda.npz")
+    assert panda.ndof == 9 and panda.get_name() == "panda"
+    assert panda.optimized_joint_indexes == fk["opt_index"].tolist()
+    assert panda.parameter_joint_indexes == fk["param_index"].tolist()
+    np.testing.assert_array_equal(panda.lower_actuated_joint_limits.toarray().ravel(), fk["lower"])
+    np.testing.assert_array_equal(panda.upper_actuated_joint_limits.toarray().ravel(), fk["upper"])
+    assert list(panda.surface_pc_map) == [str(s) for s in fk["visual_names"]]
+    assert panda.surface_pc_map["panda_hand"].points.shape == (100, 3)
+    Q = np.arange(18.0).reshape(9, 2)
+    np.testing.assert_array_equal(panda.extract_optimized_dimensions(Q), Q[:7])
+    np.testing.assert_array_equal(panda.extract_parameter_dimensions(Q), Q[7:])
+
+
+def test_builder_records_the_reference_layout(panda):
+    panda.setup_points_field(golden("grid.npz")["cloud"])
+    b = optas.OptimizationBuilder(T=50, robots=[panda])
+    for name, shape in (("qc", (9,)), ("tf_goal", (16, 3)), ("sdf_cost_all", (panda.field_size,)),
+                        ("sdf_cost_obstacle", (panda.field_size,)), ("base_position", (3,))):
+        b.add_parameter(name, *shape)
+    prob = b.build()
+    # decision variables / parameters in the reference's insertion order
+    assert list(prob.decision_variables.items()) == [("panda/q/x", (7, 50)), ("panda/dq/x", (7, 49))]
+    assert list(prob.parameters)[:2] == ["panda/q/p", "panda/dq/p"]
+    assert list(prob.parameters)[2:] == ["qc", "tf_goal", "sdf_cost_all", "sdf_cost_obstacle", "base_position"]
+    assert prob.nx == 693
+    with pytest.raises(NotImplementedError):
+        b.add_cost_term("x", 3.0)
+    with pytest.raises(KeyError):
+        b.add_parameter("qc", 9)
+    with pytest.raises(NotImplementedError):
+        optas.CasADiSolver(prob).setup("ipopt")  # no cost terms / constraints recorded yet
+
+
+def test_interpolate_waypoints_golden():
+    gi = golden("interp.npz")
+    for qc, qg, s50 in zip(gi["qc"], gi["qgoal"], gi["seeds"]):
+        np.testing.assert_allclose(interpolate_waypoints(np.stack([qc, qg]), 50, 9), s50, rtol=0, atol=2e-15)
+    # more than two waypoints go through scipy's clamped spline like the reference
+    w = np.stack([gi["qc"][0], gi["qgoal"][0], gi["qc"][1]])
+    out = interpolate_waypoints(w, 20, 9)
+    assert out.shape == (20, 9) and np.isfinite(out).all()
+
+
+def test_urdf_and_mesh_front_end(tmp_path):
+    """GTORobotModel(model_dir, urdf_filename=...) without urdf_parser_py/trimesh: a two-link arm with
+    an OBJ and a binary STL visual."""
+    (tmp_path / "a.obj").write_text("v 0 0 0\nv 0.1 0 0\nv 0 0.1 0\nv 0 0 0.2\nf 1 2 3\nf 1/1 2/1 4/1\nf 1 3 4\nf 2 3 4\n")
+    import struct
+    tri = [((0, 0, 1), (0, 0, 0), (0.1, 0, 0), (0, 0.1, 0)), ((0, 1, 0), (0, 0, 0), (0.1, 0, 0), (0, 0, 0.3))]
+    with open(tmp_path / "b.stl", "wb") as fh:
+        fh.write(b"\0" * 80 + struct.pack("<I", len(tri)))
+        for n, a, b, c in tri:
+            fh.write(struct.pack("<12fH", *n, *a, *b, *c, 0))
+    (tmp_path / "r.urdf").write_text("""<robot name="two">
+      <link name="base"><visual><geometry><mesh filename="a.obj"/></geometry></visual></link>
+      <link name="tip"><visual><origin xyz="0 0 0.1" rpy="0 0 1.57"/><geometry><mesh filename="b.stl" scale="2 2 2"/></geometry></visual></link>
+      <link name="fixed_tip"/>
+      <joint name="j1" type="revolute"><parent link="base"/><child link="tip"/><origin xyz="0 0 0.2"/>
+        <axis xyz="0 0 1"/><limit lower="-1" upper="2" velocity="1"/></joint>
+      <joint name="j2" type="fixed"><parent link="tip"/><child link="fixed_tip"/></joint>
+      <joint name="j3" type="continuous"><parent link="base"/><child link="wheel"/></joint>
+      <link name="wheel"/></robot>""")
+    r = g.GTORobotModel(str(tmp_path), urdf_filename=str(tmp_path / "r.urdf"), param_joints=["j3"], points_per_link=50)
+    d = r.desc
+    assert d.actuated_joint_names == ["j1", "j3"] and d.opt_index.tolist() == [0] and d.param_index.tolist() == [1]
+    assert d.lower.tolist() == [-1.0, -1e9] and d.upper.tolist() == [2.0, 1e9]   # missing <limit> -> +-1e9
+    assert d.link_names == ["base", "tip"] and d.n_points == 100
+    assert d.frame_names[0] == "base" and set(d.frame_names) == {"base", "tip", "fixed_tip", "wheel"}
+    assert (d.parent[1:] < np.arange(1, d.n_frames)).all()
+    p = r.surface_pc_map["tip"].points
+    assert p.max() <= 0.6 + 1e-12 and p.min() >= 0.0                          # STL scaled by 2
+    np.testing.assert_allclose(d.visual_xyz[1], [0, 0, 0.1])
+    # same seed -> same points (the reference's draw is unseeded; ours is reproducible)
+    r2 = g.GTORobotModel(str(tmp_path), urdf_filename=str(tmp_path / "r.urdf"), param_joints=["j3"], points_per_link=50)
+    np.testing.assert_array_equal(r2.desc.points, d.points)
