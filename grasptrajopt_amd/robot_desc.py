@@ -77,6 +77,15 @@ class RobotDesc:
             raise KeyError(f"link '{link_name}' is not a kinematic frame of this description "
                            f"(frames: {self.frame_names})") from None
 
+    def link_is_moving(self) -> np.ndarray:
+        """(L,) bool: True if an optimised joint lies on the chain from the root to the link."""
+        opt = set(self.opt_index.tolist())
+        moved = np.zeros(self.n_frames, dtype=bool)
+        for i in range(self.n_frames):
+            p = self.parent[i]
+            moved[i] = (p >= 0 and moved[p]) or (self.q_index[i] in opt)
+        return moved[self.link_frame]
+
     def link_points(self, link_name: str) -> np.ndarray:
         l = self.link_names.index(link_name)
         return self.points[self.point_link == l]

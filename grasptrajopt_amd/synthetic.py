@@ -102,9 +102,13 @@ def interpolate_waypoints(waypoints: np.ndarray, n: int, m: int) -> np.ndarray:
 
 
 def make_goals(desc, fk: Callable[[np.ndarray], np.ndarray], link_ee: str, n_goals: int, seed: int,
-               xlim=(0.25, 0.75), ylim=(-0.5, 0.5), zlim=(0.08, 0.7)):
+               xlim=(0.25, 0.75), ylim=(-0.5, 0.5), zlim=(0.08, 0.7),
+               collision_cost: Optional[Callable[[np.ndarray], np.ndarray]] = None):
     """Sample in-limit configurations q* whose end-effector lies in a box above the table;
-    goal pose RT = FK(q*).  ``fk(q) -> (nq, n_frames, 4, 4)``.  Returns (RT (n,4,4), q* (n,ndof))."""
+    goal pose RT = FK(q*).  ``fk(q) -> (nq, n_frames, 4, 4)``.  ``collision_cost(q) -> (nq,)`` (optional)
+    rejects configurations whose moving links touch the obstacle band (the reference's pipeline only
+    passes collision-free IK solutions on, examples/pybullet_gto_planning.py:207-263).
+    Returns (RT (n,4,4), q* (n,ndof))."""
     rng = np.random.default_rng(5000 + seed)
     lo = np.maximum(desc.lower, -3.0)
     hi = np.minimum(desc.upper, 3.0)
@@ -117,6 +121,9 @@ def make_goals(desc, fk: Callable[[np.ndarray], np.ndarray], link_ee: str, n_goa
         p = T[:, :3, 3]
         ok = ((p[:, 0] > xlim[0]) & (p[:, 0] < xlim[1]) & (p[:, 1] > ylim[0]) & (p[:, 1] < ylim[1])
               & (p[:, 2] > zlim[0]) & (p[:, 2] < zlim[1]))
+        if collision_cost is not None and ok.any():
+            idx = np.nonzero(ok)[0]
+            ok[idx[collision_cost(q[idx]) > 0.0]] = False
         for i in np.nonzero(ok)[0]:
             if len(RTs) < n_goals:
                 RTs.append(T[i])
