@@ -100,6 +100,7 @@ const char* gto_last_error(const gto_handle* h) { return h ? h->err.c_str() : g_
 
 static int validate_opts(const gto_solver_opts* o, std::string& why) {
   if (o->T < 4) { why = "T must be >= 4"; return 0; }
+  if (o->T > GTO_MAX_T) { why = "T must be <= 64 (GTO_MAX_T)"; return 0; }
   if (!(o->Tmax > 0)) { why = "Tmax must be positive"; return 0; }
   if (o->max_iter < 0) { why = "max_iter must be >= 0"; return 0; }
   int ts = o->T + o->standoff_offset;
@@ -111,7 +112,7 @@ static int validate_opts(const gto_solver_opts* o, std::string& why) {
 
 static size_t lm_lds_bytes(int T) {
   size_t m = (size_t)T - 2;
-  size_t dbl = m * 128 + 4 * m * 8 + 8 * (size_t)T + 48 + 2 * GTO_MAX_OPT * 6 + 2 * GTO_MAX_DOF + 2 * GTO_MAX_FRAMES * 12;
+  size_t dbl = m * 128 + 4 * m * 8 + 8 * (size_t)T + 48 + 2 * GTO_MAX_OPT * 6 + 2 * GTO_MAX_DOF + 2 * GTO_MAX_FRAMES * 12 + 16;
   return dbl * sizeof(double) + m * 8 * sizeof(int) + 64;
 }
 
@@ -546,7 +547,7 @@ static BatchPtrs make_ptrs(gto_handle* h, const int32_t* scene_id, const double*
 static inline int obstacle_grid(int B, int nT) { return 8 * ((B + 7) / 8) * nT; }
 
 static int launch_obstacle(gto_handle* h, hipStream_t st, const BatchPtrs& bp, const SolveParams& sp, int B, int t_begin,
-                           int nT, int fixed_mode, bool timed) {
+                           int nT, int fixed_mode, bool timed, bool with_goal_terms = false) {
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (timed) {
     size_t need = (size_t)(h->last_launches + 1) * 2;
@@ -559,8 +560,9 @@ static int launch_obstacle(gto_handle* h, hipStream_t st, const BatchPtrs& bp, c
     e1 = h->ev[2 * h->last_launches + 1];
     HIPCHK(h, hipEventRecord(e0, st));
   }
-  hipLaunchKernelGGL(k_obstacle_gram, dim3(obstacle_grid(B, nT)), dim3(256), 0, st, h->d_rb, h->d_px, h->d_py, h->d_pz,
-                     h->d_chunks, h->d_scenes, bp, sp, B, t_begin, nT, fixed_mode);
+  const int n_regular = obstacle_grid(B, nT);
+  hipLaunchKernelGGL(k_obstacle_gram, dim3(n_regular + (with_goal_terms ? B : 0)), dim3(256), 0, st, h->d_rb, h->d_px, h->d_py,
+                     h->d_pz, h->d_chunks, h->d_scenes, bp, sp, B, t_begin, nT, fixed_mode, n_regular);
   if (timed) {
     HIPCHK(h, hipEventRecord(e1, st));
     h->last_launches++;
@@ -642,8 +644,9 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
     for (int g = 0; g < G; ++g) {
       Group& gr = grp[g];
       if (!gr.live) continue;
-      if ((rc = launch_obstacle(h, gr.st, gr.bp, sp, gr.n, 2, T - 2, 0, h->profiling))) return rc;
-      hipLaunchKernelGGL(k_lm_step, dim3(gr.n), dim3(64), h->lm_lds, gr.st, h->d_rb, gr.bp, sp, gr.n);
+      // round 0 evaluates the seed, whose goal terms k_lm_init already produced
+      if ((rc = launch_obstacle(h, gr.st, gr.bp, sp, gr.n, 2, T - 2, 0, h->profiling, k > 0))) return rc;
+      hipLaunchKernelGGL(k_lm_step, dim3(gr.n), dim3(256), h->lm_lds, gr.st, h->d_rb, gr.bp, sp, gr.n);
     }
     // early exit: every few rounds look at the finished-instance counters (4-byte read-backs)
     if (h->check_every > 0 && (k % h->check_every) == h->check_every - 1 && k < sp.max_iter) {

@@ -190,6 +190,14 @@ __device__ inline void fk_block(const RobotDev* rb, const double* s_q, double* s
   __syncthreads();
 }
 
+// Ordering point for LDS traffic inside ONE wavefront (no s_barrier: DS operations of a wave are
+// processed in issue order; the fence keeps the compiler from moving accesses across it).
+__device__ inline void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // Forward kinematics of TWO configurations at once by one wavefront: lanes 0-31 work on s_q[0..],
 // s_fr[0..], lanes 32-63 on s_q[GTO_MAX_DOF..], s_fr[GTO_MAX_FRAMES*12..] (same math as fk_block).
 __device__ inline void fk_pair_wave(const RobotDev* rb, const double* s_q2, double* s_fr2, int lane) {
@@ -231,7 +239,7 @@ __device__ inline void fk_pair_wave(const RobotDev* rb, const double* s_q2, doub
       for (int k = 0; k < 12; ++k) Lo[k] = O[k];
     }
   }
-  __syncthreads();
+  wave_sync();
   if (l < 3) {
     for (int i = 0; i < F; ++i) {
       const int p = rb->parent[i];
@@ -253,7 +261,7 @@ __device__ inline void fk_pair_wave(const RobotDev* rb, const double* s_q2, doub
       __builtin_amdgcn_wave_barrier();
     }
   }
-  __syncthreads();
+  wave_sync();
 }
 
 // world screw of optimised joint j from the frame that carries it: (a ; o x a) revolute, (0 ; a) prismatic
@@ -394,7 +402,13 @@ __global__ void k_dist_relax(const uint8_t* __restrict__ in, uint8_t* __restrict
 //   main loop one link-uniform chunk of 64 Morton-sorted surface points per wave step
 //   epilogue  per-link 6x6 wrench Grams -> J^T J (n x n), J^T r (n), sum c^2
 #define GTO_MAX_ACTIVE 1024  // chunks per robot the broad phase can list (64 K surface points)
+#define GTO_MAX_T 64       // waypoints the step kernel's register-resident phases are unrolled for
 #define GTO_LIST_CAP 80  // entries of 8 doubles per wave: a full chunk (64) always fits after a drain
+struct InstState;
+__device__ inline void trial_goal_terms_wave(const RobotDev* rb, const BatchPtrs& bp, const SolveParams& sp, int B,
+                                             int b, int lane, int trial, InstState* st, double* s_q, double* s_fr,
+                                             double* s_gaff, double* s_gscr);
+
 #ifndef GTO_OBS_MIN_WAVES
 #define GTO_OBS_MIN_WAVES 4  // waves per SIMD the register allocator must leave room for
 #endif
@@ -402,15 +416,16 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
                                                        const double* __restrict__ py, const double* __restrict__ pz,
                                                        const Chunk* __restrict__ chunks, const SceneDev* __restrict__ scenes,
                                                        BatchPtrs bp, SolveParams sp, int B, int t_begin, int nT,
-                                                       int fixed_mode) {
+                                                       int fixed_mode, int n_regular) {
   // blockIdx -> (instance, waypoint), bijective, with b % 8 == blockIdx % 8
   const int bid = blockIdx.x;
   const int xcd = bid & 7, k = bid >> 3;
   const int b = (k / nT) * 8 + xcd;
   const int t = t_begin + (k % nT);
-  if (b >= B) return;
-  const InstState* st = bp.state + b;
-  if (st->done) return;
+  const bool goal_wg = bid >= n_regular;
+  if (!goal_wg && b >= B) return;
+  const InstState* st = bp.state + (goal_wg ? 0 : b);
+  if (!goal_wg && st->done) return;
 
   __shared__ double s_q[GTO_MAX_DOF];
   __shared__ double s_fr[GTO_MAX_FRAMES * 12];
@@ -423,6 +438,22 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
   __shared__ int s_nactive;
   __shared__ double s_out[BLK_STRIDE];
   double* s_u = s_list;  // [L][GTO_MAX_OPT][6] <= 1536 doubles
+
+  // Extra workgroups (blockIdx >= n_regular), one per instance: goal-set terms and velocity term of the
+  // trial trajectory.  The step kernel only needs them at its NEXT launch, so they ride in the shadow
+  // of the obstacle evaluation instead of sitting on the serial path between two launches.
+  if (goal_wg) {
+    const int bg = bid - n_regular;
+    if (bg >= B || bp.state[bg].done) return;
+    if (threadIdx.x < 64) {
+      double* s_fr2 = s_list;                       // [2][GTO_MAX_FRAMES*12]
+      double* s_q2 = s_fr2 + 2 * GTO_MAX_FRAMES * 12;  // [2][GTO_MAX_DOF]
+      double* s_ga = s_q2 + 2 * GTO_MAX_DOF;        // [48]
+      double* s_gs = s_ga + 48;                     // [2][GTO_MAX_OPT*6]
+      trial_goal_terms_wave(rb, bp, sp, B, bg, threadIdx.x, 1 - bp.state[bg].slot, bp.state + bg, s_q2, s_fr2, s_ga, s_gs);
+    }
+    return;
+  }
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int L = rb->n_links, n = rb->n_opt, T = sp.T, ndof = rb->ndof;
@@ -870,9 +901,9 @@ __device__ inline void trial_goal_terms_wave(const RobotDev* rb, const BatchPtrs
     const int which = lane >> 5, l = lane & 31;
     const int t = which == 0 ? T - 1 : sp.ts;
     if (l < ndof) s_q[which * GTO_MAX_DOF + l] = Q0b[(size_t)l * T + t];
-    __syncthreads();
+    wave_sync();
     if (l < n) s_q[which * GTO_MAX_DOF + rb->opt_index[l]] = Qt[(size_t)l * T + t];
-    __syncthreads();
+    wave_sync();
     fk_pair_wave(rb, s_q, s_fr, lane);
     const double* fr = s_fr + which * GTO_MAX_FRAMES * 12;
     if (l < 12) {
@@ -884,7 +915,7 @@ __device__ inline void trial_goal_terms_wave(const RobotDev* rb, const BatchPtrs
       for (int i = 0; i < rb->n_frames; ++i)
         if (rb->opt_of_frame[i] == j) screw_of_frame(rb, i, fr + 12 * i, s_gscr + which * GTO_MAX_OPT * 6 + 6 * j);
     }
-    __syncthreads();
+    wave_sync();
   }
   double* gblk = bp.goalblk + ((size_t)trial * B + b) * 2 * BLK_STRIDE;
   GoalOut go = goal_terms_wave(rb, sp, bp.goals + (size_t)b * sp.n_max * 16, bp.n_goals[b],
@@ -952,15 +983,12 @@ __device__ inline double fast_rcp(double x) {
 }
 
 // dynamic LDS layout of k_lm_step (doubles): Z [m][64] | A [m][64] | bfull [m][8] | y [m][8] | e [m][8] |
-// x [m][8] | Q [8][T] | gaff [48] | gscr [96] | q [32] | frames [32*12] ; then int act [m][8].
-__device__ inline size_t lm_step_lds_doubles(int T) {
-  const size_t m = (size_t)T - 2;
-  return m * 128 + 4 * m * 8 + 8 * (size_t)T + 48 + 2 * GTO_MAX_OPT * 6 + GTO_MAX_DOF + GTO_MAX_FRAMES * 12;
-}
-
-// One wavefront per instance.  Lane (r,c) = (lane>>3, lane&7) owns entry (r,c) of the 8x8 blocks.
-__global__ __launch_bounds__(64) void k_lm_step(const RobotDev* __restrict__ rb, BatchPtrs bp, SolveParams sp, int B) {
-  const int b = blockIdx.x, lane = threadIdx.x;
+// x [m][8] | Q [8][T] | gaff [48] | gscr [96] | q [64] | frames [2*32*12] | red [16] ; then int act [m][8].
+// One workgroup of four wavefronts per instance.  Lane (r,c) = (lane>>3, lane&7) of a wave owns entry
+// (r,c) of the 8x8 blocks; the data-parallel phases (assembly, projected step, predicted decrease) are
+// spread over the four waves by waypoint, the serial block recursion runs on wave 0.
+__global__ __launch_bounds__(256) void k_lm_step(const RobotDev* __restrict__ rb, BatchPtrs bp, SolveParams sp, int B) {
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   InstState* st = bp.state + b;
   if (st->done) return;
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -976,13 +1004,15 @@ __global__ __launch_bounds__(64) void k_lm_step(const RobotDev* __restrict__ rb,
   double* s_gscr = s_gaff + 48;
   double* s_q = s_gscr + 2 * GTO_MAX_OPT * 6;
   double* s_fr = s_q + 2 * GTO_MAX_DOF;
-  int* s_act = (int*)(s_fr + 2 * GTO_MAX_FRAMES * 12);  // [m][8]
+  double* s_red = s_fr + 2 * GTO_MAX_FRAMES * 12;  // [16] cross-wave scratch
+  int* s_act = (int*)(s_red + 16);                 // [m][8]
+  unsigned long long* s_dmask = (unsigned long long*)(s_red + 8);
 
   const int r = lane >> 3, c = lane & 7;
   const int trial = 1 - st->slot;
+  const long long t_dbg0 = bp.dbg ? clock64() : 0;
 
-  if (bp.dbg && b == 0 && lane == 0) bp.dbg[0] = clock64();
-  // ---- P0: objective of the trial point
+  // ---- P0: objective of the trial point (every wave computes it: cheaper than a broadcast)
   double fo = 0.0;
   {
     const double* blk = bp.blocks + ((size_t)trial * B + b) * T * BLK_STRIDE;
@@ -992,16 +1022,18 @@ __global__ __launch_bounds__(64) void k_lm_step(const RobotDev* __restrict__ rb,
   }
   const double f_try = st->fgoal_try + sp.w_obstacle * fo + st->fvel_try;
 
-  // ---- P1: accept / reject (all lanes take the same branch: inputs are wave-uniform)
+  // ---- P1: accept / reject (all threads take the same branch: inputs are block-uniform)
   double f = st->f, lambda = st->lambda, nu = st->nu;
   int slot = st->slot, done = 0, status = st->status;
   const int k = st->evals;
+  const int argmin_try = st->argmin_try, argmin_cur0 = st->argmin_cur;
+  const double pred0 = st->pred;
   bool accept = false;
   if (st->first) {
     accept = true;
-  } else if (f_try < f && st->pred > 0.0) {
+  } else if (f_try < f && pred0 > 0.0) {
     accept = true;
-    const double df = f - f_try, rho = df / st->pred;
+    const double df = f - f_try, rho = df / pred0;
     const double sg = 2.0 * rho - 1.0;
     double fac = 1.0 - sg * sg * sg;
     fac = fmax(fac, 1.0 / 3.0);
@@ -1019,259 +1051,268 @@ __global__ __launch_bounds__(64) void k_lm_step(const RobotDev* __restrict__ rb,
       done = 1;
     }
   }
-  double* Qc = bp.Qcur + (size_t)b * n * T;
-  double* Qt = bp.Qtry + (size_t)b * n * T;
+  double* __restrict__ Qc = bp.Qcur + (size_t)b * n * T;
+  double* __restrict__ Qt = bp.Qtry + (size_t)b * n * T;
   if (accept) {
     f = f_try;
     slot = trial;
   }
+  const int argmin_cur = accept ? argmin_try : argmin_cur0;
   // current iterate into LDS (rows >= n are padding); on accept it is the trial
   {
-    const double* src = accept ? Qt : Qc;
-    for (int idx = lane; idx < 8 * T; idx += 64) {
-      const int j = idx / T;
-      const double v = (j < n) ? src[idx] : 0.0;
-      s_Q[idx] = v;
-      if (accept && j < n) Qc[idx] = v;
+    const double* __restrict__ src = accept ? Qt : Qc;
+    double v[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int idx = tid + 256 * u;
+      v[u] = (idx < n * T) ? src[idx] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int idx = tid + 256 * u;
+      if (idx < 8 * T) s_Q[idx] = v[u];
+      if (accept && idx < n * T) Qc[idx] = v[u];
     }
   }
   if (!done && k >= sp.max_iter) {
     status = GTO_STATUS_MAX_ITER;
     done = 1;
   }
+  // every state field is written exactly once, by thread 0, on whichever path leaves the kernel
+#define GTO_FINISH(STATUS)                        \
+  do {                                            \
+    if (tid == 0) {                               \
+      st->f = f;                                  \
+      st->lambda = lambda;                        \
+      st->nu = nu;                                \
+      st->slot = slot;                            \
+      st->first = 0;                              \
+      st->done = 1;                               \
+      st->status = (STATUS);                      \
+      st->argmin_cur = argmin_cur;                \
+      atomicAdd(bp.n_done, 1);                    \
+    }                                             \
+    return;                                       \
+  } while (0)
   __syncthreads();
-  if (done) {
-    if (lane == 0) {
-      st->f = f;
-      st->lambda = lambda;
-      st->nu = nu;
-      st->slot = slot;
-      st->first = 0;
-      st->done = 1;
-      st->status = status;
-      if (accept) st->argmin_cur = st->argmin_try;
-      atomicAdd(bp.n_done, 1);
-    }
-    return;
-  }
+  if (done) GTO_FINISH(status);
 
-  if (bp.dbg && b == 0 && lane == 0) bp.dbg[1] = clock64();
+  if (bp.dbg && b == 0 && tid == 0) bp.dbg[1] = clock64();
   // ---- P2: normal equations at the current iterate (A = J^T J, b = J^T r; f = sum r^2)
-  const double* oblk = bp.blocks + ((size_t)slot * B + b) * T * BLK_STRIDE;
-  const double* gblk = bp.goalblk + ((size_t)slot * B + b) * 2 * BLK_STRIDE;
+  // wave w assembles waypoints s = w, w+4, ...; all global loads of the phase are issued up front.
+  const double* __restrict__ oblk = bp.blocks + ((size_t)slot * B + b) * T * BLK_STRIDE;
+  const double* __restrict__ gblk = bp.goalblk + ((size_t)slot * B + b) * 2 * BLK_STRIDE;
   const double alpha = sp.alpha;
   const bool inb = (r < n) && (c < n);
-  // undamped diagonal blocks, one coalesced 512 B read per waypoint; loads are issued eight at a time
-  // so their latencies overlap instead of serialising
-  for (int s0 = 0; s0 < m; s0 += 8) {
-    double v[8];
+  constexpr int KMAX = (GTO_MAX_T - 2 + 3) / 4;
+  double av[KMAX];  // undamped obstacle J^T J entry (r,c) of this wave's waypoints
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int s = s0 + u;
-      v[u] = (inb && s < m) ? oblk[(size_t)(s + 2) * BLK_STRIDE + BLK_JTJ + lane] : 0.0;
+  for (int kk = 0; kk < KMAX; ++kk) {
+    const int s = wave + 4 * kk;
+    av[kk] = (inb && s < m) ? oblk[(size_t)(s + 2) * BLK_STRIDE + BLK_JTJ + lane] : 0.0;
+  }
+  double jv[2];  // obstacle J^T r of this thread's (waypoint, joint) items
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int idx = tid + 256 * u, i = idx & 7;
+    jv[u] = (idx < m * 8 && i < n) ? oblk[(size_t)((idx >> 3) + 2) * BLK_STRIDE + BLK_JTR + i] : 0.0;
+  }
+  const double gA0 = inb ? gblk[BLK_JTJ + lane] : 0.0;
+  const double gA1 = (inb && sp.use_standoff) ? gblk[BLK_STRIDE + BLK_JTJ + lane] : 0.0;
+  if (tid < 16) {  // goal J^T r of both goal waypoints -> LDS (s_gaff is free until P6)
+    const int w = tid >> 3, i = tid & 7;
+    s_gaff[tid] = (i < n && (w == 0 || sp.use_standoff)) ? gblk[w * BLK_STRIDE + BLK_JTR + i] : 0.0;
+  }
+  if (tid == 0) *s_dmask = 0ull;
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int idx = tid + 256 * u;
+    if (idx < m * 8) {
+      const int sI = idx >> 3, i = idx & 7, t = sI + 2;
+      double bv = 0.0;
+      int act = 1;  // padded rows count as frozen
+      if (i < n) {
+        bv = sp.w_obstacle * jv[u];
+        if (t == T - 1) bv += s_gaff[i];
+        if (sp.use_standoff && t == sp.ts) bv += s_gaff[8 + i];
+        const double qt = s_Q[i * T + t], qm = s_Q[i * T + t - 1];
+        bv += alpha * (qt - qm);
+        if (t < T - 1) bv -= alpha * (s_Q[i * T + t + 1] - qt);
+        // active set: on a bound with the descent direction pointing outward
+        act = (qt <= rb->lower[i] && bv > 0.0) || (qt >= rb->upper[i] && bv < 0.0);
+      }
+      s_b[idx] = bv;
+      s_act[idx] = act;
     }
+  }
+  __syncthreads();
+  // undamped blocks -> s_A, damped / frozen system -> s_Z; remember which blocks are purely diagonal
+  {
+    unsigned long long dm = 0ull;
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int s = s0 + u, t = s + 2;
+    for (int kk = 0; kk < KMAX; ++kk) {
+      const int s = wave + 4 * kk;
       if (s < m) {
-        double a = sp.w_obstacle * v[u];
+        const int t = s + 2;
+        double a = sp.w_obstacle * av[kk];
+        if (t == T - 1) a += gA0;
+        if (t == sp.ts) a += gA1;
         if (inb && r == c) a += (t < T - 1) ? 2.0 * alpha : alpha;
         s_A[(size_t)s * 64 + lane] = a;
+        const int ar = s_act[s * 8 + r], ac = s_act[s * 8 + c];
+        double v = a;
+        if (ar || ac) v = (r == c) ? 1.0 : 0.0;
+        else if (r == c) v *= (1.0 + lambda);
+        s_Z[(size_t)s * 64 + lane] = v;
+        if (__any(r != c && v != 0.0)) dm |= 1ull << s;
       }
     }
+    if (lane == 0 && dm) atomicOr(s_dmask, dm);
   }
-  __syncthreads();
-  if (inb) {
-    s_A[(size_t)(T - 3) * 64 + lane] += gblk[BLK_JTJ + lane];
-    if (sp.use_standoff) s_A[(size_t)(sp.ts - 2) * 64 + lane] += gblk[BLK_STRIDE + BLK_JTJ + lane];
-  }
-  for (int idx = lane; idx < m * 8; idx += 64) {
-    const int s = idx >> 3, i = idx & 7, t = s + 2;
-    double bv = 0.0;
-    int act = 1;  // padded rows count as frozen
-    if (i < n) {
-      bv = sp.w_obstacle * oblk[(size_t)t * BLK_STRIDE + BLK_JTR + i];
-      if (t == T - 1) bv += gblk[BLK_JTR + i];
-      if (sp.use_standoff && t == sp.ts) bv += gblk[BLK_STRIDE + BLK_JTR + i];
-      const double qt = s_Q[i * T + t], qm = s_Q[i * T + t - 1];
-      bv += alpha * (qt - qm);
-      if (t < T - 1) bv -= alpha * (s_Q[i * T + t + 1] - qt);
-      // active set: on a bound with the descent direction pointing outward
-      act = (qt <= rb->lower[i] && bv > 0.0) || (qt >= rb->upper[i] && bv < 0.0);
-    }
-    s_b[idx] = bv;
-    s_act[idx] = act;
-  }
-  __syncthreads();
-  // damped / frozen system; remember which blocks are purely diagonal
-  unsigned long long dense_mask = 0ull;
-  for (int s = 0; s < m; ++s) {
-    double v = s_A[(size_t)s * 64 + lane];
-    const int ar = s_act[s * 8 + r], ac = s_act[s * 8 + c];
-    if (ar || ac) v = (r == c) ? 1.0 : 0.0;
-    else if (r == c) v *= (1.0 + lambda);
-    s_Z[(size_t)s * 64 + lane] = v;
-    if (__any(r != c && v != 0.0)) dense_mask |= 1ull << s;
-  }
-  for (int idx = lane; idx < m * 8; idx += 64) {
-    const int s = idx >> 3;
+  for (int idx = tid; idx < m * 8; idx += 256) {
+    const int sI = idx >> 3;
     const int a0 = s_act[idx];
-    const int a1 = (s < m - 1) ? s_act[idx + 8] : 1;
+    const int a1 = (sI < m - 1) ? s_act[idx + 8] : 1;
     s_e[idx] = (a0 || a1) ? 0.0 : -alpha;
     s_y[idx] = a0 ? 0.0 : -s_b[idx];  // right-hand side
   }
   __syncthreads();
+  const unsigned long long dense_mask = *s_dmask;
+  const int s_dense = dense_mask ? (__ffsll((long long)dense_mask) - 1) : m;
 
-  if (bp.dbg && b == 0 && lane == 0) bp.dbg[2] = clock64();
-  // ---- P3: block-tridiagonal solve by the inverse-based Schur recursion
+  if (bp.dbg && b == 0 && tid == 0) bp.dbg[2] = clock64();
+  // ---- P3 (wave 0): block-tridiagonal solve by the inverse-based Schur recursion
   //   S_s = D_s - E_{s-1} Z_{s-1} E_{s-1},  Z_s = S_s^{-1},  z_s = rhs_s - E_{s-1} y_{s-1},  y_s = Z_s z_s
   //   x_s = y_s - Z_s E_s x_{s+1}
   // Leading diagonal stretch (free-space waypoints carry only the velocity term, so S stays diagonal
-  // until the first dense block): a scalar recurrence on the diagonal lanes, ~6 dependent FMAs per
-  // waypoint.  Dense blocks: Gauss-Jordan without pivoting (SPD) with the pivot row/column moved by
-  // cross-lane shuffles and the mat-vec reductions done in registers; no LDS round trip, no barrier.
-  int fail = 0;
-  const int s_dense = dense_mask ? (__ffsll((long long)dense_mask) - 1) : m;
-  double zp = 0.0, yp = 0.0;
-  if (r == c) {
-    for (int s = 0; s < s_dense; ++s) {
-      const double ep = (s > 0) ? s_e[(s - 1) * 8 + r] : 0.0;
-      const double S = s_Z[(size_t)s * 64 + lane] - ep * ep * zp;
-      if (!(S > 0.0)) fail = 1;
-      const double Zr = fast_rcp(S);
-      const double y = Zr * (s_y[s * 8 + r] - ep * yp);
-      s_Z[(size_t)s * 64 + lane] = Zr;
-      s_x[s * 8 + r] = y;
-      zp = Zr;
-      yp = y;
+  // until the first dense block): a scalar recurrence on the diagonal lanes.  Dense blocks:
+  // Gauss-Jordan without pivoting (SPD) with the pivot row/column moved by cross-lane shuffles and the
+  // mat-vec reductions done in registers; no LDS round trip, no barrier.
+  if (wave == 0) {
+    int fail = 0;
+    double zp = 0.0, yp = 0.0;
+    if (r == c) {
+      for (int s = 0; s < s_dense; ++s) {
+        const double ep = (s > 0) ? s_e[(s - 1) * 8 + r] : 0.0;
+        const double S = s_Z[(size_t)s * 64 + lane] - ep * ep * zp;
+        if (!(S > 0.0)) fail = 1;
+        const double Zr = fast_rcp(S);
+        const double y = Zr * (s_y[s * 8 + r] - ep * yp);
+        s_Z[(size_t)s * 64 + lane] = Zr;
+        s_x[s * 8 + r] = y;
+        zp = Zr;
+        yp = y;
+      }
     }
-  }
-  __syncthreads();
-  if (bp.dbg && b == 0 && lane == 0) bp.dbg[3] = clock64();
-  double Zprev = (r == c) ? zp : 0.0;
-  double yprev_c = (s_dense > 0) ? s_x[(s_dense - 1) * 8 + c] : 0.0;  // y_{s-1}[c] for lane (r,c)
-  for (int s = s_dense; s < m; ++s) {
-    double S = s_Z[(size_t)s * 64 + lane];
-    double zc = s_y[s * 8 + c];
-    if (s > 0) {
-      const double er = s_e[(s - 1) * 8 + r], ec = s_e[(s - 1) * 8 + c];
-      S -= er * ec * Zprev;
-      zc -= ec * yprev_c;
-    }
+    wave_sync();
+    if (bp.dbg && b == 0 && tid == 0) bp.dbg[3] = clock64();
+    double Zprev = (r == c) ? zp : 0.0;
+    double yprev_c = (s_dense > 0) ? s_x[(s_dense - 1) * 8 + c] : 0.0;  // y_{s-1}[c] for lane (r,c)
+    for (int s = s_dense; s < m; ++s) {
+      double S = s_Z[(size_t)s * 64 + lane];
+      double zc = s_y[s * 8 + c];
+      if (s > 0) {
+        const double er = s_e[(s - 1) * 8 + r], ec = s_e[(s - 1) * 8 + c];
+        S -= er * ec * Zprev;
+        zc -= ec * yprev_c;
+      }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const double pjj = __shfl(S, j * 9, 64);
-      const double prj = __shfl(S, (lane & 56) | j, 64);
-      const double pjc = __shfl(S, j * 8 + c, 64);
-      if (!(pjj > 0.0)) fail = 1;
-      const double piv = fast_rcp(pjj);
-      if (r == j && c == j) S = piv;
-      else if (r == j) S = pjc * piv;
-      else if (c == j) S = -prj * piv;
-      else S = fma(-prj * piv, pjc, S);
-    }
-    s_Z[(size_t)s * 64 + lane] = S;  // Z_s
-    Zprev = S;
-    double pr = S * zc;  // y_s[r] = sum_c Z[r][c] z[c]
-    pr += __shfl_xor(pr, 1, 64);
-    pr += __shfl_xor(pr, 2, 64);
-    pr += __shfl_xor(pr, 4, 64);
-    if (c == 0) s_x[s * 8 + r] = pr;
-    yprev_c = __shfl(pr, c << 3, 64);  // transpose: lane (r,c) picks y_s[c] from row c
-  }
-  if (__any(fail)) {
-    if (lane == 0) {
-      st->f = f;
-      st->slot = slot;
-      st->first = 0;
-      st->done = 1;
-      st->status = GTO_STATUS_NUMERICAL;
-      if (accept) st->argmin_cur = st->argmin_try;
-      atomicAdd(bp.n_done, 1);
-    }
-    return;
-  }
-  __syncthreads();
-  if (bp.dbg && b == 0 && lane == 0) bp.dbg[4] = clock64();
-  // backward sweep; xr = x_{s+1}[r] (row copy), xc = x_{s+1}[c] (column copy) per lane
-  {
-    double xr = s_x[(m - 1) * 8 + r], xc = s_x[(m - 1) * 8 + c];
-    for (int s = m - 2; s >= s_dense; --s) {  // dense blocks
-      double pr = s_Z[(size_t)s * 64 + lane] * (s_e[s * 8 + c] * xc);
+      for (int j = 0; j < 8; ++j) {
+        const double pjj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(S), j * 9),
+                                            __builtin_amdgcn_readlane(__double2loint(S), j * 9));
+        const double prj = __shfl(S, (lane & 56) | j, 64);
+        const double pjc = __shfl(S, j * 8 + c, 64);
+        if (!(pjj > 0.0)) fail = 1;
+        const double piv = fast_rcp(pjj);
+        if (r == j && c == j) S = piv;
+        else if (r == j) S = pjc * piv;
+        else if (c == j) S = -prj * piv;
+        else S = fma(-prj * piv, pjc, S);
+      }
+      s_Z[(size_t)s * 64 + lane] = S;  // Z_s
+      Zprev = S;
+      double pr = S * zc;  // y_s[r] = sum_c Z[r][c] z[c]
       pr += __shfl_xor(pr, 1, 64);
       pr += __shfl_xor(pr, 2, 64);
       pr += __shfl_xor(pr, 4, 64);
-      xr = s_x[s * 8 + r] - pr;
-      if (c == 0) s_x[s * 8 + r] = xr;
-      xc = __shfl(xr, c << 3, 64);
+      if (c == 0) s_x[s * 8 + r] = pr;
+      yprev_c = __shfl(pr, c << 3, 64);  // transpose: lane (r,c) picks y_s[c] from row c
     }
-    if (r == c) {  // diagonal stretch
-      const int top = (s_dense < m - 1 ? s_dense : m - 1) - 1;
-      for (int s = top; s >= 0; --s) {
-        xr = s_x[s * 8 + r] - s_Z[(size_t)s * 64 + lane] * (s_e[s * 8 + r] * xr);
-        s_x[s * 8 + r] = xr;
+    wave_sync();
+    if (bp.dbg && b == 0 && tid == 0) bp.dbg[4] = clock64();
+    if (!__any(fail)) {
+      // backward sweep; xr = x_{s+1}[r] (row copy), xc = x_{s+1}[c] (column copy) per lane
+      double xr = s_x[(m - 1) * 8 + r], xc = s_x[(m - 1) * 8 + c];
+      for (int s = m - 2; s >= s_dense; --s) {  // dense blocks
+        double pr = s_Z[(size_t)s * 64 + lane] * (s_e[s * 8 + c] * xc);
+        pr += __shfl_xor(pr, 1, 64);
+        pr += __shfl_xor(pr, 2, 64);
+        pr += __shfl_xor(pr, 4, 64);
+        xr = s_x[s * 8 + r] - pr;
+        if (c == 0) s_x[s * 8 + r] = xr;
+        xc = __shfl(xr, c << 3, 64);
+      }
+      if (r == c) {  // diagonal stretch
+        const int top = (s_dense < m - 1 ? s_dense : m - 1) - 1;
+        for (int s = top; s >= 0; --s) {
+          xr = s_x[s * 8 + r] - s_Z[(size_t)s * 64 + lane] * (s_e[s * 8 + r] * xr);
+          s_x[s * 8 + r] = xr;
+        }
       }
     }
+    if (lane == 0) s_red[0] = __any(fail) ? 1.0 : 0.0;
   }
   __syncthreads();
+  if (s_red[0] != 0.0) GTO_FINISH(GTO_STATUS_NUMERICAL);
 
-  if (bp.dbg && b == 0 && lane == 0) bp.dbg[5] = clock64();
-  // ---- P4: projected trial point
+  if (bp.dbg && b == 0 && tid == 0) bp.dbg[5] = clock64();
+  // ---- P4: projected trial point; the LDS copy of Q becomes the trial, s_x the projected step
   double maxstep = 0.0;
-  for (int idx = lane; idx < m * 8; idx += 64) {
-    const int s = idx >> 3, i = idx & 7, t = s + 2;
+  for (int idx = tid; idx < m * 8; idx += 256) {
+    const int sI = idx >> 3, i = idx & 7, t = sI + 2;
     double sv = 0.0;
     if (i < n) {
       const double q0 = s_Q[i * T + t];
       double v = q0 + s_x[idx];
       v = fmin(fmax(v, rb->lower[i]), rb->upper[i]);
       Qt[(size_t)i * T + t] = v;
+      s_Q[i * T + t] = v;
       sv = v - q0;
     }
-    s_x[idx] = sv;  // actual (projected) step
+    s_x[idx] = sv;
     maxstep = fmax(maxstep, fabs(sv));
   }
-  for (int idx = lane; idx < n * 2; idx += 64) Qt[(size_t)(idx >> 1) * T + (idx & 1)] = s_Q[(idx >> 1) * T + (idx & 1)];
+  if (tid < n * 2) Qt[(size_t)(tid >> 1) * T + (tid & 1)] = s_Q[(tid >> 1) * T + (tid & 1)];
   maxstep = wave_max(maxstep);
+  if (lane == 0) s_red[1 + wave] = maxstep;
   __syncthreads();
-  if (maxstep < sp.tol_step) {
-    if (lane == 0) {
-      st->f = f;
-      st->lambda = lambda;
-      st->nu = nu;
-      st->slot = slot;
-      st->first = 0;
-      st->done = 1;
-      st->status = GTO_STATUS_CONVERGED;
-      if (accept) st->argmin_cur = st->argmin_try;
-      atomicAdd(bp.n_done, 1);
-    }
-    return;
-  }
-  if (bp.dbg && b == 0 && lane == 0) bp.dbg[6] = clock64();
-  // ---- P5: predicted decrease of the undamped model: -(2 b.s + s^T A s)
-  double acc = 0.0;
+  maxstep = fmax(fmax(s_red[1], s_red[2]), fmax(s_red[3], s_red[4]));
+  if (maxstep < sp.tol_step) GTO_FINISH(GTO_STATUS_CONVERGED);
+
+  if (bp.dbg && b == 0 && tid == 0) bp.dbg[6] = clock64();
+  // ---- P5: predicted decrease of the undamped model: -(2 b.s + s^T A s), waypoints split over waves
   {
-    double part[4] = {0.0, 0.0, 0.0, 0.0};
-    for (int s0 = 0; s0 < m; s0 += 4) {
+    double part = 0.0;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int s = s0 + u;
-        if (s < m) {
-          const double sr = s_x[s * 8 + r], scv = s_x[s * 8 + c];
-          double v = s_A[(size_t)s * 64 + lane] * sr * scv;
-          if (c == 0) {
-            v += 2.0 * s_b[s * 8 + r] * sr;
-            if (s < m - 1) v += 2.0 * (-alpha) * sr * s_x[(s + 1) * 8 + r];
-          }
-          part[u] += v;
+    for (int kk = 0; kk < KMAX; ++kk) {
+      const int s = wave + 4 * kk;
+      if (s < m) {
+        const double sr = s_x[s * 8 + r], scv = s_x[s * 8 + c];
+        double v = s_A[(size_t)s * 64 + lane] * sr * scv;
+        if (c == 0) {
+          v += 2.0 * s_b[s * 8 + r] * sr;
+          if (s < m - 1) v += 2.0 * (-alpha) * sr * s_x[(s + 1) * 8 + r];
         }
+        part += v;
       }
     }
-    acc = (part[0] + part[1]) + (part[2] + part[3]);
+    part = wave_sum(part);
+    if (lane == 0) s_red[8 + wave] = part;
   }
-  acc = wave_sum(acc);
-  if (lane == 0) {
+  __syncthreads();
+  const double acc = (s_red[8] + s_red[9]) + (s_red[10] + s_red[11]);
+  if (tid == 0) {
     st->f = f;
     st->lambda = lambda;
     st->nu = nu;
@@ -1280,14 +1321,17 @@ __global__ __launch_bounds__(64) void k_lm_step(const RobotDev* __restrict__ rb,
     st->first = 0;
     st->status = status;
     st->evals = k + 1;
-    if (accept) st->argmin_cur = st->argmin_try;
+    st->argmin_cur = argmin_cur;
   }
-  __syncthreads();
-  if (bp.dbg && b == 0 && lane == 0) bp.dbg[7] = clock64();
-  // ---- P6: goal terms of the new trial (the obstacle kernel evaluates the rest)
-  trial_goal_terms_wave(rb, bp, sp, B, b, lane, 1 - slot, st, s_q, s_fr, s_gaff, s_gscr);
-  if (bp.dbg && b == 0 && lane == 0) bp.dbg[8] = clock64();
-  if (bp.dbg && b == 0 && lane == 0) bp.dbg[9] = s_dense;
+#undef GTO_FINISH
+  if (bp.dbg && b == 0 && tid == 0) bp.dbg[7] = clock64();
+  // The goal-set and velocity terms of the new trial are evaluated by the extra workgroups of the next
+  // k_obstacle_gram launch (off the serial path).
+  if (bp.dbg && b == 0 && tid == 0) {
+    bp.dbg[8] = clock64();
+    bp.dbg[9] = s_dense;
+    bp.dbg[0] = t_dbg0;
+  }
 }
 
 __global__ __launch_bounds__(64) void k_lm_finalize(const RobotDev* __restrict__ rb, BatchPtrs bp, SolveParams sp, int B,
