@@ -145,7 +145,7 @@ int gto_create(const gto_robot_desc* d, const gto_solver_opts* opts, int device,
   h->opts = *opts;
   if (const char* e = getenv("GTO_GROUPS")) h->n_groups = std::max(1, std::min(GTO_MAX_GROUPS, atoi(e)));
   if (const char* e = getenv("GTO_CHECK_EVERY")) h->check_every = atoi(e);
-  if (getenv("GTO_DEBUG_TIMING")) { (void)hipMalloc((void**)&h->dbg, 16 * sizeof(long long)); (void)hipMemset(h->dbg, 0, 16 * sizeof(long long)); }
+  if (getenv("GTO_DEBUG_TIMING")) { (void)hipMalloc((void**)&h->dbg, 32 * sizeof(long long)); (void)hipMemset(h->dbg, 0, 32 * sizeof(long long)); }
   RobotDev& rb = h->rb;
   memset(&rb, 0, sizeof rb);
   rb.n_frames = d->n_frames;
@@ -156,9 +156,11 @@ int gto_create(const gto_robot_desc* d, const gto_solver_opts* opts, int device,
   rb.n_gripper_points = d->n_gripper_points;
   rb.frame_ee = d->frame_ee;
   rb.frame_gripper = d->frame_gripper;
+  for (int i = 0; i < GTO_MAX_DOF; ++i) rb.opt_of_dof[i] = -1;
   for (int j = 0; j < d->n_opt; ++j) {
     if (d->opt_index[j] < 0 || d->opt_index[j] >= d->ndof) { delete h; return fail(nullptr, GTO_ERR_INVALID_ARG, "opt_index out of range"); }
     rb.opt_index[j] = d->opt_index[j];
+    rb.opt_of_dof[d->opt_index[j]] = j;
     rb.lower[j] = d->lower[j];
     rb.upper[j] = d->upper[j];
     if (!(d->lower[j] <= d->upper[j])) { delete h; return fail(nullptr, GTO_ERR_INVALID_ARG, "lower > upper"); }
@@ -194,6 +196,15 @@ int gto_create(const gto_robot_desc* d, const gto_solver_opts* opts, int device,
           anc |= 1u << j;
         }
     rb.frame_anc[i] = anc;
+  }
+  {
+    int depth[GTO_MAX_FRAMES], maxd = 1;
+    for (int i = 0; i < d->n_frames; ++i) {
+      depth[i] = rb.parent[i] < 0 ? 0 : depth[rb.parent[i]] + 1;
+      maxd = std::max(maxd, depth[i]);
+    }
+    rb.fk_rounds = 0;
+    while ((1 << rb.fk_rounds) < maxd) ++rb.fk_rounds;
   }
   for (int l = 0; l < d->n_links; ++l) {
     int f = d->link_frame[l];
@@ -280,7 +291,7 @@ int gto_create(const gto_robot_desc* d, const gto_solver_opts* opts, int device,
     i = j;
   }
   rb.n_chunks = (int)chunks.size();
-  if (rb.n_chunks > GTO_MAX_ACTIVE) { delete h; return fail(nullptr, GTO_ERR_UNSUPPORTED, "too many surface points (max 65536)"); }
+  if (rb.n_chunks > GTO_MAX_ACTIVE) { delete h; return fail(nullptr, GTO_ERR_UNSUPPORTED, "too many surface points (max 16384)"); }
 
   if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return fail(nullptr, GTO_ERR_HIP, "hipStreamCreate failed"); }
   auto up = [&](void** dst, const void* src, size_t bytes) -> bool {
@@ -678,10 +689,13 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
   HIPCHK(h, hipGetLastError());
   if (h->dbg) {
     HIPCHK(h, hipStreamSynchronize(st));
-    long long t[16];
+    long long t[32];
     HIPCHK(h, hipMemcpy(t, h->dbg, sizeof t, hipMemcpyDeviceToHost));
     fprintf(stderr, "[gto dbg] step-kernel phases (cycles) P0+P1 %lld | P2 %lld | diag %lld | dense %lld | back %lld | P4 %lld | P5 %lld | P6 %lld | s_dense %lld\n",
             t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3], t[5] - t[4], t[6] - t[5], t[7] - t[6], t[8] - t[7], t[9]);
+    fprintf(stderr, "[gto dbg] obstacle WG (b=0,t=T-1) cycles: prologue %lld | broad %lld | loop %lld | epilogue %lld | active chunks %lld\n",
+            t[11] - t[10], t[12] - t[11], t[13] - t[12], t[14] - t[13], t[15]);
+    fprintf(stderr, "[gto dbg] prologue split: loads+q %lld | local transforms %lld | chain %lld | vis+screw %lld\n", t[16] - t[10], t[17] - t[16], t[18] - t[17], t[11] - t[18]);
   }
   if (h->profiling) {
     HIPCHK(h, hipStreamSynchronize(st));

@@ -21,10 +21,12 @@
 struct RobotDev {
   int32_t n_frames, ndof, n_opt, n_links, n_points, n_chunks, n_gripper_points;
   int32_t frame_ee, frame_gripper;
+  int32_t fk_rounds;  // ceil(log2(depth of the kinematic tree)): pointer-jumping rounds of the parallel FK
   int32_t parent[GTO_MAX_FRAMES];
   int32_t joint_type[GTO_MAX_FRAMES];
   int32_t q_index[GTO_MAX_FRAMES];
   int32_t opt_of_frame[GTO_MAX_FRAMES];  // optimised-joint slot driven by this frame's joint, or -1
+  int32_t opt_of_dof[GTO_MAX_DOF];       // optimised-joint slot of actuated joint i, or -1 (parameter joint)
   uint32_t frame_anc[GTO_MAX_FRAMES];    // bit j: optimised joint j moves this frame
   double origin[GTO_MAX_FRAMES][12];     // rt2tr(rpy2r(rpy), xyz)  (optas/models.py:848-857)
   double axis_unit[GTO_MAX_FRAMES][3];   // unit(axis)              (optas/models.py:653-659)

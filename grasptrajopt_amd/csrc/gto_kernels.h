@@ -124,6 +124,12 @@ __device__ inline double wave_sum4(double a, double b, double c, double d) {
   return row_sum16(swap16_add(swap32_add(a, b), swap32_add(c, d)));
 }
 
+__device__ inline void wave_sync_lds() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // Forward kinematics of ONE configuration by a whole workgroup (optas/models.py:826-868, prefix
 // shared): s_q [ndof] in LDS -> s_fr [n_frames][12] global frame transforms in LDS.
 // Must be called by every thread of the block (contains barriers).
@@ -165,26 +171,46 @@ __device__ inline void fk_block(const RobotDev* rb, const double* s_q, double* s
     }
   }
   __syncthreads();
-  // chain T_i = T_parent @ L_i in place; lane r (<3) carries row r, so no cross-lane traffic
+  // chain T_i = T_parent @ L_i in place; lane r (<3) carries row r of the running product in registers,
+  // so a serial chain needs no LDS write->read round trip (only branching parents are re-read)
   if (tid < 3) {
+    double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
+    int have = -1;  // frame whose row is held in p0..p3
     for (int i = 0; i < F; ++i) {
       const int p = rb->parent[i];
-      if (p < 0) continue;  // root: T = L
-      const double* P = s_fr + 12 * p + 4 * tid;
-      const double* L = s_fr + 12 * i;
-      const double p0 = P[0], p1 = P[1], p2 = P[2], p3 = P[3];
-      const double t0 = p0 * L[0] + p1 * L[4] + p2 * L[8];
-      const double t1 = p0 * L[1] + p1 * L[5] + p2 * L[9];
-      const double t2 = p0 * L[2] + p1 * L[6] + p2 * L[10];
-      const double t3 = p0 * L[3] + p1 * L[7] + p2 * L[11] + p3;
+      if (p < 0) {  // root: T = L
+        const double* Lr = s_fr + 12 * i + 4 * tid;
+        p0 = Lr[0];
+        p1 = Lr[1];
+        p2 = Lr[2];
+        p3 = Lr[3];
+        have = i;
+        continue;
+      }
+      if (p != have) {
+        wave_sync_lds();
+        const double* P = s_fr + 12 * p + 4 * tid;
+        p0 = P[0];
+        p1 = P[1];
+        p2 = P[2];
+        p3 = P[3];
+      }
+      const double* Lm = s_fr + 12 * i;
+      const double t0 = p0 * Lm[0] + p1 * Lm[4] + p2 * Lm[8];
+      const double t1 = p0 * Lm[1] + p1 * Lm[5] + p2 * Lm[9];
+      const double t2 = p0 * Lm[2] + p1 * Lm[6] + p2 * Lm[10];
+      const double t3 = p0 * Lm[3] + p1 * Lm[7] + p2 * Lm[11] + p3;
       __builtin_amdgcn_wave_barrier();  // every row has read L_i before any row overwrites it
-      double* O = s_fr + 12 * i + 4 * tid;
-      O[0] = t0;
-      O[1] = t1;
-      O[2] = t2;
-      O[3] = t3;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
+      double* Oo = s_fr + 12 * i + 4 * tid;
+      Oo[0] = t0;
+      Oo[1] = t1;
+      Oo[2] = t2;
+      Oo[3] = t3;
+      p0 = t0;
+      p1 = t1;
+      p2 = t2;
+      p3 = t3;
+      have = i;
     }
   }
   __syncthreads();
@@ -241,12 +267,28 @@ __device__ inline void fk_pair_wave(const RobotDev* rb, const double* s_q2, doub
   }
   wave_sync();
   if (l < 3) {
+    double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
+    int have = -1;
     for (int i = 0; i < F; ++i) {
       const int p = rb->parent[i];
-      if (p < 0) continue;
-      const double* P = s_fr + 12 * p + 4 * l;
+      if (p < 0) {
+        const double* Lr = s_fr + 12 * i + 4 * l;
+        p0 = Lr[0];
+        p1 = Lr[1];
+        p2 = Lr[2];
+        p3 = Lr[3];
+        have = i;
+        continue;
+      }
+      if (p != have) {
+        wave_sync();
+        const double* P = s_fr + 12 * p + 4 * l;
+        p0 = P[0];
+        p1 = P[1];
+        p2 = P[2];
+        p3 = P[3];
+      }
       const double* Lm = s_fr + 12 * i;
-      const double p0 = P[0], p1 = P[1], p2 = P[2], p3 = P[3];
       const double t0 = p0 * Lm[0] + p1 * Lm[4] + p2 * Lm[8];
       const double t1 = p0 * Lm[1] + p1 * Lm[5] + p2 * Lm[9];
       const double t2 = p0 * Lm[2] + p1 * Lm[6] + p2 * Lm[10];
@@ -257,8 +299,11 @@ __device__ inline void fk_pair_wave(const RobotDev* rb, const double* s_q2, doub
       Oo[1] = t1;
       Oo[2] = t2;
       Oo[3] = t3;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
+      p0 = t0;
+      p1 = t1;
+      p2 = t2;
+      p3 = t3;
+      have = i;
     }
   }
   wave_sync();
@@ -401,7 +446,7 @@ __global__ void k_dist_relax(const uint8_t* __restrict__ in, uint8_t* __restrict
 //             transforms of the collision links and joint screws staged in LDS
 //   main loop one link-uniform chunk of 64 Morton-sorted surface points per wave step
 //   epilogue  per-link 6x6 wrench Grams -> J^T J (n x n), J^T r (n), sum c^2
-#define GTO_MAX_ACTIVE 1024  // chunks per robot the broad phase can list (64 K surface points)
+#define GTO_MAX_ACTIVE 256   // chunks per robot the broad phase can list (16 K surface points)
 #define GTO_MAX_T 64       // waypoints the step kernel's register-resident phases are unrolled for
 #define GTO_LIST_CAP 80  // entries of 8 doubles per wave: a full chunk (64) always fits after a drain
 struct InstState;
@@ -433,11 +478,14 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
   __shared__ double s_screw[GTO_MAX_OPT * 6];
   __shared__ double s_gram[GTO_MAX_LINKS * GTO_GRAM];
   __shared__ double s_list[4 * GTO_LIST_CAP * 8];  // per-wave wrench lists; reused as s_u in the epilogue
-  __shared__ int s_active[GTO_MAX_ACTIVE];  // broad phase: chunks that may touch a non-zero voxel
+  __shared__ int4 s_active[GTO_MAX_ACTIVE];  // broad phase: {link, start, count, id} of chunks that may touch a non-zero voxel
   __shared__ int s_wcount[4];
   __shared__ int s_nactive;
+  __shared__ unsigned s_touched;  // links whose Gram received a contribution
+  __shared__ int s_parent[GTO_MAX_FRAMES], s_parentB[GTO_MAX_FRAMES];
   __shared__ double s_out[BLK_STRIDE];
   double* s_u = s_list;  // [L][GTO_MAX_OPT][6] <= 1536 doubles
+  double* s_frB = s_list;  // FK ping-pong buffer (prologue only)
 
   // Extra workgroups (blockIdx >= n_regular), one per instance: goal-set terms and velocity term of the
   // trial trajectory.  The step kernel only needs them at its NEXT launch, so they ride in the shadow
@@ -458,25 +506,164 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int L = rb->n_links, n = rb->n_opt, T = sp.T, ndof = rb->ndof;
 
-  // ---- prologue: q_t (parameter rows from Q0, optimised rows from the trial), FK, visual tf, screws
-  if (tid < ndof) s_q[tid] = bp.Q0[((size_t)b * ndof + tid) * T + t];
+  if (bp.dbg && b == 0 && t == sp.T - 1 && tid == 0) bp.dbg[10] = clock64();
+  // ---- prologue: q_t (parameter rows from Q0, optimised rows from the trial), FK, visual tf, screws.
+  // Every global load the prologue needs (configuration, per-frame and per-link constants) is issued
+  // up front so the workgroup pays ONE memory round trip before the LDS-only chain.
+  double qv = 0.0;
+  int qdst = -1;
+  if (tid < ndof) {
+    qv = bp.Q0[((size_t)b * ndof + tid) * T + t];
+    qdst = tid;
+  } else if (tid >= 64 && tid < 64 + n) {
+    qv = bp.Qtry[((size_t)b * n + (tid - 64)) * T + t];
+    qdst = rb->opt_index[tid - 64];
+  }
+  const int F = rb->n_frames;
+  int f_jt = 0, f_qi = 0;
+  double fO[12], fax[3] = {0, 0, 0};
+  if (tid < F) {
+    s_parent[tid] = rb->parent[tid];
+    f_jt = rb->joint_type[tid];
+    f_qi = rb->q_index[tid];
+#pragma unroll
+    for (int k2 = 0; k2 < 12; ++k2) fO[k2] = rb->origin[tid][k2];
+#pragma unroll
+    for (int k2 = 0; k2 < 3; ++k2) fax[k2] = rb->axis_unit[tid][k2];
+  }
+  // visual-transform role: thread (l, e) for l < L, e < 12
+  const int v_l = tid / 12, v_e = tid % 12, v_r = v_e >> 2, v_c = v_e & 3;
+  int v_frame = 0;
+  double vo0 = 0.0, vo1 = 0.0, vo2 = 0.0;
+  if (tid < L * 12) {
+    v_frame = rb->link_frame[v_l];
+    vo0 = rb->vis_origin[v_l][v_c];
+    vo1 = rb->vis_origin[v_l][4 + v_c];
+    vo2 = rb->vis_origin[v_l][8 + v_c];
+  }
+  // screw role: threads 192 .. 192+F
+  const int sc_i = tid - 192;
+  int sc_j = -1, sc_jt = 0;
+  double sax[3] = {0, 0, 0};
+  if (sc_i >= 0 && sc_i < F) {
+    sc_j = rb->opt_of_frame[sc_i];
+    sc_jt = rb->joint_type[sc_i];
+#pragma unroll
+    for (int k2 = 0; k2 < 3; ++k2) sax[k2] = rb->axis_unit[sc_i][k2];
+  }
   for (int i = tid; i < L * GTO_GRAM; i += 256) s_gram[i] = 0.0;
   if (tid < BLK_STRIDE) s_out[tid] = 0.0;
+  if (tid == 0) s_touched = 0u;
+  if (tid < ndof) s_q[qdst] = qv;
   __syncthreads();
-  if (tid < n) s_q[rb->opt_index[tid]] = bp.Qtry[((size_t)b * n + tid) * T + t];
+  if (tid >= 64 && qdst >= 0) s_q[qdst] = qv;  // optimised rows override
   __syncthreads();
-  fk_block(rb, s_q, s_fr, tid);
+  if (bp.dbg && b == 0 && t == sp.T - 1 && tid == 0) bp.dbg[16] = clock64();
+  if (tid < F) {  // local transform L_i = origin_i @ joint_motion_i(q)
+    double* Lo = s_fr + 12 * tid;
+    if (f_jt == GTO_JOINT_REVOLUTE) {
+      // Rodrigues about the unit axis u: R = cos*I + sin*[u]x + (1-cos) u u^T (optas/spatialmath.py:90-100)
+      const double th = s_q[f_qi];
+      double sn, cs;
+      sincos(th, &sn, &cs);
+      const double c1 = 1.0 - cs, u0 = fax[0], u1 = fax[1], u2 = fax[2];
+      const double R00 = cs + c1 * u0 * u0, R01 = c1 * u0 * u1 - sn * u2, R02 = c1 * u0 * u2 + sn * u1;
+      const double R10 = c1 * u1 * u0 + sn * u2, R11 = cs + c1 * u1 * u1, R12 = c1 * u1 * u2 - sn * u0;
+      const double R20 = c1 * u2 * u0 - sn * u1, R21 = c1 * u2 * u1 + sn * u0, R22 = cs + c1 * u2 * u2;
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const double o0 = fO[4 * r], o1 = fO[4 * r + 1], o2 = fO[4 * r + 2];
+        Lo[4 * r] = o0 * R00 + o1 * R10 + o2 * R20;
+        Lo[4 * r + 1] = o0 * R01 + o1 * R11 + o2 * R21;
+        Lo[4 * r + 2] = o0 * R02 + o1 * R12 + o2 * R22;
+        Lo[4 * r + 3] = fO[4 * r + 3];
+      }
+    } else if (f_jt == GTO_JOINT_PRISMATIC) {
+      const double qi = s_q[f_qi];
+      const double t0 = qi * fax[0], t1 = qi * fax[1], t2 = qi * fax[2];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const double o0 = fO[4 * r], o1 = fO[4 * r + 1], o2 = fO[4 * r + 2];
+        Lo[4 * r] = o0;
+        Lo[4 * r + 1] = o1;
+        Lo[4 * r + 2] = o2;
+        Lo[4 * r + 3] = o0 * t0 + o1 * t1 + o2 * t2 + fO[4 * r + 3];
+      }
+    } else {
+#pragma unroll
+      for (int k2 = 0; k2 < 12; ++k2) Lo[k2] = fO[k2];
+    }
+  }
+  __syncthreads();
+  if (bp.dbg && b == 0 && t == sp.T - 1 && tid == 0) bp.dbg[17] = clock64();
+  // global transforms by pointer jumping over the kinematic tree (parallel prefix of the chain
+  // products): every round replaces M_i by M_anc(i) @ M_i and anc(i) by anc(anc(i)); after
+  // ceil(log2(depth)) rounds M_i is the global transform of frame i.  All F*12 matrix elements are
+  // computed in parallel each round, so the latency is ~4 LDS round trips instead of one per frame.
+  {
+    double* Ma = s_fr;    // ping
+    double* Mb = s_frB;   // pong
+    int* Aa = s_parent;
+    int* Ab = s_parentB;
+    for (int rd = 0; rd < rb->fk_rounds; ++rd) {
+      for (int idx = tid; idx < F * 12; idx += 256) {
+        const int i = idx / 12, e = idx % 12, rr = e >> 2, cc = e & 3;
+        const int a = Aa[i];
+        double v;
+        if (a >= 0) {
+          const double* P = Ma + 12 * a + 4 * rr;
+          const double* Lm = Ma + 12 * i;
+          v = P[0] * Lm[cc] + P[1] * Lm[4 + cc] + P[2] * Lm[8 + cc];
+          if (cc == 3) v += P[3];
+          if (e == 0) Ab[i] = Aa[a];
+        } else {
+          v = Ma[idx];
+          if (e == 0) Ab[i] = -1;
+        }
+        Mb[idx] = v;
+      }
+      __syncthreads();
+      double* tM = Ma;
+      Ma = Mb;
+      Mb = tM;
+      int* tA = Aa;
+      Aa = Ab;
+      Ab = tA;
+    }
+    if (Ma != s_fr) {  // odd number of rounds: results live in the pong buffer
+      for (int idx = tid; idx < F * 12; idx += 256) s_fr[idx] = Ma[idx];
+      __syncthreads();
+    }
+  }
+  if (bp.dbg && b == 0 && t == sp.T - 1 && tid == 0) bp.dbg[18] = clock64();
   if (tid < L * 12) {  // visual_tf = link_tf @ visual origin (gto/gto_models.py:92-100)
-    const int l = tid / 12, e = tid % 12, r = e >> 2, c = e & 3;
-    const double* Fr = s_fr + 12 * rb->link_frame[l] + 4 * r;
-    const double* Vo = rb->vis_origin[l];
-    double v = Fr[0] * Vo[c] + Fr[1] * Vo[4 + c] + Fr[2] * Vo[8 + c];
-    if (c == 3) v += Fr[3];
+    const double* Fr = s_fr + 12 * v_frame + 4 * v_r;
+    double v = Fr[0] * vo0 + Fr[1] * vo1 + Fr[2] * vo2;
+    if (v_c == 3) v += Fr[3];
     s_vis[tid] = v;
   }
-  if (tid >= 192 && tid < 192 + rb->n_frames) {
-    const int i = tid - 192, j = rb->opt_of_frame[i];
-    if (j >= 0) screw_of_frame(rb, i, s_fr + 12 * i, s_screw + 6 * j);
+  if (sc_j >= 0) {  // world screw (a ; o x a) of the optimised joint carried by frame sc_i
+    const double* Fm = s_fr + 12 * sc_i;
+    double a[3], o[3];
+#pragma unroll
+    for (int r2 = 0; r2 < 3; ++r2) {
+      a[r2] = Fm[4 * r2] * sax[0] + Fm[4 * r2 + 1] * sax[1] + Fm[4 * r2 + 2] * sax[2];
+      o[r2] = Fm[4 * r2 + 3];
+    }
+    double* sw = s_screw + 6 * sc_j;
+    if (sc_jt == GTO_JOINT_PRISMATIC) {
+      sw[0] = sw[1] = sw[2] = 0.0;
+      sw[3] = a[0];
+      sw[4] = a[1];
+      sw[5] = a[2];
+    } else {
+      sw[0] = a[0];
+      sw[1] = a[1];
+      sw[2] = a[2];
+      sw[3] = o[1] * a[2] - o[2] * a[1];
+      sw[4] = o[2] * a[0] - o[0] * a[2];
+      sw[5] = o[0] * a[1] - o[1] * a[0];
+    }
   }
   __syncthreads();
 
@@ -488,6 +675,7 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
   const bool need_grad = !fixed_mode && sp.grad_mode == GTO_GRAD_CENTRAL_DIFF;
   const int nz = sc.nz;
 
+  if (bp.dbg && b == 0 && t == sp.T - 1 && tid == 0) bp.dbg[11] = clock64();
   // ---- broad phase: one thread per chunk transforms the chunk's bounding-sphere centre and looks up
   // the Chebyshev distance to the nearest non-zero voxel; a chunk whose sphere (radius R voxels, +1
   // for the floor of the centre) cannot reach one contributes exact zeros and is skipped.  The list
@@ -499,8 +687,10 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
   for (int base_c = 0; base_c < C; base_c += 256) {
     const int ci = base_c + tid;
     bool keep = false;
+    int4 desc4 = make_int4(0, 0, 0, 0);
     if (ci < C) {
       const Chunk cc = chunks[ci];
+      desc4 = make_int4(cc.link, cc.start, cc.count, ci);
       const double* V = s_vis + 12 * cc.link;
       const double u0 = (V[0] * cc.cx + V[1] * cc.cy + V[2] * cc.cz + V[3] + bx - sc.ox) * sc.rinv;
       const double u1 = (V[4] * cc.cx + V[5] * cc.cy + V[6] * cc.cz + V[7] + by - sc.oy) * sc.rinv;
@@ -519,7 +709,7 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
     for (int w = 0; w < wave; ++w) woff += s_wcount[w];
     if (keep) {
       const int pos = woff + __popcll(bm & ((1ull << lane) - 1ull));
-      if (pos < GTO_MAX_ACTIVE) s_active[pos] = ci;
+      if (pos < GTO_MAX_ACTIVE) s_active[pos] = desc4;
     }
     __syncthreads();
     if (tid == 0) s_nactive = min(s_nactive + s_wcount[0] + s_wcount[1] + s_wcount[2] + s_wcount[3], GTO_MAX_ACTIVE);
@@ -529,6 +719,7 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
   // contiguous range of surviving chunks per wave
   const int c0 = (int)(((long)NA * wave) / 4), c1 = (int)(((long)NA * (wave + 1)) / 4);
 
+  if (bp.dbg && b == 0 && t == sp.T - 1 && tid == 0) bp.dbg[12] = clock64();
   // Sparse Gram accumulation.  Most surface points are in free space (zero gradient): a lane whose
   // point has a non-zero gradient appends its wrench (y x w, w) and cost c to a small per-wave LDS
   // list; the list is folded into the per-link 6x6 Gram by the wave with ONE accumulator per lane
@@ -571,16 +762,23 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
 #define GTO_FLUSH(link)                                                                      \
   do {                                                                                       \
     if (cnt) GTO_DRAIN();                                                                    \
-    if (grp >= 0 && kk < 27 && gacc != 0.0) atomicAdd(&s_gram[(link)*GTO_GRAM + kk], gacc);  \
+    if (grp >= 0 && kk < 27 && gacc != 0.0) {                                                \
+      atomicAdd(&s_gram[(link)*GTO_GRAM + kk], gacc);                                        \
+      atomicOr(&s_touched, 1u << (link));                                                    \
+    }                                                                                        \
     gacc = 0.0;                                                                              \
   } while (0)
 
   // software prefetch: the next chunk's descriptor and point coordinates are requested before the
   // current chunk is processed, so two memory round trips (points, voxel records) overlap
-  Chunk ch = {0, 0, 0, 0, 0, 0, 0, 0};
+  struct ChunkLite {
+    int link, start, count;
+  };
+  ChunkLite ch = {0, 0, 0};
   double x0 = 0.0, x1 = 0.0, x2 = 0.0;
   if (c0 < c1) {
-    ch = chunks[s_active[c0]];
+    const int4 d4 = s_active[c0];
+    ch = {d4.x, d4.y, d4.z};
     if (lane < ch.count) {
       x0 = px[ch.start + lane];
       x1 = py[ch.start + lane];
@@ -589,10 +787,11 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
   }
 #pragma unroll 1
   for (int c = c0; c < c1; ++c) {
-    Chunk nch = {0, 0, 0, 0, 0, 0, 0, 0};
+    ChunkLite nch = {0, 0, 0};
     double n0 = 0.0, n1 = 0.0, n2 = 0.0;
     if (c + 1 < c1) {
-      nch = chunks[s_active[c + 1]];
+      const int4 d4 = s_active[c + 1];
+      nch = {d4.x, d4.y, d4.z};
       if (lane < nch.count) {
         n0 = px[nch.start + lane];
         n1 = py[nch.start + lane];
@@ -654,22 +853,28 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
   if (cur_link >= 0) GTO_FLUSH(cur_link);
 #undef GTO_FLUSH
 #undef GTO_DRAIN
+  if (bp.dbg && b == 0 && t == sp.T - 1 && tid == 0) bp.dbg[13] = clock64();
   ss = wave_sum(ss);
   if (lane == 0) atomicAdd(&s_out[BLK_SS], ss);
   __syncthreads();
 
-  // projection of the per-link wrench Grams onto the joint screws:
+  // projection of the per-link wrench Grams onto the joint screws, over the links that were touched:
   //   JtJ[i][j] = sum_l [i,j in anc(l)] s_i^T W_l s_j ,  Jtr[i] = sum_l [i in anc(l)] s_i . v_l
-  if (!fixed_mode) {
+  const unsigned touched = s_touched;
+  if (!fixed_mode && touched) {
     for (int idx = tid; idx < L * n; idx += 256) {
       const int l = idx / n, j = idx % n;
+      if (!((touched >> l) & 1u)) continue;
       const double* W = s_gram + l * GTO_GRAM;
       const double* sj = s_screw + 6 * j;
       const bool on = (rb->link_anc[l] >> j) & 1u;
+#pragma unroll
       for (int r = 0; r < 6; ++r) {
         double u = 0.0;
-        if (on)
+        if (on) {
+#pragma unroll
           for (int c = 0; c < 6; ++c) u += W[sym6(r, c)] * sj[c];
+        }
         s_u[(l * GTO_MAX_OPT + j) * 6 + r] = u;
       }
     }
@@ -682,7 +887,7 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
         const double* si = s_screw + 6 * i;
         for (int l = 0; l < L; ++l) {
           const uint32_t anc = rb->link_anc[l];
-          if (((anc >> i) & 1u) && ((anc >> j) & 1u)) {
+          if (((touched >> l) & 1u) && ((anc >> i) & 1u) && ((anc >> j) & 1u)) {
             const double* u = s_u + (l * GTO_MAX_OPT + j) * 6;
             v += si[0] * u[0] + si[1] * u[1] + si[2] * u[2] + si[3] * u[3] + si[4] * u[4] + si[5] * u[5];
           }
@@ -695,7 +900,7 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
       if (i < n) {
         const double* si = s_screw + 6 * i;
         for (int l = 0; l < L; ++l)
-          if ((rb->link_anc[l] >> i) & 1u) {
+          if (((touched >> l) & 1u) && ((rb->link_anc[l] >> i) & 1u)) {
             const double* vv = s_gram + l * GTO_GRAM + 21;
             v += si[0] * vv[0] + si[1] * vv[1] + si[2] * vv[2] + si[3] * vv[3] + si[4] * vv[4] + si[5] * vv[5];
           }
@@ -704,6 +909,10 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
     }
   }
   __syncthreads();
+  if (bp.dbg && b == 0 && t == sp.T - 1 && tid == 0) {
+    bp.dbg[14] = clock64();
+    bp.dbg[15] = NA;
+  }
   if (fixed_mode) {
     if (tid == 0) bp.ss_fixed[2 * b + t] = s_out[BLK_SS];
   } else {
