@@ -40,6 +40,7 @@ struct gto_handle {
   int32_t* h_ndone = nullptr;  // pinned
   int check_every = 8;
   int n_groups = 1;
+  int obs_tg = 1;  // waypoints per workgroup of the obstacle kernel (grouping measured slower: DESIGN.md section 7)
   long long* dbg = nullptr;
   hipStream_t gstream[GTO_MAX_GROUPS] = {nullptr};
   hipEvent_t ev_fork = nullptr, ev_join[GTO_MAX_GROUPS] = {nullptr};
@@ -145,6 +146,7 @@ int gto_create(const gto_robot_desc* d, const gto_solver_opts* opts, int device,
   h->opts = *opts;
   if (const char* e = getenv("GTO_GROUPS")) h->n_groups = std::max(1, std::min(GTO_MAX_GROUPS, atoi(e)));
   if (const char* e = getenv("GTO_CHECK_EVERY")) h->check_every = atoi(e);
+  if (const char* e = getenv("GTO_OBS_TG")) h->obs_tg = std::max(1, std::min(GTO_MAX_TG, atoi(e)));
   if (getenv("GTO_DEBUG_TIMING")) { (void)hipMalloc((void**)&h->dbg, 32 * sizeof(long long)); (void)hipMemset(h->dbg, 0, 32 * sizeof(long long)); }
   RobotDev& rb = h->rb;
   memset(&rb, 0, sizeof rb);
@@ -305,6 +307,15 @@ int gto_create(const gto_robot_desc* d, const gto_solver_opts* opts, int device,
   if (!ok) { gto_destroy(h); return fail(nullptr, GTO_ERR_ALLOC, "device allocation failed in gto_create"); }
   h->lm_lds = lm_lds_bytes(opts->T);
   if (h->lm_lds > 160 * 1024) { gto_destroy(h); return fail(nullptr, GTO_ERR_UNSUPPORTED, "T too large for the step kernel's LDS"); }
+  {
+    const ObsLds lay(GTO_MAX_TG, rb.n_frames, rb.n_links, GTO_MAX_TG * rb.n_chunks);
+    const size_t lds = (size_t)lay.total_doubles * sizeof(double);
+    if (lds > 150 * 1024) { gto_destroy(h); return fail(nullptr, GTO_ERR_UNSUPPORTED, "robot too large for the obstacle kernel's LDS"); }
+    if (hipFuncSetAttribute((const void*)k_obstacle_gram, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      gto_destroy(h);
+      return fail(nullptr, GTO_ERR_HIP, "hipFuncSetAttribute(k_obstacle_gram) failed");
+    }
+  }
   if (hipFuncSetAttribute((const void*)k_lm_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lm_lds) != hipSuccess) {
     gto_destroy(h);
     return fail(nullptr, GTO_ERR_HIP, "hipFuncSetAttribute(k_lm_step) failed");
@@ -555,7 +566,7 @@ static BatchPtrs make_ptrs(gto_handle* h, const int32_t* scene_id, const double*
   return bp;
 }
 
-static inline int obstacle_grid(int B, int nT) { return 8 * ((B + 7) / 8) * nT; }
+static inline int obstacle_grid(int B, int nG) { return 8 * ((B + 7) / 8) * nG; }
 
 static int launch_obstacle(gto_handle* h, hipStream_t st, const BatchPtrs& bp, const SolveParams& sp, int B, int t_begin,
                            int nT, int fixed_mode, bool timed, bool with_goal_terms = false) {
@@ -571,9 +582,15 @@ static int launch_obstacle(gto_handle* h, hipStream_t st, const BatchPtrs& bp, c
     e1 = h->ev[2 * h->last_launches + 1];
     HIPCHK(h, hipEventRecord(e0, st));
   }
-  const int n_regular = obstacle_grid(B, nT);
-  hipLaunchKernelGGL(k_obstacle_gram, dim3(n_regular + (with_goal_terms ? B : 0)), dim3(256), 0, st, h->d_rb, h->d_px, h->d_py,
-                     h->d_pz, h->d_chunks, h->d_scenes, bp, sp, B, t_begin, nT, fixed_mode, n_regular);
+  // waypoints per workgroup: groups of h->obs_tg (the two pinned waypoints form one group)
+  const int TG = std::max(1, std::min(h->obs_tg, nT));
+  const int nG = (nT + TG - 1) / TG;
+  const int n_regular = obstacle_grid(B, nG);
+  const int cap_active = TG * h->rb.n_chunks;
+  const ObsLds lay(TG, h->rb.n_frames, h->rb.n_links, cap_active);
+  const size_t lds = (size_t)lay.total_doubles * sizeof(double);
+  hipLaunchKernelGGL(k_obstacle_gram, dim3(n_regular + (with_goal_terms ? B : 0)), dim3(256), lds, st, h->d_rb, h->d_px, h->d_py,
+                     h->d_pz, h->d_chunks, h->d_scenes, bp, sp, B, t_begin, nT, fixed_mode, n_regular, TG, cap_active);
   if (timed) {
     HIPCHK(h, hipEventRecord(e1, st));
     h->last_launches++;

@@ -17,6 +17,12 @@
 #define BLK_JTR 64
 #define BLK_SS 72
 #define BLK_STRIDE 80  // doubles per (instance, waypoint) block: 8x8 J^T J, 8 J^T r, sum c^2, pad
+#define GTO_MAX_ACTIVE 256   // chunks per robot (16 K surface points)
+#define GTO_MAX_TG 8         // waypoints per workgroup of the obstacle kernel
+#define GTO_MAX_T 64         // waypoints the step kernel's register-resident phases are unrolled for
+#ifndef GTO_LIST_CAP
+#define GTO_LIST_CAP 80      // wrench-list entries (8 doubles) per wave: a full chunk (64) fits after a drain
+#endif
 
 struct InstState {
   double f, lambda, nu, pred;
@@ -439,16 +445,33 @@ __global__ void k_dist_relax(const uint8_t* __restrict__ in, uint8_t* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------
-// Dominant kernel.  grid.x = 8 * ceil(B/8) * nT  (XCD-aware: all waypoints of one instance, hence all
-// gathers into one scene's field, are issued from the same XCD and share its 4 MiB L2).
-// t_begin/nT select the waypoint range (the two pinned waypoints are evaluated once at init).
-//   prologue  forward kinematics of this (instance, waypoint) by the workgroup itself -> visual
-//             transforms of the collision links and joint screws staged in LDS
-//   main loop one link-uniform chunk of 64 Morton-sorted surface points per wave step
-//   epilogue  per-link 6x6 wrench Grams -> J^T J (n x n), J^T r (n), sum c^2
-#define GTO_MAX_ACTIVE 256   // chunks per robot the broad phase can list (16 K surface points)
-#define GTO_MAX_T 64       // waypoints the step kernel's register-resident phases are unrolled for
-#define GTO_LIST_CAP 80  // entries of 8 doubles per wave: a full chunk (64) always fits after a drain
+// Dominant kernel.  One workgroup per (instance, group of TG consecutive waypoints):
+//   grid.x = 8 * ceil(B/8) * ceil(nT/TG) (+ B goal workgroups);  b == blockIdx (mod 8), so all waypoints
+//   of one instance (hence all gathers into one scene's field) are issued from one XCD and share its L2.
+//   prologue  configuration -> forward kinematics of the TG waypoints IN PARALLEL inside the workgroup
+//             (local transforms, then pointer jumping over the kinematic tree) -> visual transforms of the
+//             collision links and joint screws staged in LDS.  Grouping waypoints amortises the latency
+//             of this serial-ish part over TG times more surface-point work.
+//   broad     one thread per (waypoint, chunk): bounding sphere vs Chebyshev distance field -> compacted
+//             list of chunks that can touch a non-zero voxel
+//   main loop one link-uniform chunk of 64 Morton-sorted surface points per wave step (sparse wrench lists)
+//   epilogue  per-link 6x6 wrench Grams -> J^T J (n x n), J^T r (n), sum c^2 per waypoint
+struct ObsLds {  // dynamic LDS layout (offsets in doubles), computed identically on host and device
+  int q, fr, vis, screw, gram, out, list, active, total_doubles;
+  __host__ __device__ ObsLds(int TG, int F, int L, int cap_active) {
+    int o = 0;
+    q = o;      o += TG * GTO_MAX_DOF;
+    fr = o;     o += TG * F * 12;
+    vis = o;    o += TG * L * 12;
+    screw = o;  o += TG * GTO_MAX_OPT * 6;
+    gram = o;   o += TG * L * GTO_GRAM;
+    out = o;    o += TG * BLK_STRIDE;
+    list = o;   o += 4 * GTO_LIST_CAP * 8 > TG * F * 12 ? 4 * GTO_LIST_CAP * 8 : TG * F * 12;  // also FK pong buffer / s_u
+    active = o; o += cap_active * 2;  // int4 per entry
+    total_doubles = o;
+  }
+};
+
 struct InstState;
 __device__ inline void trial_goal_terms_wave(const RobotDev* rb, const BatchPtrs& bp, const SolveParams& sp, int B,
                                              int b, int lane, int trial, InstState* st, double* s_q, double* s_fr,
@@ -461,166 +484,134 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
                                                        const double* __restrict__ py, const double* __restrict__ pz,
                                                        const Chunk* __restrict__ chunks, const SceneDev* __restrict__ scenes,
                                                        BatchPtrs bp, SolveParams sp, int B, int t_begin, int nT,
-                                                       int fixed_mode, int n_regular) {
-  // blockIdx -> (instance, waypoint), bijective, with b % 8 == blockIdx % 8
-  const int bid = blockIdx.x;
-  const int xcd = bid & 7, k = bid >> 3;
-  const int b = (k / nT) * 8 + xcd;
-  const int t = t_begin + (k % nT);
-  const bool goal_wg = bid >= n_regular;
-  if (!goal_wg && b >= B) return;
-  const InstState* st = bp.state + (goal_wg ? 0 : b);
-  if (!goal_wg && st->done) return;
-
-  __shared__ double s_q[GTO_MAX_DOF];
-  __shared__ double s_fr[GTO_MAX_FRAMES * 12];
-  __shared__ double s_vis[GTO_MAX_LINKS * 12];
-  __shared__ double s_screw[GTO_MAX_OPT * 6];
-  __shared__ double s_gram[GTO_MAX_LINKS * GTO_GRAM];
-  __shared__ double s_list[4 * GTO_LIST_CAP * 8];  // per-wave wrench lists; reused as s_u in the epilogue
-  __shared__ int4 s_active[GTO_MAX_ACTIVE];  // broad phase: {link, start, count, id} of chunks that may touch a non-zero voxel
+                                                       int fixed_mode, int n_regular, int TG, int cap_active) {
+  extern __shared__ __attribute__((aligned(16))) double smem_obs[];
+  __shared__ int s_parent[GTO_MAX_FRAMES], s_parentB[GTO_MAX_FRAMES];
   __shared__ int s_wcount[4];
   __shared__ int s_nactive;
-  __shared__ unsigned s_touched;  // links whose Gram received a contribution
-  __shared__ int s_parent[GTO_MAX_FRAMES], s_parentB[GTO_MAX_FRAMES];
-  __shared__ double s_out[BLK_STRIDE];
-  double* s_u = s_list;  // [L][GTO_MAX_OPT][6] <= 1536 doubles
-  double* s_frB = s_list;  // FK ping-pong buffer (prologue only)
+  __shared__ unsigned s_touched[GTO_MAX_TG];  // per waypoint of the group: links whose Gram got a contribution
+
+  const int bid = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int L = rb->n_links, n = rb->n_opt, T = sp.T, ndof = rb->ndof, F = rb->n_frames;
+  const ObsLds lay(TG, F, L, cap_active);
+  double* s_q = smem_obs + lay.q;
+  double* s_fr = smem_obs + lay.fr;
+  double* s_vis = smem_obs + lay.vis;
+  double* s_screw = smem_obs + lay.screw;
+  double* s_gram = smem_obs + lay.gram;
+  double* s_out = smem_obs + lay.out;
+  double* s_list = smem_obs + lay.list;
+  int4* s_active = reinterpret_cast<int4*>(smem_obs + lay.active);
+  double* s_u = s_list;    // [L][GTO_MAX_OPT][6] in the epilogue
+  double* s_frB = s_list;  // FK ping-pong buffer in the prologue
 
   // Extra workgroups (blockIdx >= n_regular), one per instance: goal-set terms and velocity term of the
   // trial trajectory.  The step kernel only needs them at its NEXT launch, so they ride in the shadow
   // of the obstacle evaluation instead of sitting on the serial path between two launches.
-  if (goal_wg) {
+  if (bid >= n_regular) {
     const int bg = bid - n_regular;
     if (bg >= B || bp.state[bg].done) return;
-    if (threadIdx.x < 64) {
-      double* s_fr2 = s_list;                       // [2][GTO_MAX_FRAMES*12]
+    if (tid < 64) {
+      double* s_fr2 = s_list;                          // [2][GTO_MAX_FRAMES*12] (list region is >= 2560 doubles)
       double* s_q2 = s_fr2 + 2 * GTO_MAX_FRAMES * 12;  // [2][GTO_MAX_DOF]
-      double* s_ga = s_q2 + 2 * GTO_MAX_DOF;        // [48]
-      double* s_gs = s_ga + 48;                     // [2][GTO_MAX_OPT*6]
-      trial_goal_terms_wave(rb, bp, sp, B, bg, threadIdx.x, 1 - bp.state[bg].slot, bp.state + bg, s_q2, s_fr2, s_ga, s_gs);
+      double* s_ga = s_q2 + 2 * GTO_MAX_DOF;           // [48]
+      double* s_gs = s_ga + 48;                        // [2][GTO_MAX_OPT*6]
+      trial_goal_terms_wave(rb, bp, sp, B, bg, tid, 1 - bp.state[bg].slot, bp.state + bg, s_q2, s_fr2, s_ga, s_gs);
     }
     return;
   }
+  // blockIdx -> (instance, waypoint group), bijective, with b % 8 == blockIdx % 8
+  const int nG = (nT + TG - 1) / TG;
+  const int xcd = bid & 7, kb = bid >> 3;
+  const int b = (kb / nG) * 8 + xcd;
+  const int grp_id = kb % nG;
+  if (b >= B) return;
+  const InstState* st = bp.state + b;
+  if (st->done) return;
+  const int t0w = t_begin + grp_id * TG;                 // first waypoint of this group
+  const int ng = min(TG, t_begin + nT - t0w);            // waypoints in this group
+  const bool dbg_wg = bp.dbg && b == 0 && grp_id == nG - 1;
+  if (dbg_wg && tid == 0) bp.dbg[10] = clock64();
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int L = rb->n_links, n = rb->n_opt, T = sp.T, ndof = rb->ndof;
-
-  if (bp.dbg && b == 0 && t == sp.T - 1 && tid == 0) bp.dbg[10] = clock64();
-  // ---- prologue: q_t (parameter rows from Q0, optimised rows from the trial), FK, visual tf, screws.
-  // Every global load the prologue needs (configuration, per-frame and per-link constants) is issued
-  // up front so the workgroup pays ONE memory round trip before the LDS-only chain.
-  double qv = 0.0;
-  int qdst = -1;
-  if (tid < ndof) {
-    qv = bp.Q0[((size_t)b * ndof + tid) * T + t];
-    qdst = tid;
-  } else if (tid >= 64 && tid < 64 + n) {
-    qv = bp.Qtry[((size_t)b * n + (tid - 64)) * T + t];
-    qdst = rb->opt_index[tid - 64];
+  // ---- prologue.  Every global load it needs is issued up front: ONE memory round trip.
+  for (int idx = tid; idx < ng * ndof; idx += 256) {
+    const int kq = idx / ndof, i = idx % ndof, j = rb->opt_of_dof[i];
+    s_q[kq * GTO_MAX_DOF + i] = (j >= 0) ? bp.Qtry[((size_t)b * n + j) * T + t0w + kq]
+                                         : bp.Q0[((size_t)b * ndof + i) * T + t0w + kq];
   }
-  const int F = rb->n_frames;
-  int f_jt = 0, f_qi = 0;
-  double fO[12], fax[3] = {0, 0, 0};
-  if (tid < F) {
-    s_parent[tid] = rb->parent[tid];
-    f_jt = rb->joint_type[tid];
-    f_qi = rb->q_index[tid];
-#pragma unroll
-    for (int k2 = 0; k2 < 12; ++k2) fO[k2] = rb->origin[tid][k2];
-#pragma unroll
-    for (int k2 = 0; k2 < 3; ++k2) fax[k2] = rb->axis_unit[tid][k2];
-  }
-  // visual-transform role: thread (l, e) for l < L, e < 12
-  const int v_l = tid / 12, v_e = tid % 12, v_r = v_e >> 2, v_c = v_e & 3;
-  int v_frame = 0;
-  double vo0 = 0.0, vo1 = 0.0, vo2 = 0.0;
-  if (tid < L * 12) {
-    v_frame = rb->link_frame[v_l];
-    vo0 = rb->vis_origin[v_l][v_c];
-    vo1 = rb->vis_origin[v_l][4 + v_c];
-    vo2 = rb->vis_origin[v_l][8 + v_c];
-  }
-  // screw role: threads 192 .. 192+F
-  const int sc_i = tid - 192;
-  int sc_j = -1, sc_jt = 0;
-  double sax[3] = {0, 0, 0};
-  if (sc_i >= 0 && sc_i < F) {
-    sc_j = rb->opt_of_frame[sc_i];
-    sc_jt = rb->joint_type[sc_i];
-#pragma unroll
-    for (int k2 = 0; k2 < 3; ++k2) sax[k2] = rb->axis_unit[sc_i][k2];
-  }
-  for (int i = tid; i < L * GTO_GRAM; i += 256) s_gram[i] = 0.0;
-  if (tid < BLK_STRIDE) s_out[tid] = 0.0;
-  if (tid == 0) s_touched = 0u;
-  if (tid < ndof) s_q[qdst] = qv;
+  if (tid < F) s_parent[tid] = rb->parent[tid];
+  for (int i = tid; i < ng * L * GTO_GRAM; i += 256) s_gram[i] = 0.0;
+  for (int i = tid; i < ng * BLK_STRIDE; i += 256) s_out[i] = 0.0;
+  if (tid < GTO_MAX_TG) s_touched[tid] = 0u;
+  if (tid == 0) s_nactive = 0;
   __syncthreads();
-  if (tid >= 64 && qdst >= 0) s_q[qdst] = qv;  // optimised rows override
-  __syncthreads();
-  if (bp.dbg && b == 0 && t == sp.T - 1 && tid == 0) bp.dbg[16] = clock64();
-  if (tid < F) {  // local transform L_i = origin_i @ joint_motion_i(q)
-    double* Lo = s_fr + 12 * tid;
-    if (f_jt == GTO_JOINT_REVOLUTE) {
+  if (dbg_wg && tid == 0) bp.dbg[16] = clock64();
+  // local transforms L_i = origin_i @ joint_motion_i(q) for every (waypoint, frame)
+  for (int idx = tid; idx < ng * F; idx += 256) {
+    const int kq = idx / F, i = idx % F;
+    const int jt = rb->joint_type[i];
+    const double* O = rb->origin[i];
+    double* Lo = s_fr + (kq * F + i) * 12;
+    if (jt == GTO_JOINT_REVOLUTE) {
       // Rodrigues about the unit axis u: R = cos*I + sin*[u]x + (1-cos) u u^T (optas/spatialmath.py:90-100)
-      const double th = s_q[f_qi];
+      const double th = s_q[kq * GTO_MAX_DOF + rb->q_index[i]];
       double sn, cs;
       sincos(th, &sn, &cs);
-      const double c1 = 1.0 - cs, u0 = fax[0], u1 = fax[1], u2 = fax[2];
+      const double c1 = 1.0 - cs, u0 = rb->axis_unit[i][0], u1 = rb->axis_unit[i][1], u2 = rb->axis_unit[i][2];
       const double R00 = cs + c1 * u0 * u0, R01 = c1 * u0 * u1 - sn * u2, R02 = c1 * u0 * u2 + sn * u1;
       const double R10 = c1 * u1 * u0 + sn * u2, R11 = cs + c1 * u1 * u1, R12 = c1 * u1 * u2 - sn * u0;
       const double R20 = c1 * u2 * u0 - sn * u1, R21 = c1 * u2 * u1 + sn * u0, R22 = cs + c1 * u2 * u2;
 #pragma unroll
       for (int r = 0; r < 3; ++r) {
-        const double o0 = fO[4 * r], o1 = fO[4 * r + 1], o2 = fO[4 * r + 2];
+        const double o0 = O[4 * r], o1 = O[4 * r + 1], o2 = O[4 * r + 2];
         Lo[4 * r] = o0 * R00 + o1 * R10 + o2 * R20;
         Lo[4 * r + 1] = o0 * R01 + o1 * R11 + o2 * R21;
         Lo[4 * r + 2] = o0 * R02 + o1 * R12 + o2 * R22;
-        Lo[4 * r + 3] = fO[4 * r + 3];
+        Lo[4 * r + 3] = O[4 * r + 3];
       }
-    } else if (f_jt == GTO_JOINT_PRISMATIC) {
-      const double qi = s_q[f_qi];
-      const double t0 = qi * fax[0], t1 = qi * fax[1], t2 = qi * fax[2];
+    } else if (jt == GTO_JOINT_PRISMATIC) {
+      const double qi = s_q[kq * GTO_MAX_DOF + rb->q_index[i]];
+      const double t0 = qi * rb->axis_unit[i][0], t1 = qi * rb->axis_unit[i][1], t2 = qi * rb->axis_unit[i][2];
 #pragma unroll
       for (int r = 0; r < 3; ++r) {
-        const double o0 = fO[4 * r], o1 = fO[4 * r + 1], o2 = fO[4 * r + 2];
+        const double o0 = O[4 * r], o1 = O[4 * r + 1], o2 = O[4 * r + 2];
         Lo[4 * r] = o0;
         Lo[4 * r + 1] = o1;
         Lo[4 * r + 2] = o2;
-        Lo[4 * r + 3] = o0 * t0 + o1 * t1 + o2 * t2 + fO[4 * r + 3];
+        Lo[4 * r + 3] = o0 * t0 + o1 * t1 + o2 * t2 + O[4 * r + 3];
       }
     } else {
 #pragma unroll
-      for (int k2 = 0; k2 < 12; ++k2) Lo[k2] = fO[k2];
+      for (int k2 = 0; k2 < 12; ++k2) Lo[k2] = O[k2];
     }
   }
   __syncthreads();
-  if (bp.dbg && b == 0 && t == sp.T - 1 && tid == 0) bp.dbg[17] = clock64();
+  if (dbg_wg && tid == 0) bp.dbg[17] = clock64();
   // global transforms by pointer jumping over the kinematic tree (parallel prefix of the chain
   // products): every round replaces M_i by M_anc(i) @ M_i and anc(i) by anc(anc(i)); after
-  // ceil(log2(depth)) rounds M_i is the global transform of frame i.  All F*12 matrix elements are
-  // computed in parallel each round, so the latency is ~4 LDS round trips instead of one per frame.
+  // ceil(log2(depth)) rounds M_i is the global transform of frame i (all waypoints at once).
   {
-    double* Ma = s_fr;    // ping
-    double* Mb = s_frB;   // pong
+    double* Ma = s_fr;
+    double* Mb = s_frB;
     int* Aa = s_parent;
     int* Ab = s_parentB;
+    const int FE = F * 12;
     for (int rd = 0; rd < rb->fk_rounds; ++rd) {
-      for (int idx = tid; idx < F * 12; idx += 256) {
-        const int i = idx / 12, e = idx % 12, rr = e >> 2, cc = e & 3;
+      for (int idx = tid; idx < ng * FE; idx += 256) {
+        const int kq = idx / FE, rem = idx % FE, i = rem / 12, e = rem % 12, rr = e >> 2, cc = e & 3;
         const int a = Aa[i];
+        const double* Mk = Ma + kq * FE;
         double v;
         if (a >= 0) {
-          const double* P = Ma + 12 * a + 4 * rr;
-          const double* Lm = Ma + 12 * i;
+          const double* P = Mk + 12 * a + 4 * rr;
+          const double* Lm = Mk + 12 * i;
           v = P[0] * Lm[cc] + P[1] * Lm[4 + cc] + P[2] * Lm[8 + cc];
           if (cc == 3) v += P[3];
-          if (e == 0) Ab[i] = Aa[a];
         } else {
-          v = Ma[idx];
-          if (e == 0) Ab[i] = -1;
+          v = Mk[rem];
         }
         Mb[idx] = v;
+        if (kq == 0 && e == 0) Ab[i] = (a >= 0) ? Aa[a] : -1;
       }
       __syncthreads();
       double* tM = Ma;
@@ -631,76 +622,59 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
       Ab = tA;
     }
     if (Ma != s_fr) {  // odd number of rounds: results live in the pong buffer
-      for (int idx = tid; idx < F * 12; idx += 256) s_fr[idx] = Ma[idx];
+      for (int idx = tid; idx < ng * FE; idx += 256) s_fr[idx] = Ma[idx];
       __syncthreads();
     }
   }
-  if (bp.dbg && b == 0 && t == sp.T - 1 && tid == 0) bp.dbg[18] = clock64();
-  if (tid < L * 12) {  // visual_tf = link_tf @ visual origin (gto/gto_models.py:92-100)
-    const double* Fr = s_fr + 12 * v_frame + 4 * v_r;
-    double v = Fr[0] * vo0 + Fr[1] * vo1 + Fr[2] * vo2;
-    if (v_c == 3) v += Fr[3];
-    s_vis[tid] = v;
+  if (dbg_wg && tid == 0) bp.dbg[18] = clock64();
+  // visual_tf = link_tf @ visual origin (gto/gto_models.py:92-100)
+  for (int idx = tid; idx < ng * L * 12; idx += 256) {
+    const int kq = idx / (L * 12), rem = idx % (L * 12), l = rem / 12, e = rem % 12, r = e >> 2, c = e & 3;
+    const double* Fr = s_fr + (kq * F + rb->link_frame[l]) * 12 + 4 * r;
+    const double* Vo = rb->vis_origin[l];
+    double v = Fr[0] * Vo[c] + Fr[1] * Vo[4 + c] + Fr[2] * Vo[8 + c];
+    if (c == 3) v += Fr[3];
+    s_vis[idx] = v;
   }
-  if (sc_j >= 0) {  // world screw (a ; o x a) of the optimised joint carried by frame sc_i
-    const double* Fm = s_fr + 12 * sc_i;
-    double a[3], o[3];
-#pragma unroll
-    for (int r2 = 0; r2 < 3; ++r2) {
-      a[r2] = Fm[4 * r2] * sax[0] + Fm[4 * r2 + 1] * sax[1] + Fm[4 * r2 + 2] * sax[2];
-      o[r2] = Fm[4 * r2 + 3];
-    }
-    double* sw = s_screw + 6 * sc_j;
-    if (sc_jt == GTO_JOINT_PRISMATIC) {
-      sw[0] = sw[1] = sw[2] = 0.0;
-      sw[3] = a[0];
-      sw[4] = a[1];
-      sw[5] = a[2];
-    } else {
-      sw[0] = a[0];
-      sw[1] = a[1];
-      sw[2] = a[2];
-      sw[3] = o[1] * a[2] - o[2] * a[1];
-      sw[4] = o[2] * a[0] - o[0] * a[2];
-      sw[5] = o[0] * a[1] - o[1] * a[0];
-    }
+  // world screws (a ; o x a) of the optimised joints
+  for (int idx = tid; idx < ng * F; idx += 256) {
+    const int kq = idx / F, i = idx % F, j = rb->opt_of_frame[i];
+    if (j >= 0) screw_of_frame(rb, i, s_fr + (kq * F + i) * 12, s_screw + (kq * GTO_MAX_OPT + j) * 6);
   }
   __syncthreads();
+  if (dbg_wg && tid == 0) bp.dbg[11] = clock64();
 
   const SceneDev sc = scenes[bp.scene_id[b]];
-  const float* __restrict__ field = (t < sp.ts) ? sc.c_all : sc.c_obs;  // gto/gto_planner.py:117-131
-  const VoxelRec* __restrict__ rec = (t < sp.ts) ? sc.r_all : sc.r_obs;
   const double bx = bp.base_pos[3 * b], by = bp.base_pos[3 * b + 1], bz = bp.base_pos[3 * b + 2];
   const double cx = (bx - sc.ox) * sc.rinv, cy = (by - sc.oy) * sc.rinv, cz = (bz - sc.oz) * sc.rinv;
   const bool need_grad = !fixed_mode && sp.grad_mode == GTO_GRAD_CENTRAL_DIFF;
   const int nz = sc.nz;
 
-  if (bp.dbg && b == 0 && t == sp.T - 1 && tid == 0) bp.dbg[11] = clock64();
-  // ---- broad phase: one thread per chunk transforms the chunk's bounding-sphere centre and looks up
-  // the Chebyshev distance to the nearest non-zero voxel; a chunk whose sphere (radius R voxels, +1
-  // for the floor of the centre) cannot reach one contributes exact zeros and is skipped.  The list
-  // of surviving chunks keeps the link order (ballot prefix), so a wave still sees few link changes.
+  // ---- broad phase: one thread per (waypoint, chunk) transforms the chunk's bounding-sphere centre and
+  // looks up the Chebyshev distance to the nearest non-zero voxel; a chunk whose sphere (radius R voxels,
+  // +2 for the floor of the centre and index rounding) cannot reach one contributes exact zeros and is
+  // skipped.  Survivors keep (waypoint, link) order (ballot prefix): a wave still sees few key changes.
   const int C = rb->n_chunks;
-  const uint8_t* __restrict__ dist = (t < sp.ts) ? sc.d_all : sc.d_obs;
-  if (tid == 0) s_nactive = 0;
-  __syncthreads();
-  for (int base_c = 0; base_c < C; base_c += 256) {
-    const int ci = base_c + tid;
+  for (int base_c = 0; base_c < ng * C; base_c += 256) {
+    const int gi = base_c + tid;
     bool keep = false;
     int4 desc4 = make_int4(0, 0, 0, 0);
-    if (ci < C) {
+    if (gi < ng * C) {
+      const int kq = gi / C, ci = gi % C;
       const Chunk cc = chunks[ci];
-      desc4 = make_int4(cc.link, cc.start, cc.count, ci);
-      const double* V = s_vis + 12 * cc.link;
+      desc4 = make_int4(cc.link | (kq << 16), cc.start, cc.count, ci);
+      const double* V = s_vis + (kq * L + cc.link) * 12;
       const double u0 = (V[0] * cc.cx + V[1] * cc.cy + V[2] * cc.cz + V[3] + bx - sc.ox) * sc.rinv;
       const double u1 = (V[4] * cc.cx + V[5] * cc.cy + V[6] * cc.cz + V[7] + by - sc.oy) * sc.rinv;
       const double u2 = (V[8] * cc.cx + V[9] * cc.cy + V[10] * cc.cz + V[11] + bz - sc.oz) * sc.rinv;
-      const int R = (int)ceil(cc.r * sc.rinv) + 2;  // sphere radius in voxels, + centre floor + index rounding
+      const int R = (int)ceil(cc.r * sc.rinv) + 2;
       const int k0 = (int)floor(u0), k1 = (int)floor(u1), k2 = (int)floor(u2);
       keep = true;
       // only spheres that lie inside the grid (no clipped indices) and are closer than the cap can be culled
-      if (R < GTO_DIST_CAP && k0 - R >= 0 && k1 - R >= 0 && k2 - R >= 0 && k0 + R < sc.nx && k1 + R < sc.ny && k2 + R < sc.nz)
+      if (R < GTO_DIST_CAP && k0 - R >= 0 && k1 - R >= 0 && k2 - R >= 0 && k0 + R < sc.nx && k1 + R < sc.ny && k2 + R < sc.nz) {
+        const uint8_t* __restrict__ dist = (t0w + kq < sp.ts) ? sc.d_all : sc.d_obs;
         keep = (int)dist[k2 + nz * (k1 + sc.ny * k0)] <= R;
+      }
     }
     const unsigned long long bm = __ballot(keep);
     if (lane == 0) s_wcount[wave] = __popcll(bm);
@@ -709,17 +683,17 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
     for (int w = 0; w < wave; ++w) woff += s_wcount[w];
     if (keep) {
       const int pos = woff + __popcll(bm & ((1ull << lane) - 1ull));
-      if (pos < GTO_MAX_ACTIVE) s_active[pos] = desc4;
+      if (pos < cap_active) s_active[pos] = desc4;
     }
     __syncthreads();
-    if (tid == 0) s_nactive = min(s_nactive + s_wcount[0] + s_wcount[1] + s_wcount[2] + s_wcount[3], GTO_MAX_ACTIVE);
+    if (tid == 0) s_nactive = min(s_nactive + s_wcount[0] + s_wcount[1] + s_wcount[2] + s_wcount[3], cap_active);
     __syncthreads();
   }
   const int NA = s_nactive;
   // contiguous range of surviving chunks per wave
   const int c0 = (int)(((long)NA * wave) / 4), c1 = (int)(((long)NA * (wave + 1)) / 4);
+  if (dbg_wg && tid == 0) bp.dbg[12] = clock64();
 
-  if (bp.dbg && b == 0 && t == sp.T - 1 && tid == 0) bp.dbg[12] = clock64();
   // Sparse Gram accumulation.  Most surface points are in free space (zero gradient): a lane whose
   // point has a non-zero gradient appends its wrench (y x w, w) and cost c to a small per-wave LDS
   // list; the list is folded into the per-link 6x6 Gram by the wave with ONE accumulator per lane
@@ -746,9 +720,9 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
       oj = kk - 21;
     }
   }
-  double gacc = 0.0;  // this lane's Gram entry of the current link
-  double ss = 0.0;    // sum of c^2 over this lane's points (all links)
-  int cnt = 0, cur_link = -1;
+  double gacc = 0.0;  // this lane's Gram entry of the current (waypoint, link)
+  double ss = 0.0;    // sum of c^2 over this lane's points of the current waypoint
+  int cnt = 0, cur_key = -1;
 
 #define GTO_DRAIN()                                                                          \
   do {                                                                                       \
@@ -759,20 +733,27 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
     __builtin_amdgcn_wave_barrier();                                                         \
     cnt = 0;                                                                                 \
   } while (0)
-#define GTO_FLUSH(link)                                                                      \
+  // key = link | waypoint << 16
+#define GTO_FLUSH(key)                                                                       \
   do {                                                                                       \
     if (cnt) GTO_DRAIN();                                                                    \
+    const int fk_ = (key) >> 16, fl_ = (key)&0xffff;                                         \
     if (grp >= 0 && kk < 27 && gacc != 0.0) {                                                \
-      atomicAdd(&s_gram[(link)*GTO_GRAM + kk], gacc);                                        \
-      atomicOr(&s_touched, 1u << (link));                                                    \
+      atomicAdd(&s_gram[(fk_ * L + fl_) * GTO_GRAM + kk], gacc);                             \
+      atomicOr(&s_touched[fk_], 1u << fl_);                                                  \
     }                                                                                        \
     gacc = 0.0;                                                                              \
+    if ((cur_key >> 16) != fk_ || true) {                                                    \
+      const double sw_ = wave_sum(ss);                                                       \
+      if (lane == 0 && sw_ != 0.0) atomicAdd(&s_out[fk_ * BLK_STRIDE + BLK_SS], sw_);        \
+      ss = 0.0;                                                                              \
+    }                                                                                        \
   } while (0)
 
-  // software prefetch: the next chunk's descriptor and point coordinates are requested before the
-  // current chunk is processed, so two memory round trips (points, voxel records) overlap
+  // software prefetch: the next chunk's point coordinates are requested before the current chunk is
+  // processed, so two memory round trips (points, voxel records) overlap
   struct ChunkLite {
-    int link, start, count;
+    int key, start, count;
   };
   ChunkLite ch = {0, 0, 0};
   double x0 = 0.0, x1 = 0.0, x2 = 0.0;
@@ -798,14 +779,16 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
         n2 = pz[nch.start + lane];
       }
     }
-    if (ch.link != cur_link) {
-      if (cur_link >= 0) GTO_FLUSH(cur_link);
-      cur_link = ch.link;
+    if (ch.key != cur_key) {
+      if (cur_key >= 0) GTO_FLUSH(cur_key);
+      cur_key = ch.key;
     }
     {
       // lanes past the end of the chunk carry x = 0 and have their cost and gradient zeroed
       const bool valid = lane < ch.count;
-      const double* V = s_vis + 12 * ch.link;
+      const int kq = ch.key >> 16, link = ch.key & 0xffff;
+      const bool pre = (t0w + kq) < sp.ts;  // gto/gto_planner.py:117-131: c_all before the standoff waypoint
+      const double* V = s_vis + (kq * L + link) * 12;
       // point in the robot-base frame (gto/gto_planner.py:114-116); the field frame adds base_position
       const double y0 = V[0] * x0 + V[1] * x1 + V[2] * x2 + V[3];
       const double y1 = V[4] * x0 + V[5] * x1 + V[6] * x2 + V[7];
@@ -815,11 +798,13 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
       const int iz = voxel_axis_fast(y2, cz, bz, sc.oz, sc.res, sc.rinv, sc.nz);
       const int off = iz + nz * (iy + sc.ny * ix);
       if (!need_grad) {
+        const float* __restrict__ field = pre ? sc.c_all : sc.c_obs;
         const double cval = valid ? (double)field[off] : 0.0;
         ss = fma(cval, cval, ss);
       } else {
         // one 32-B voxel record: cost + central differences (gto/sdf_callback.py:90-114); the divisor
         // stays 2*res also at clipped borders
+        const VoxelRec* __restrict__ rec = pre ? sc.r_all : sc.r_obs;
         const double4 lo4 = *reinterpret_cast<const double4*>(&rec[off]);  // two 16-B loads, one line
         const double cval = valid ? (double)__builtin_bit_cast(float, (unsigned)__double2loint(lo4.w)) : 0.0;
         ss = fma(cval, cval, ss);
@@ -850,74 +835,78 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
     x1 = n1;
     x2 = n2;
   }
-  if (cur_link >= 0) GTO_FLUSH(cur_link);
+  if (cur_key >= 0) GTO_FLUSH(cur_key);
 #undef GTO_FLUSH
 #undef GTO_DRAIN
-  if (bp.dbg && b == 0 && t == sp.T - 1 && tid == 0) bp.dbg[13] = clock64();
-  ss = wave_sum(ss);
-  if (lane == 0) atomicAdd(&s_out[BLK_SS], ss);
+  if (dbg_wg && tid == 0) bp.dbg[13] = clock64();
   __syncthreads();
 
   // projection of the per-link wrench Grams onto the joint screws, over the links that were touched:
   //   JtJ[i][j] = sum_l [i,j in anc(l)] s_i^T W_l s_j ,  Jtr[i] = sum_l [i in anc(l)] s_i . v_l
-  const unsigned touched = s_touched;
-  if (!fixed_mode && touched) {
-    for (int idx = tid; idx < L * n; idx += 256) {
-      const int l = idx / n, j = idx % n;
-      if (!((touched >> l) & 1u)) continue;
-      const double* W = s_gram + l * GTO_GRAM;
-      const double* sj = s_screw + 6 * j;
-      const bool on = (rb->link_anc[l] >> j) & 1u;
+  if (!fixed_mode) {
+    for (int kq = 0; kq < ng; ++kq) {
+      const unsigned touched = s_touched[kq];
+      if (!touched) continue;  // block-uniform
+      const double* gram = s_gram + kq * L * GTO_GRAM;
+      const double* screw = s_screw + kq * GTO_MAX_OPT * 6;
+      __syncthreads();  // s_u reuse between waypoints
+      for (int idx = tid; idx < L * n; idx += 256) {
+        const int l = idx / n, j = idx % n;
+        if (!((touched >> l) & 1u)) continue;
+        const double* W = gram + l * GTO_GRAM;
+        const double* sj = screw + 6 * j;
+        const bool on = (rb->link_anc[l] >> j) & 1u;
 #pragma unroll
-      for (int r = 0; r < 6; ++r) {
-        double u = 0.0;
-        if (on) {
+        for (int r = 0; r < 6; ++r) {
+          double u = 0.0;
+          if (on) {
 #pragma unroll
-          for (int c = 0; c < 6; ++c) u += W[sym6(r, c)] * sj[c];
-        }
-        s_u[(l * GTO_MAX_OPT + j) * 6 + r] = u;
-      }
-    }
-    __syncthreads();
-    // one thread per output entry, links summed in order (deterministic, no atomics)
-    if (tid < 64) {
-      const int i = tid >> 3, j = tid & 7;
-      double v = 0.0;
-      if (i < n && j < n) {
-        const double* si = s_screw + 6 * i;
-        for (int l = 0; l < L; ++l) {
-          const uint32_t anc = rb->link_anc[l];
-          if (((touched >> l) & 1u) && ((anc >> i) & 1u) && ((anc >> j) & 1u)) {
-            const double* u = s_u + (l * GTO_MAX_OPT + j) * 6;
-            v += si[0] * u[0] + si[1] * u[1] + si[2] * u[2] + si[3] * u[3] + si[4] * u[4] + si[5] * u[5];
+            for (int c = 0; c < 6; ++c) u += W[sym6(r, c)] * sj[c];
           }
+          s_u[(l * GTO_MAX_OPT + j) * 6 + r] = u;
         }
       }
-      s_out[BLK_JTJ + tid] = v;
-    } else if (tid < 72) {
-      const int i = tid - 64;
-      double v = 0.0;
-      if (i < n) {
-        const double* si = s_screw + 6 * i;
-        for (int l = 0; l < L; ++l)
-          if (((touched >> l) & 1u) && ((rb->link_anc[l] >> i) & 1u)) {
-            const double* vv = s_gram + l * GTO_GRAM + 21;
-            v += si[0] * vv[0] + si[1] * vv[1] + si[2] * vv[2] + si[3] * vv[3] + si[4] * vv[4] + si[5] * vv[5];
+      __syncthreads();
+      // one thread per output entry, links summed in order (deterministic, no atomics)
+      if (tid < 64) {
+        const int i = tid >> 3, j = tid & 7;
+        double v = 0.0;
+        if (i < n && j < n) {
+          const double* si = screw + 6 * i;
+          for (int l = 0; l < L; ++l) {
+            const uint32_t anc = rb->link_anc[l];
+            if (((touched >> l) & 1u) && ((anc >> i) & 1u) && ((anc >> j) & 1u)) {
+              const double* u = s_u + (l * GTO_MAX_OPT + j) * 6;
+              v += si[0] * u[0] + si[1] * u[1] + si[2] * u[2] + si[3] * u[3] + si[4] * u[4] + si[5] * u[5];
+            }
           }
+        }
+        s_out[kq * BLK_STRIDE + BLK_JTJ + tid] = v;
+      } else if (tid < 72) {
+        const int i = tid - 64;
+        double v = 0.0;
+        if (i < n) {
+          const double* si = screw + 6 * i;
+          for (int l = 0; l < L; ++l)
+            if (((touched >> l) & 1u) && ((rb->link_anc[l] >> i) & 1u)) {
+              const double* vv = gram + l * GTO_GRAM + 21;
+              v += si[0] * vv[0] + si[1] * vv[1] + si[2] * vv[2] + si[3] * vv[3] + si[4] * vv[4] + si[5] * vv[5];
+            }
+        }
+        s_out[kq * BLK_STRIDE + BLK_JTR + i] = v;
       }
-      s_out[BLK_JTR + i] = v;
     }
   }
   __syncthreads();
-  if (bp.dbg && b == 0 && t == sp.T - 1 && tid == 0) {
+  if (dbg_wg && tid == 0) {
     bp.dbg[14] = clock64();
     bp.dbg[15] = NA;
   }
   if (fixed_mode) {
-    if (tid == 0) bp.ss_fixed[2 * b + t] = s_out[BLK_SS];
+    if (tid < ng) bp.ss_fixed[2 * b + t0w + tid] = s_out[tid * BLK_STRIDE + BLK_SS];
   } else {
-    double* out = bp.blocks + (((size_t)(1 - st->slot) * B + b) * T + t) * BLK_STRIDE;
-    if (tid < BLK_STRIDE) out[tid] = s_out[tid];
+    double* out = bp.blocks + (((size_t)(1 - st->slot) * B + b) * T + t0w) * BLK_STRIDE;
+    for (int i = tid; i < ng * BLK_STRIDE; i += 256) out[i] = s_out[i];
   }
 }
 
