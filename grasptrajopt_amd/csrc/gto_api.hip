@@ -36,7 +36,7 @@ struct gto_handle {
   SceneDev* d_scenes = nullptr;
   size_t d_scenes_cap = 0;
   // solve workspace (grown on demand)
-  DevBuf state, Qcur, Qtry, vis, screw, blocks, goalblk, ssfixed, ndone;
+  DevBuf state, Qcur, Qtry, vis, screw, blocks, goalblk, ssfixed, ndone, qref, margin;
   int32_t* h_ndone = nullptr;  // pinned
   int check_every = 8;
   int n_groups = 1;
@@ -226,6 +226,37 @@ int gto_create(const gto_robot_desc* d, const gto_solver_opts* opts, int device,
       for (int c = 0; c < 3; ++c) rb.grip_M[3 * r + c] += p[r] * p[c];
     }
   }
+  // reach[j]: conservative bound on the displacement of any surface point per unit motion of joint j:
+  // sum of the origin offsets along the chain below the joint (+ travel of prismatic joints below it)
+  // + visual-origin offset + farthest surface point of the link, maximised over the links it moves.
+  {
+    std::vector<double> maxpt(d->n_links, 0.0);
+    for (int i = 0; i < d->n_points; ++i) {
+      const double* p = d->points + 3 * i;
+      maxpt[d->point_link[i]] = std::max(maxpt[d->point_link[i]], std::sqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]));
+    }
+    for (int j = 0; j < d->n_opt; ++j) rb.reach[j] = 0.0;
+    bool ok = true;
+    for (int l = 0; l < d->n_links; ++l) {
+      const double* vx = d->visual_xyz + 3 * l;
+      double below = std::sqrt(vx[0] * vx[0] + vx[1] * vx[1] + vx[2] * vx[2]) + maxpt[l];  // offsets below the current frame
+      for (int f = d->link_frame[l]; f >= 0; f = d->parent[f]) {
+        const int j = rb.opt_of_frame[f];
+        if (j >= 0) rb.reach[j] = std::max(rb.reach[j], rb.joint_type[f] == GTO_JOINT_PRISMATIC ? 1.0 : below);
+        if (rb.joint_type[f] == GTO_JOINT_PRISMATIC) {
+          // travel of this joint moves everything below it further from the joints above
+          double travel = 1e9;
+          if (j >= 0) travel = std::max(std::fabs(rb.lower[j]), std::fabs(rb.upper[j]));
+          else travel = 2.0;  // parameter prismatic joints (torso lift, fingers): generous constant
+          if (!(travel < 1e3)) ok = false;
+          below += travel;
+        }
+        const double* ox = d->origin_xyz + 3 * f;
+        below += std::sqrt(ox[0] * ox[0] + ox[1] * ox[1] + ox[2] * ox[2]);
+      }
+    }
+    if (!ok) for (int j = 0; j < d->n_opt; ++j) rb.reach[j] = -1.0;
+  }
   // points sorted by link (stable), chunk table of <= 64 link-uniform points
   const int P = d->n_points;
   std::vector<int32_t> perm(P);
@@ -289,7 +320,7 @@ int gto_create(const gto_robot_desc* d, const gto_solver_opts* opts, int device,
       double dx = px[k] - cx, dy = py[k] - cy, dz = pz[k] - cz;
       r2 = std::max(r2, dx * dx + dy * dy + dz * dz);
     }
-    chunks.push_back(Chunk{l, i, j - i, 0, cx, cy, cz, std::sqrt(r2) * (1.0 + 1e-9) + 1e-12});
+    chunks.push_back(Chunk{l, i, j - i, rb.link_anc[l] == 0u ? 1 : 0, cx, cy, cz, std::sqrt(r2) * (1.0 + 1e-9) + 1e-12});
     i = j;
   }
   rb.n_chunks = (int)chunks.size();
@@ -346,7 +377,7 @@ void gto_destroy(gto_handle* h) {
   (void)hipFree(h->d_plink);
   (void)hipFree(h->d_perm);
   (void)hipFree(h->d_chunks);
-  DevBuf* bufs[] = {&h->state, &h->Qcur, &h->Qtry, &h->vis, &h->screw, &h->blocks, &h->goalblk, &h->ssfixed, &h->ndone};
+  DevBuf* bufs[] = {&h->state, &h->Qcur, &h->Qtry, &h->vis, &h->screw, &h->blocks, &h->goalblk, &h->ssfixed, &h->ndone, &h->qref, &h->margin};
   if (h->h_ndone) (void)hipHostFree(h->h_ndone);
   for (int g = 0; g < GTO_MAX_GROUPS; ++g) {
     if (h->gstream[g]) (void)hipStreamDestroy(h->gstream[g]);
@@ -539,8 +570,10 @@ static int ensure_workspace(gto_handle* h, int B) {
   if ((rc = ensure(h, h->Qtry, (size_t)B * n * T * sizeof(double)))) return rc;
   if ((rc = ensure(h, h->blocks, (size_t)2 * B * T * BLK_STRIDE * sizeof(double)))) return rc;
   if ((rc = ensure(h, h->goalblk, (size_t)2 * B * 2 * BLK_STRIDE * sizeof(double)))) return rc;
-  if ((rc = ensure(h, h->ssfixed, (size_t)B * 2 * sizeof(double)))) return rc;
+  if ((rc = ensure(h, h->ssfixed, (size_t)B * 4 * sizeof(double)))) return rc;
   if ((rc = ensure(h, h->ndone, 64))) return rc;
+  if ((rc = ensure(h, h->qref, (size_t)B * T * GTO_MAX_OPT * sizeof(double)))) return rc;
+  if ((rc = ensure(h, h->margin, (size_t)B * T * sizeof(int32_t)))) return rc;
   if (!h->h_ndone) HIPCHK(h, hipHostMalloc((void**)&h->h_ndone, 64));
   return GTO_OK;
 }
@@ -562,6 +595,8 @@ static BatchPtrs make_ptrs(gto_handle* h, const int32_t* scene_id, const double*
   bp.goalblk = (double*)h->goalblk.p;
   bp.ss_fixed = (double*)h->ssfixed.p;
   bp.n_done = (int32_t*)h->ndone.p;
+  bp.qref = (double*)h->qref.p;
+  bp.margin = (int32_t*)h->margin.p;
   bp.dbg = h->dbg;
   return bp;
 }
@@ -583,7 +618,7 @@ static int launch_obstacle(gto_handle* h, hipStream_t st, const BatchPtrs& bp, c
     HIPCHK(h, hipEventRecord(e0, st));
   }
   // waypoints per workgroup: groups of h->obs_tg (the two pinned waypoints form one group)
-  const int TG = std::max(1, std::min(h->obs_tg, nT));
+  const int TG = fixed_mode ? 1 : std::max(1, std::min(h->obs_tg, nT));  // the init pass has 4 virtual waypoints
   const int nG = (nT + TG - 1) / TG;
   const int n_regular = obstacle_grid(B, nG);
   const int cap_active = TG * h->rb.n_chunks;
@@ -659,11 +694,13 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
     gr.bp.Qtry += o * nopt * T;
     gr.bp.blocks += 2 * o * T * BLK_STRIDE;  // the two slots of a group are contiguous: [2][n][T][..]
     gr.bp.goalblk += 2 * o * 2 * BLK_STRIDE;
-    gr.bp.ss_fixed += o * 2;
+    gr.bp.ss_fixed += o * 4;
     gr.bp.n_done += g;
+    gr.bp.qref += o * T * GTO_MAX_OPT;
+    gr.bp.margin += o * T;
     if (G > 1) HIPCHK(h, hipStreamWaitEvent(gr.st, h->ev_fork, 0));
     hipLaunchKernelGGL(k_lm_init, dim3(gr.n), dim3(64), 0, gr.st, h->d_rb, gr.bp, sp, gr.n, 0);
-    if ((rc = launch_obstacle(h, gr.st, gr.bp, sp, gr.n, 0, 2, 1, false))) return rc;
+    if ((rc = launch_obstacle(h, gr.st, gr.bp, sp, gr.n, 0, 4, 1, false))) return rc;
   }
   // one round = evaluate the trial trajectory (obstacle kernel) + accept/solve/new trial (step kernel);
   // instances that are done exit both kernels immediately
@@ -878,11 +915,11 @@ static int eval_common(gto_handle* h, int B, int n_max, const int32_t* scene_id,
                            (const double*)d_so, (const double*)d_base, (const double*)d_Q0);
   HIPCHK(h, hipMemsetAsync(bp.n_done, 0, sizeof(int32_t), h->stream));
   hipLaunchKernelGGL(k_lm_init, dim3(B), dim3(64), 0, h->stream, h->d_rb, bp, sp, B, 1 /* raw: evaluate Q as given */);
-  if ((rc = launch_obstacle(h, h->stream, bp, sp, B, 0, 2, 1, false))) return rc;
+  if ((rc = launch_obstacle(h, h->stream, bp, sp, B, 0, 4, 1, false))) return rc;
   if ((rc = launch_obstacle(h, h->stream, bp, sp, B, 2, (int)T - 2, 0, false))) return rc;
   states.resize(B);
   blocks.resize((size_t)B * T * BLK_STRIDE);
-  ssfixed.resize((size_t)B * 2);
+  ssfixed.resize((size_t)B * 4);
   HIPCHK(h, hipMemcpyAsync(states.data(), h->state.p, B * sizeof(InstState), hipMemcpyDeviceToHost, h->stream));
   // trial slot is 1 right after init (slot = 0)
   HIPCHK(h, hipMemcpyAsync(blocks.data(), (double*)h->blocks.p + (size_t)1 * B * T * BLK_STRIDE,
@@ -905,7 +942,7 @@ int gto_eval_objective(gto_handle* h, int32_t B, int32_t n_max, const int32_t* s
   if (rc) return rc;
   const int T = h->opts.T;
   for (int b = 0; b < B; ++b) {
-    double so = ssf[2 * b] + ssf[2 * b + 1];
+    double so = ssf[4 * b] + ssf[4 * b + 1];
     for (int t = 2; t < T; ++t) so += blocks[((size_t)b * T + t) * BLK_STRIDE + BLK_SS];
     if (f_goal) f_goal[b] = st[b].fgoal_try;
     if (f_obs) f_obs[b] = h->opts.w_obstacle * so;
@@ -933,7 +970,7 @@ int gto_eval_obstacle_normal_eq(gto_handle* h, int32_t B, const int32_t* scene_i
           if (JtJ) JtJ[(((size_t)b * T + t) * n + i) * n + j] = (t < 2) ? 0.0 : blk[BLK_JTJ + 8 * i + j];
         if (Jtr) Jtr[((size_t)b * T + t) * n + i] = (t < 2) ? 0.0 : blk[BLK_JTR + i];
       }
-      if (sumsq) sumsq[(size_t)b * T + t] = (t < 2) ? ssf[2 * b + t] : blk[BLK_SS];
+      if (sumsq) sumsq[(size_t)b * T + t] = (t < 2) ? ssf[4 * b + t] : blk[BLK_SS];
     }
   return GTO_OK;
 }

@@ -35,6 +35,9 @@ struct RobotDev {
   double vis_origin[GTO_MAX_LINKS][12];  // rt2tr(rpy2r(vis_rpy), vis_xyz) (gto/gto_models.py:95-96)
   int32_t opt_index[GTO_MAX_OPT];
   double lower[GTO_MAX_OPT], upper[GTO_MAX_OPT];
+  // reach[j]: upper bound on |dx/dq_j| over every surface point and configuration (metres per radian,
+  // or 1 for a prismatic joint); < 0 disables temporal culling
+  double reach[GTO_MAX_OPT];
   // moments of the gripper point cloud p_k (gto/gto_planner.py:37): K, mu = sum p, M = sum p p^T
   double grip_count, grip_mu[3], grip_M[9];
 };

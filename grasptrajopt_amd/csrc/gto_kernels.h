@@ -50,8 +50,10 @@ struct BatchPtrs {
   double* Qtry;      // [B][n][T]
   double* blocks;    // [2][B][T][BLK_STRIDE]
   double* goalblk;   // [2][B][2][BLK_STRIDE]
-  double* ss_fixed;  // [B][2]  sum c^2 of the two pinned waypoints
+  double* ss_fixed;  // [B][4]  sum c^2 of the two pinned waypoints; of the static links under c_all / c_obs
   int32_t* n_done;   // [1]     instances that have finished
+  double* qref;      // [B][T][GTO_MAX_OPT] configuration at which `margin` was measured
+  int32_t* margin;   // [B][T] voxels of clearance left at qref when the whole waypoint was in free space, else -1
   long long* dbg;    // optional: phase timestamps of instance 0's step kernel (GTO_DEBUG_TIMING)
 };
 
@@ -528,8 +530,13 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
   if (b >= B) return;
   const InstState* st = bp.state + b;
   if (st->done) return;
-  const int t0w = t_begin + grp_id * TG;                 // first waypoint of this group
-  const int ng = min(TG, t_begin + nT - t0w);            // waypoints in this group
+  // fixed mode evaluates four "virtual waypoints": 0,1 = the two pinned waypoints (all links, value only);
+  // 2,3 = the links no optimised joint moves, under c_all and under c_obs (their sum of c^2 is the same
+  // at every waypoint and every iteration, so the solve loop never touches those points again)
+  const int t0v = t_begin + grp_id * TG;                 // first (virtual) waypoint of this group
+  const bool static_only = fixed_mode && t0v >= 2;
+  const int t0w = static_only ? 0 : t0v;                 // waypoint whose configuration is used
+  const int ng = static_only ? 1 : min(TG, (fixed_mode ? 2 : t_begin + nT) - t0v);  // waypoints in this group
   const bool dbg_wg = bp.dbg && b == 0 && grp_id == nG - 1;
   if (dbg_wg && tid == 0) bp.dbg[10] = clock64();
 
@@ -538,6 +545,28 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
     const int kq = idx / ndof, i = idx % ndof, j = rb->opt_of_dof[i];
     s_q[kq * GTO_MAX_DOF + i] = (j >= 0) ? bp.Qtry[((size_t)b * n + j) * T + t0w + kq]
                                          : bp.Q0[((size_t)b * ndof + i) * T + t0w + kq];
+  }
+  // Temporal culling (exact): if at configuration qref every chunk of this waypoint was at least
+  // `margin` voxels clear of any non-zero voxel, and no surface point can have moved further than that
+  // since (|dx| <= sum_j |dq_j| reach_j), the waypoint still contributes exact zeros: write them and leave.
+  if (TG == 1 && !fixed_mode) {
+    const int mg = bp.margin[(size_t)b * T + t0w];
+    if (mg >= 0) {  // block-uniform
+      double dsum = 0.0;
+      if (tid < n) {
+        const double dq = bp.Qtry[((size_t)b * n + tid) * T + t0w] - bp.qref[((size_t)b * T + t0w) * GTO_MAX_OPT + tid];
+        dsum = fabs(dq) * rb->reach[tid];
+      }
+      if (tid < 64) dsum = wave_sum(dsum);
+      if (tid == 0) s_nactive = (rb->reach[0] >= 0.0 && (int)ceil(dsum * scenes[bp.scene_id[b]].rinv) <= mg) ? 1 : 0;
+      __syncthreads();
+      if (s_nactive) {
+        double* out = bp.blocks + (((size_t)(1 - st->slot) * B + b) * T + t0w) * BLK_STRIDE;
+        if (tid < BLK_STRIDE) out[tid] = (tid == BLK_SS) ? bp.ss_fixed[4 * b + (t0w < sp.ts ? 2 : 3)] : 0.0;
+        return;
+      }
+      __syncthreads();
+    }
   }
   if (tid < F) s_parent[tid] = rb->parent[tid];
   for (int i = tid; i < ng * L * GTO_GRAM; i += 256) s_gram[i] = 0.0;
@@ -654,7 +683,9 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
   // looks up the Chebyshev distance to the nearest non-zero voxel; a chunk whose sphere (radius R voxels,
   // +2 for the floor of the centre and index rounding) cannot reach one contributes exact zeros and is
   // skipped.  Survivors keep (waypoint, link) order (ballot prefix): a wave still sees few key changes.
+  auto use_all = [&](int kq_) { return static_only ? (t0v == 2) : ((t0w + kq_) < sp.ts); };
   const int C = rb->n_chunks;
+  int my_slack = 1 << 20;  // min over this thread's chunks of (distance - radius), voxels
   for (int base_c = 0; base_c < ng * C; base_c += 256) {
     const int gi = base_c + tid;
     bool keep = false;
@@ -663,6 +694,7 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
       const int kq = gi / C, ci = gi % C;
       const Chunk cc = chunks[ci];
       desc4 = make_int4(cc.link | (kq << 16), cc.start, cc.count, ci);
+      const bool is_static = cc.pad != 0;  // link not moved by any optimised joint
       const double* V = s_vis + (kq * L + cc.link) * 12;
       const double u0 = (V[0] * cc.cx + V[1] * cc.cy + V[2] * cc.cz + V[3] + bx - sc.ox) * sc.rinv;
       const double u1 = (V[4] * cc.cx + V[5] * cc.cy + V[6] * cc.cz + V[7] + by - sc.oy) * sc.rinv;
@@ -670,10 +702,22 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
       const int R = (int)ceil(cc.r * sc.rinv) + 2;
       const int k0 = (int)floor(u0), k1 = (int)floor(u1), k2 = (int)floor(u2);
       keep = true;
+      if ((is_static && !fixed_mode) || (!is_static && static_only)) {
+        keep = false;  // static links are accounted once at init; the static-only pass ignores the rest
+      } else
       // only spheres that lie inside the grid (no clipped indices) and are closer than the cap can be culled
       if (R < GTO_DIST_CAP && k0 - R >= 0 && k1 - R >= 0 && k2 - R >= 0 && k0 + R < sc.nx && k1 + R < sc.ny && k2 + R < sc.nz) {
-        const uint8_t* __restrict__ dist = (t0w + kq < sp.ts) ? sc.d_all : sc.d_obs;
-        keep = (int)dist[k2 + nz * (k1 + sc.ny * k0)] <= R;
+        const uint8_t* __restrict__ dist = use_all(kq) ? sc.d_all : sc.d_obs;
+        const int dd = (int)dist[k2 + nz * (k1 + sc.ny * k0)];
+        keep = dd <= R;
+        // clearance that also survives a move of the sphere: stay inside the grid and below the cap
+        int sl = dd - R;
+        sl = min(sl, min(min(k0, k1), k2) - R);
+        sl = min(sl, min(min(sc.nx - 1 - k0, sc.ny - 1 - k1), sc.nz - 1 - k2) - R);
+        sl = min(sl, GTO_DIST_CAP - 1 - R);
+        my_slack = min(my_slack, sl);
+      } else {
+        my_slack = -1000;
       }
     }
     const unsigned long long bm = __ballot(keep);
@@ -690,6 +734,19 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
     __syncthreads();
   }
   const int NA = s_nactive;
+  if (TG == 1 && !fixed_mode) {
+    // remember how much room this waypoint had (only if the whole waypoint was culled)
+    int ms = my_slack;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ms = min(ms, __shfl_xor(ms, o, 64));
+    if (lane == 0) s_wcount[wave] = ms;
+    __syncthreads();
+    if (tid < n) bp.qref[((size_t)b * T + t0w) * GTO_MAX_OPT + tid] = s_q[rb->opt_index[tid]];
+    if (tid == 0) {
+      const int mall = min(min(s_wcount[0], s_wcount[1]), min(s_wcount[2], s_wcount[3]));
+      bp.margin[(size_t)b * T + t0w] = (NA == 0 && mall >= 2) ? mall - 2 : -1;
+    }
+  }
   // contiguous range of surviving chunks per wave
   const int c0 = (int)(((long)NA * wave) / 4), c1 = (int)(((long)NA * (wave + 1)) / 4);
   if (dbg_wg && tid == 0) bp.dbg[12] = clock64();
@@ -787,7 +844,7 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
       // lanes past the end of the chunk carry x = 0 and have their cost and gradient zeroed
       const bool valid = lane < ch.count;
       const int kq = ch.key >> 16, link = ch.key & 0xffff;
-      const bool pre = (t0w + kq) < sp.ts;  // gto/gto_planner.py:117-131: c_all before the standoff waypoint
+      const bool pre = use_all(kq);  // gto/gto_planner.py:117-131: c_all before the standoff waypoint
       const double* V = s_vis + (kq * L + link) * 12;
       // point in the robot-base frame (gto/gto_planner.py:114-116); the field frame adds base_position
       const double y0 = V[0] * x0 + V[1] * x1 + V[2] * x2 + V[3];
@@ -903,8 +960,11 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
     bp.dbg[15] = NA;
   }
   if (fixed_mode) {
-    if (tid < ng) bp.ss_fixed[2 * b + t0w + tid] = s_out[tid * BLK_STRIDE + BLK_SS];
+    if (tid < ng) bp.ss_fixed[4 * b + t0v + tid] = s_out[tid * BLK_STRIDE + BLK_SS];
   } else {
+    // add the constant contribution of the static links (measured once at init)
+    if (tid < ng) s_out[tid * BLK_STRIDE + BLK_SS] += bp.ss_fixed[4 * b + ((t0w + tid) < sp.ts ? 2 : 3)];
+    __syncthreads();
     double* out = bp.blocks + (((size_t)(1 - st->slot) * B + b) * T + t0w) * BLK_STRIDE;
     for (int i = tid; i < ng * BLK_STRIDE; i += 256) out[i] = s_out[i];
   }
@@ -1154,6 +1214,7 @@ __global__ __launch_bounds__(64) void k_lm_init(const RobotDev* __restrict__ rb,
     st->evals = 0;
     st->argmin_cur = 0;
   }
+  for (int t = lane; t < T; t += 64) bp.margin[(size_t)b * T + t] = -1;
   // seed: optimised rows of Q0, first two waypoints pinned to qc, the rest clipped into the bounds
   const double* Q0b = bp.Q0 + (size_t)b * rb->ndof * T;
   double* Qt = bp.Qtry + (size_t)b * n * T;
@@ -1216,7 +1277,7 @@ __global__ __launch_bounds__(256) void k_lm_step(const RobotDev* __restrict__ rb
     const double* blk = bp.blocks + ((size_t)trial * B + b) * T * BLK_STRIDE;
     for (int t = 2 + lane; t < T; t += 64) fo += blk[(size_t)t * BLK_STRIDE + BLK_SS];
     fo = wave_sum(fo);
-    fo += bp.ss_fixed[2 * b] + bp.ss_fixed[2 * b + 1];
+    fo += bp.ss_fixed[4 * b] + bp.ss_fixed[4 * b + 1];
   }
   const double f_try = st->fgoal_try + sp.w_obstacle * fo + st->fvel_try;
 
