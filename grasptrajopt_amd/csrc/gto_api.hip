@@ -90,7 +90,7 @@ void gto_default_opts(gto_solver_opts* o) {
   o->w_vel = 0.01;  // :135
   o->max_iter = 100;  // :141
   o->tol_step = 1e-7;
-  o->tol_rel_f = 1e-10;
+  o->tol_rel_f = 1e-8;  // relative decrease of f below which an accepted step ends the solve (scipy least_squares ftol default)
   o->lambda0 = 1e-3;
   o->grad_mode = GTO_GRAD_CENTRAL_DIFF;
 }

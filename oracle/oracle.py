@@ -57,7 +57,7 @@ def reference_opts(**kw) -> CSolverOpts:
     o.T, o.Tmax, o.standoff_offset = 50, 10.0, -10
     o.w_obstacle, o.w_vel = 10.0, 0.01
     o.max_iter = 100
-    o.tol_step, o.tol_rel_f, o.lambda0 = 1e-7, 1e-10, 1e-3
+    o.tol_step, o.tol_rel_f, o.lambda0 = 1e-7, 1e-8, 1e-3
     o.grad_mode = 0
     for k, v in kw.items():
         if not hasattr(o, k):
