@@ -6,6 +6,10 @@ trajectory problems of BASELINE.json configs[1] (Panda 7-DoF, T=50 waypoints, ~5
 128^3 float32 cost field, 64 candidate goal grasps of one scene) with the batched Gauss-Newton/LM
 solver behind the C ABI (gto_solve_batch_device: inputs already resident in HBM).
 N GPUs = N ranks, each solving its own scene x 64 grasps (weak scaling, no data-path collective).
+The K timed steps run through grasptrajopt_amd.parallel.BatchPipeline with --pipeline D steps in flight
+per GPU (one solver handle + stream + host thread each): a single batch of 64 is a latency-bound chain
+of launches that leaves most CUs idle, and consecutive batches are independent.  The strictly serial
+rate (D = 1) is reported next to it in "pipeline".
 
 Prints ONE JSON line (rank 0).  Extra objects:
   roofline      dominant kernel (k_obstacle_gram), algorithmic field-gather bytes / HIP-event time
@@ -31,6 +35,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="goal grasps (instances) per GPU per step")
+    ap.add_argument("--pipeline", type=int, default=3, help="batches (steps) in flight per GPU: solver handles/streams")
     ap.add_argument("--max-iter", type=int, default=100, help="iteration cap (reference IPOPT cap: 100)")
     ap.add_argument("--robot", default="panda_5k")
     ap.add_argument("--grid", type=int, default=128)
@@ -40,6 +45,9 @@ def main():
                     help="HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes (see profiles/)")
     args = ap.parse_args()
 
+    # the HIP runtime multiplexes streams onto this many hardware queues (default 4); the pipeline lanes
+    # must not share one, or their launches serialise
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     import torch
     import torch.distributed as dist
 
@@ -61,15 +69,15 @@ def main():
     if not os.path.exists(g.HIP_LIB):
         g.build()
     from grasptrajopt_amd import _capi, synthetic as syn
-    from grasptrajopt_amd.parallel import shard_range
+    from grasptrajopt_amd.parallel import BatchPipeline, shard_range
     from grasptrajopt_amd.robot_desc import load_builtin
 
     cfg = json.load(open(os.path.join(ROOT, "grasptrajopt_amd", "data", "panda_cfg.json")))
     desc = load_builtin(args.robot)
     opts = _capi.default_opts()
     opts.max_iter = args.max_iter
-    h = _capi.SolverHandle(desc, cfg["link_ee"], cfg["link_gripper"], opts, device=local_rank, n_gripper_points=100)
     T, ndof, B = opts.T, desc.ndof, args.batch
+    D = max(1, args.pipeline)
 
     # this rank's shard of the global problem list: scene = global rank id, 64 grasps each
     lo, hi = shard_range(world * B, rank, world)
@@ -77,7 +85,32 @@ def main():
     scene_seed = lo // B
     res = 2.24 / args.grid  # covers the 2.24 m reach box (0.0175 m at 128^3)
     sc = syn.make_scene(scene_seed, n=args.grid, res=res)
-    h.set_scene(0, sc.c_all, sc.c_obs, sc.shape, sc.origin, sc.res)
+
+    # D pipeline lanes: each one solver handle bound to ONE stream of its own, with its own copy of the
+    # batch in HBM and its own outputs (grasptrajopt_amd.parallel.BatchPipeline runs them concurrently)
+    class Lane:
+        def __init__(self):
+            self.stream = torch.cuda.Stream(dev)
+            self.h = _capi.SolverHandle(desc, cfg["link_ee"], cfg["link_gripper"], opts, device=local_rank, n_gripper_points=100)
+            self.h.set_stream(self.stream.cuda_stream)
+            self.h.set_scene(0, sc.c_all, sc.c_obs, sc.shape, sc.origin, sc.res)
+
+        def upload(self, qc, RT, S, base, Q0):
+            t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(dt).to(dev)
+            self.inp = [torch.zeros(B, dtype=torch.int32, device=dev), t(qc, torch.float64), t(RT.reshape(B, 1, 16), torch.float64),
+                        torch.ones(B, dtype=torch.int32, device=dev), t(S, torch.float64), t(base, torch.float64), t(Q0, torch.float64)]
+            self.d_Q = torch.empty((B, ndof, T), dtype=torch.float64, device=dev)
+            self.d_dQ = torch.empty((B, ndof, T - 1), dtype=torch.float64, device=dev)
+            self.d_cost = torch.empty(B, dtype=torch.float64, device=dev)
+            self.d_it = torch.empty(B, dtype=torch.int32, device=dev)
+            self.d_st = torch.empty(B, dtype=torch.int32, device=dev)
+            self.ptrs = [x.data_ptr() for x in self.inp + [self.d_Q, self.d_dQ, self.d_cost, self.d_it, self.d_st]]
+
+        def step(self):
+            self.h.solve_batch_device(B, 1, *self.ptrs, self.stream.cuda_stream)
+
+    lanes = [Lane() for _ in range(D)]
+    h = lanes[0].h
     # goal grasps: collision-free configurations w.r.t. the obstacle field (target object removed);
     # links that no optimised joint moves (the base) are ignored
     moving = desc.link_is_moving()[desc.point_link]
@@ -91,44 +124,51 @@ def main():
     Q0 = np.stack([syn.make_seed(qc[b], qg[b], T, desc.param_index) for b in range(B)])
     S = np.tile(syn.standoff_pose(-0.1, cfg["axis_standoff"]).reshape(1, 16), (B, 1))
     base = np.zeros((B, 3))
-
-    t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(dt).to(dev)
-    d_sid = torch.zeros(B, dtype=torch.int32, device=dev)
-    d_qc, d_goals = t(qc, torch.float64), t(RT.reshape(B, 1, 16), torch.float64)
-    d_ng = torch.ones(B, dtype=torch.int32, device=dev)
-    d_S, d_base, d_Q0 = t(S, torch.float64), t(base, torch.float64), t(Q0, torch.float64)
-    d_Q = torch.empty((B, ndof, T), dtype=torch.float64, device=dev)
-    d_dQ = torch.empty((B, ndof, T - 1), dtype=torch.float64, device=dev)
-    d_cost = torch.empty(B, dtype=torch.float64, device=dev)
-    d_it = torch.empty(B, dtype=torch.int32, device=dev)
-    d_st = torch.empty(B, dtype=torch.int32, device=dev)
-    stream = torch.cuda.current_stream(dev).cuda_stream
-
-    def step():
-        h.solve_batch_device(B, 1, d_sid.data_ptr(), d_qc.data_ptr(), d_goals.data_ptr(), d_ng.data_ptr(),
-                             d_S.data_ptr(), d_base.data_ptr(), d_Q0.data_ptr(), d_Q.data_ptr(), d_dQ.data_ptr(),
-                             d_cost.data_ptr(), d_it.data_ptr(), d_st.data_ptr(), stream)
+    for ln in lanes:
+        ln.upload(qc, RT, S, base, Q0)
+    torch.cuda.synchronize(dev)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        step()
+    def run_steps(pipe, n):
+        futs = [pipe.submit("step") for _ in range(n)]
+        for f in futs:
+            f.result()
+
+    pipe = BatchPipeline(lanes)
+    run_steps(pipe, args.warmup * D)  # every lane sees >= W warmup steps
     barrier()
-    h.set_profiling(True)  # HIP events around every launch of the dominant kernel, on the launch stream
-    kern_ms, kern_launches = 0.0, 0
-    barrier()
+    # ---- timed region: exactly K steps (batches), up to D of them in flight
     t0 = time.perf_counter()
+    run_steps(pipe, args.steps)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    pipe.close()
+
+    # ---- the same K steps strictly one after the other on one lane: per-batch latency, then once more
+    # with HIP events around every launch of the dominant kernel (on its launch stream) for the roofline;
+    # alone on the GPU, so a launch's duration is the kernel's own and matches the rocprofv3 summary
+    ln0 = lanes[0]
+    barrier()
+    ts = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        ln0.step()
+    barrier()
+    serial_elapsed = time.perf_counter() - ts
+    h.set_profiling(True)
+    kern_ms, kern_launches = 0.0, 0
+    for _ in range(args.steps):
+        ln0.step()
         ms, nl = h.last_kernel_time()
         kern_ms += ms
         kern_launches += nl
     barrier()
-    elapsed = time.perf_counter() - t0
     h.set_profiling(False)
+    d_it, d_st, d_cost, d_Q = ln0.d_it, ln0.d_st, ln0.d_cost, ln0.d_Q
+    same = all(bool(torch.equal(l.d_Q, d_Q)) and bool(torch.equal(l.d_it, d_it)) for l in lanes[1:])
 
     # the same solve through the host-pointer entry point (H2D/D2H of per-instance data included)
     host_rate = None
@@ -182,7 +222,9 @@ def main():
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "alg_bytes_per_launch": round(alg_bytes / max(kern_launches, 1)),
                     "avg_launch_us": round(avg_launch_us, 2), "launches": kern_launches,
-                    "kernel_time_frac_of_step": round(kern_ms * 1e-3 / elapsed, 3)}
+                    "kernel_time_frac_of_serial_step": round(kern_ms * 1e-3 / serial_elapsed, 3),
+                    "measured": "HIP events on the launch stream over K serial steps (pipeline depth 1) run right after the "
+                                "timed region, so that launches of other batches do not stretch the durations"}
 
         cpu_baseline = None
         if not args.no_cpu_baseline:
@@ -217,7 +259,12 @@ def main():
             "config": {"workload": "BASELINE configs[1]: Panda 7-DoF, 1 scene x 64 goal grasps per GPU, T=50, "
                                    f"{P} surface points, {args.grid}^3 f32 SDF cost field",
                        "batch_per_gpu": B, "T": int(T), "surface_points": int(P), "grid": args.grid,
-                       "max_iter": args.max_iter, "parallelism": f"instances sharded over {world} GPU(s), no collective"},
+                       "max_iter": args.max_iter, "pipeline_depth": D,
+                       "parallelism": f"instances sharded over {world} GPU(s), no collective"},
+            "pipeline": {"depth": D, "what": "steps in flight per GPU: one solver handle + HIP stream + host thread each",
+                         "serial_ms_per_step": round(1e3 * serial_elapsed / args.steps, 3),
+                         "serial_trajectories_per_s": round(B * args.steps / serial_elapsed, 2),
+                         "lanes_bit_identical": same},
             "sqp_iters_per_s": round(iters_per_s, 1),
             "host_api_trajectories_per_s": round(host_rate, 2),
             "iters_mean": round(float(iters.mean()), 2), "iters_max": int(iters.max()),
@@ -231,7 +278,8 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
         print(json.dumps(out))
-    h.close()
+    for ln in lanes:
+        ln.h.close()
     if world > 1:
         dist.destroy_process_group()
 

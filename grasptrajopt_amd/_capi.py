@@ -134,13 +134,14 @@ def load_library(path: Optional[str] = None):
     lib.gto_solve_batch_device.argtypes = solve_args + [C.c_void_p]
     lib.gto_last_kernel_time.argtypes = [H, _pd, _pi]
     lib.gto_set_profiling.argtypes = [H, C.c_int32]
+    lib.gto_set_stream.argtypes = [H, C.c_void_p]
     lib.gto_eval_fk.argtypes = [H, C.c_int32, _pd, _pd]
     lib.gto_eval_points.argtypes = [H, C.c_int32, C.c_int32, _pd, _pd, C.c_int32, _pd, _pi, _pd, _pd]
     lib.gto_eval_objective.argtypes = [H, C.c_int32, C.c_int32, _pi, _pd, _pi, _pd, _pd, _pd, _pd, _pd, _pd, _pi]
     lib.gto_eval_obstacle_normal_eq.argtypes = [H, C.c_int32, _pi, _pd, _pd, _pd, _pd, _pd]
     lib.gto_plan_cost.argtypes = [H, C.c_int32, C.c_int32, _pd, _pd, _pd, _pd]
     for fn in ("gto_create", "gto_set_opts", "gto_set_scene", "gto_drop_scene", "gto_solve_batch",
-               "gto_solve_batch_device", "gto_last_kernel_time", "gto_set_profiling", "gto_eval_fk",
+               "gto_solve_batch_device", "gto_last_kernel_time", "gto_set_profiling", "gto_set_stream", "gto_eval_fk",
                "gto_eval_points", "gto_eval_objective", "gto_eval_obstacle_normal_eq", "gto_plan_cost"):
         getattr(lib, fn).restype = C.c_int
     if path is None:
@@ -151,7 +152,7 @@ def load_library(path: Optional[str] = None):
 EXPORTED_SYMBOLS = (
     "gto_default_opts", "gto_version", "gto_create", "gto_destroy", "gto_last_error", "gto_set_opts",
     "gto_set_scene", "gto_drop_scene", "gto_solve_batch", "gto_solve_batch_device",
-    "gto_last_kernel_time", "gto_set_profiling", "gto_eval_fk", "gto_eval_points",
+    "gto_last_kernel_time", "gto_set_profiling", "gto_set_stream", "gto_eval_fk", "gto_eval_points",
     "gto_eval_objective", "gto_eval_obstacle_normal_eq", "gto_plan_cost",
 )
 
@@ -262,6 +263,11 @@ class SolverHandle:
                                              vp(standoff), vp(base_pos), vp(Q0), vp(Q_out), vp(dQ_out),
                                              vp(cost_out), vp(iters_out), vp(status_out), vp(stream))
         self._check(rc, "gto_solve_batch_device")
+
+    def set_stream(self, stream):
+        """Bind every launch/copy of this handle to the caller's HIP stream (an int such as
+        torch.cuda.Stream.cuda_stream); None restores a private stream."""
+        self._check(self.lib.gto_set_stream(self._h, None if stream is None else C.c_void_p(int(stream))), "gto_set_stream")
 
     def set_profiling(self, enabled: bool):
         self._check(self.lib.gto_set_profiling(self._h, int(enabled)), "gto_set_profiling")

@@ -25,6 +25,7 @@ struct DevBuf {
 struct gto_handle {
   int device = 0;
   hipStream_t stream = nullptr;
+  bool own_stream = true;  // false after gto_set_stream(h, caller's stream)
   std::string err;
   gto_solver_opts opts;
   RobotDev rb;  // host copy
@@ -388,7 +389,7 @@ void gto_destroy(gto_handle* h) {
   for (auto& b : h->in) (void)hipFree(b.p);
   for (auto& b : h->out) (void)hipFree(b.p);
   for (auto e : h->ev) (void)hipEventDestroy(e);
-  if (h->stream) (void)hipStreamDestroy(h->stream);
+  if (h->stream && h->own_stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
 
@@ -517,6 +518,22 @@ int gto_drop_scene(gto_handle* h, int32_t id) {
   HIPCHK(h, hipFree((void*)s.d_all));
   memset(&s, 0, sizeof s);
   return sync_scene_table(h);
+}
+
+int gto_set_stream(gto_handle* h, void* stream) {
+  if (!h) return GTO_ERR_INVALID_ARG;
+  HIPCHK(h, hipSetDevice(h->device));
+  if (h->stream) HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (h->stream && h->own_stream) HIPCHK(h, hipStreamDestroy(h->stream));
+  h->stream = nullptr;
+  if (stream) {
+    h->stream = (hipStream_t)stream;
+    h->own_stream = false;
+  } else {
+    HIPCHK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    h->own_stream = true;
+  }
+  return GTO_OK;
 }
 
 int gto_set_profiling(gto_handle* h, int32_t enabled) {

@@ -466,7 +466,7 @@ struct ObsLds {  // dynamic LDS layout (offsets in doubles), computed identicall
     fr = o;     o += TG * F * 12;
     vis = o;    o += TG * L * 12;
     screw = o;  o += TG * GTO_MAX_OPT * 6;
-    gram = o;   o += TG * L * GTO_GRAM;
+    gram = o;   o += 4 * TG * L * GTO_GRAM;  // one private copy per wave, summed in wave order (deterministic)
     out = o;    o += TG * BLK_STRIDE;
     list = o;   o += 4 * GTO_LIST_CAP * 8 > TG * F * 12 ? 4 * GTO_LIST_CAP * 8 : TG * F * 12;  // also FK pong buffer / s_u
     active = o; o += cap_active * 2;  // int4 per entry
@@ -492,6 +492,7 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
   __shared__ int s_wcount[4];
   __shared__ int s_nactive;
   __shared__ unsigned s_touched[GTO_MAX_TG];  // per waypoint of the group: links whose Gram got a contribution
+  __shared__ double s_ssw[4][GTO_MAX_TG];     // per wave: sum of c^2 of each waypoint of the group
 
   const int bid = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int L = rb->n_links, n = rb->n_opt, T = sp.T, ndof = rb->ndof, F = rb->n_frames;
@@ -569,7 +570,8 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
     }
   }
   if (tid < F) s_parent[tid] = rb->parent[tid];
-  for (int i = tid; i < ng * L * GTO_GRAM; i += 256) s_gram[i] = 0.0;
+  for (int i = tid; i < 4 * ng * L * GTO_GRAM; i += 256) s_gram[i] = 0.0;
+  if (tid < 4 * GTO_MAX_TG) (&s_ssw[0][0])[tid] = 0.0;
   for (int i = tid; i < ng * BLK_STRIDE; i += 256) s_out[i] = 0.0;
   if (tid < GTO_MAX_TG) s_touched[tid] = 0u;
   if (tid == 0) s_nactive = 0;
@@ -758,6 +760,7 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
   // carries no 28-wide per-lane accumulator, needs no cross-lane reduction and its cost follows the
   // number of points that actually touch the obstacle band.
   double* lst = s_list + wave * (GTO_LIST_CAP * 8);
+  double* gram_w = s_gram + (size_t)wave * ng * L * GTO_GRAM;  // this wave's private Gram copy
   const int grp = lane < 28 ? 0 : (lane < 56 ? 1 : -1);
   const int kk = lane - 28 * (grp > 0 ? 1 : 0);  // Gram entry owned by this lane (valid when grp >= 0)
   int oi = 0, oj = 0;                            // list-entry components multiplied by this lane
@@ -795,14 +798,16 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
   do {                                                                                       \
     if (cnt) GTO_DRAIN();                                                                    \
     const int fk_ = (key) >> 16, fl_ = (key)&0xffff;                                         \
-    if (grp >= 0 && kk < 27 && gacc != 0.0) {                                                \
-      atomicAdd(&s_gram[(fk_ * L + fl_) * GTO_GRAM + kk], gacc);                             \
+    /* even-slot + odd-slot partial sums meet in the lower lane; one writer per address */   \
+    const double gsum_ = gacc + __shfl(gacc, (lane + 28) & 63, 64);                          \
+    if (grp == 0 && kk < 27 && gsum_ != 0.0) {                                               \
+      gram_w[(fk_ * L + fl_) * GTO_GRAM + kk] += gsum_;                                      \
       atomicOr(&s_touched[fk_], 1u << fl_);                                                  \
     }                                                                                        \
     gacc = 0.0;                                                                              \
-    if ((cur_key >> 16) != fk_ || true) {                                                    \
+    {                                                                                        \
       const double sw_ = wave_sum(ss);                                                       \
-      if (lane == 0 && sw_ != 0.0) atomicAdd(&s_out[fk_ * BLK_STRIDE + BLK_SS], sw_);        \
+      if (lane == 0) s_ssw[wave][fk_] += sw_;                                                \
       ss = 0.0;                                                                              \
     }                                                                                        \
   } while (0)
@@ -896,6 +901,13 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
 #undef GTO_FLUSH
 #undef GTO_DRAIN
   if (dbg_wg && tid == 0) bp.dbg[13] = clock64();
+  __syncthreads();
+  // fold the four per-wave copies in wave order: the result does not depend on which wave ran first
+  {
+    const int ne = ng * L * GTO_GRAM;
+    for (int i = tid; i < ne; i += 256) s_gram[i] = ((s_gram[i] + s_gram[ne + i]) + s_gram[2 * ne + i]) + s_gram[3 * ne + i];
+    if (tid < ng) s_out[tid * BLK_STRIDE + BLK_SS] = ((s_ssw[0][tid] + s_ssw[1][tid]) + s_ssw[2][tid]) + s_ssw[3][tid];
+  }
   __syncthreads();
 
   // projection of the per-link wrench Grams onto the joint screws, over the links that were touched:

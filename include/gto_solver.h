@@ -167,6 +167,16 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
                            double* Q_out, double* dQ_out, double* cost_out, int32_t* iters_out,
                            int32_t* status_out, void* stream);
 
+/*
+ * Bind the handle to the caller's HIP stream (e.g. torch.cuda.current_stream().cuda_stream): every
+ * launch and copy of every entry point then goes to that stream and the handle creates none of its
+ * own.  NULL gives the handle a private non-blocking stream again (the state after gto_create).
+ * The runtime maps streams onto a small number of hardware queues (GPU_MAX_HW_QUEUES, default 4);
+ * handles that are meant to overlap on one GPU (grasptrajopt_amd.parallel.BatchPipeline) should each
+ * own exactly one stream so that no two of them share a queue.
+ */
+int gto_set_stream(gto_handle* h, void* stream);
+
 /* Time spent inside the dominant kernel (gto_obstacle_gram) during the most recent solve,
  * measured with HIP events on the launch stream: total milliseconds and launch count. */
 int gto_last_kernel_time(gto_handle* h, double* total_ms, int32_t* launches);

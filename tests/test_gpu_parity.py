@@ -261,3 +261,37 @@ def test_full_size_properties(capi, oracle_mod):
     np.testing.assert_array_equal(it[sel], ito)
     np.testing.assert_allclose(Q[sel], Qo, rtol=0, atol=1e-6)
     h.close()
+
+
+def test_pipelined_batches_equal_serial_solves(capi, oracle_mod):
+    """Three handles, each bound to its own stream (gto_set_stream), driven concurrently by
+    BatchPipeline: every batch must come back exactly as one handle solving them one by one."""
+    import torch
+    from grasptrajopt_amd.parallel import BatchPipeline
+    probs = [Problem("panda", B=b, scene_seed=s) for b, s in ((9, 1), (16, 2), (5, 3), (12, 4), (7, 5), (16, 6))]
+    opts = oracle_mod.reference_opts(max_iter=12)
+    streams = [torch.cuda.Stream(torch.device("cuda", 0)) for _ in range(3)]
+    hs = []
+    for st in streams:
+        h = capi.SolverHandle(probs[0].desc, probs[0].cfg["link_ee"], probs[0].cfg["link_gripper"], opts, device=0)
+        h.set_stream(st.cuda_stream)
+        hs.append(h)
+    for i, p in enumerate(probs):
+        p.finish(hs[0].eval_fk)
+        for h in hs:
+            h.set_scene(i, p.scene.c_all, p.scene.c_obs, p.scene.shape, p.scene.origin, p.scene.res)
+    batches = [(np.full(p.B, i, np.int32), p.qc, p.goals, 1, p.S, p.base, p.Q0) for i, p in enumerate(probs)]
+    serial = [hs[0].solve_batch(*b) for b in batches]
+    with BatchPipeline(hs) as pipe:
+        piped = pipe.solve_batches(batches * 3)
+    for k, out in enumerate(piped):
+        ref = serial[k % len(batches)]
+        np.testing.assert_array_equal(out[3], ref[3])
+        np.testing.assert_array_equal(out[0], ref[0])  # bit-identical trajectories
+        np.testing.assert_array_equal(out[2], ref[2])
+    # back to a private stream
+    hs[1].set_stream(None)
+    again = hs[1].solve_batch(*batches[0])
+    np.testing.assert_array_equal(again[0], serial[0][0])
+    for h in hs:
+        h.close()

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch.multiprocessing as mp
 
-from grasptrajopt_amd.parallel import shard_by_scene, shard_range
+from grasptrajopt_amd.parallel import BatchPipeline, shard_by_scene, shard_range
 
 
 def test_shard_range_partitions_everything():
@@ -30,6 +30,48 @@ def test_shard_by_scene_keeps_scenes_together():
         assert len(set(a[sid == s])) == 1
     load = np.bincount(a, minlength=8)
     assert load.max() - load.min() <= np.bincount(sid).max()
+
+
+def test_batch_pipeline_orders_results_and_reuses_handles():
+    import threading
+    import time
+
+    class Fake:
+        def __init__(self, tag):
+            self.tag, self.busy, self.calls = tag, threading.Lock(), 0
+
+        def solve_batch(self, x, delay):
+            assert self.busy.acquire(blocking=False), "a handle was entered by two threads at once"
+            try:
+                time.sleep(delay)
+                self.calls += 1
+                return x * 2
+            finally:
+                self.busy.release()
+
+    fakes = [Fake(i) for i in range(3)]
+    with BatchPipeline(fakes) as pipe:
+        t0 = time.perf_counter()
+        out = pipe.solve_batches([(i, 0.05 if i % 2 else 0.01) for i in range(12)])
+        el = time.perf_counter() - t0
+    assert out == [2 * i for i in range(12)]
+    assert sum(f.calls for f in fakes) == 12 and all(f.calls > 0 for f in fakes)
+    assert el < 0.9 * (6 * 0.05 + 6 * 0.01)  # batches overlapped
+    with pytest.raises(ValueError):
+        BatchPipeline([])
+
+
+def test_batch_pipeline_propagates_errors():
+    class Bad:
+        def solve_batch(self):
+            raise RuntimeError("boom")
+
+    with BatchPipeline([Bad()]) as pipe:
+        with pytest.raises(RuntimeError):
+            pipe.submit("solve_batch").result()
+        # the handle went back to the idle queue
+        with pytest.raises(RuntimeError):
+            pipe.submit("solve_batch").result()
 
 
 def _worker(rank, world, port, tmp):
