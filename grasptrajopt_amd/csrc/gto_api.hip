@@ -40,6 +40,7 @@ struct gto_handle {
   DevBuf state, Qcur, Qtry, vis, screw, blocks, goalblk, ssfixed, ndone, qref, margin;
   int32_t* h_ndone = nullptr;  // pinned
   int check_every = 8;
+  int dbg_cut = 0;  // GTO_DEBUG_CUT: timing experiments only, results are garbage
   int n_groups = 1;
   int obs_tg = 1;  // waypoints per workgroup of the obstacle kernel (grouping measured slower: DESIGN.md section 7)
   long long* dbg = nullptr;
@@ -114,7 +115,7 @@ static int validate_opts(const gto_solver_opts* o, std::string& why) {
 
 static size_t lm_lds_bytes(int T) {
   size_t m = (size_t)T - 2;
-  size_t dbl = m * 128 + 4 * m * 8 + 8 * (size_t)T + 48 + 2 * GTO_MAX_OPT * 6 + 2 * GTO_MAX_DOF + 2 * GTO_MAX_FRAMES * 12 + 16;
+  size_t dbl = m * 128 + 4 * m * 8 + 8 * (size_t)T + 16 + 16;
   return dbl * sizeof(double) + m * 8 * sizeof(int) + 64;
 }
 
@@ -147,6 +148,7 @@ int gto_create(const gto_robot_desc* d, const gto_solver_opts* opts, int device,
   h->opts = *opts;
   if (const char* e = getenv("GTO_GROUPS")) h->n_groups = std::max(1, std::min(GTO_MAX_GROUPS, atoi(e)));
   if (const char* e = getenv("GTO_CHECK_EVERY")) h->check_every = atoi(e);
+  if (const char* e = getenv("GTO_DEBUG_CUT")) h->dbg_cut = atoi(e);
   if (const char* e = getenv("GTO_OBS_TG")) h->obs_tg = std::max(1, std::min(GTO_MAX_TG, atoi(e)));
   if (getenv("GTO_DEBUG_TIMING")) { (void)hipMalloc((void**)&h->dbg, 32 * sizeof(long long)); (void)hipMemset(h->dbg, 0, 32 * sizeof(long long)); }
   RobotDev& rb = h->rb;
@@ -217,6 +219,45 @@ int gto_create(const gto_robot_desc* d, const gto_solver_opts* opts, int device,
     double R[9];
     rpy2r(d->visual_rpy + 3 * l, R);
     rt2aff(R, d->visual_xyz + 3 * l, rb.vis_origin[l]);
+  }
+  {  // operand table of fk_mfma_tree
+    std::memset(rb.fk_tab, 0, sizeof rb.fk_tab);
+    const int F = d->n_frames, L = d->n_links;
+    auto hom = [](const double* aff, int a, int c) { return a < 3 ? aff[4 * a + c] : (c == 3 ? 1.0 : 0.0); };
+    for (int i = 0; i < F; ++i) {
+      const double* u = rb.axis_unit[i];
+      const double K[3][3] = {{0, -u[2], u[1]}, {u[2], 0, -u[0]}, {-u[1], u[0], 0}};
+      double* tab = rb.fk_tab + 64 * i;
+      for (int a = 0; a < 4; ++a)
+        for (int c = 0; c < 4; ++c) {
+          const int e = 4 * a + c;
+          const double uu = (a < 3 && c < 3) ? u[a] * u[c] : 0.0;
+          const double dl = (a == c && a < 3) ? 1.0 : 0.0, hh = (a == 3 && c == 3) ? 1.0 : 0.0;
+          tab[e] = hom(rb.origin[i], a, c);
+          tab[16 + e] = hh + uu;  // M = c0 + cos c1 + sin K
+          tab[32 + e] = dl - uu;
+          if (rb.joint_type[i] == GTO_JOINT_PRISMATIC) tab[48 + e] = (a < 3 && c == 3) ? u[a] : 0.0;
+          else tab[48 + e] = (a < 3 && c < 3) ? K[a][c] : 0.0;
+        }
+      if (rb.opt_of_frame[i] >= 0) {
+        const int j = rb.opt_of_frame[i];
+        rb.opt_frame[j] = i;
+        double* tu = rb.fk_tab + 64 * F + 16 * L + 16 * j;
+        for (int a = 0; a < 3; ++a) tu[4 * a] = u[a];
+        tu[4 * 3 + 1] = 1.0;
+      }
+    }
+    for (int l = 0; l < L; ++l)
+      for (int a = 0; a < 4; ++a)
+        for (int c = 0; c < 4; ++c) rb.fk_tab[64 * F + 16 * l + 4 * a + c] = hom(rb.vis_origin[l], a, c);
+    const int n = d->n_opt;
+    double* tI = rb.fk_tab + 64 * F + 16 * L + 16 * n;
+    for (int l = 0; l < L; ++l) tI[l] = rb.link_frame[l];
+    for (int j = 0; j < n; ++j) {
+      tI[L + j] = rb.opt_frame[j];
+      tI[L + n + j] = rb.joint_type[rb.opt_frame[j]] == GTO_JOINT_PRISMATIC ? 1.0 : 0.0;
+    }
+    for (int i = 0; i < F; ++i) tI[L + 2 * n + i] = rb.parent[i];
   }
   // moments of the gripper point cloud
   rb.grip_count = (double)d->n_gripper_points;
@@ -575,6 +616,7 @@ static SolveParams make_params(const gto_handle* h, int n_max, bool use_standoff
   sp.tol_step = o.tol_step;
   sp.tol_rel_f = o.tol_rel_f;
   sp.lambda0 = o.lambda0;
+  sp.dbg_cut = h->dbg_cut;
   return sp;
 }
 
@@ -716,7 +758,7 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
     gr.bp.qref += o * T * GTO_MAX_OPT;
     gr.bp.margin += o * T;
     if (G > 1) HIPCHK(h, hipStreamWaitEvent(gr.st, h->ev_fork, 0));
-    hipLaunchKernelGGL(k_lm_init, dim3(gr.n), dim3(64), 0, gr.st, h->d_rb, gr.bp, sp, gr.n, 0);
+    hipLaunchKernelGGL(k_lm_init, dim3(gr.n), dim3(256), 0, gr.st, h->d_rb, gr.bp, sp, gr.n, 0);
     if ((rc = launch_obstacle(h, gr.st, gr.bp, sp, gr.n, 0, 4, 1, false))) return rc;
   }
   // one round = evaluate the trial trajectory (obstacle kernel) + accept/solve/new trial (step kernel);
@@ -762,11 +804,11 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
     HIPCHK(h, hipStreamSynchronize(st));
     long long t[32];
     HIPCHK(h, hipMemcpy(t, h->dbg, sizeof t, hipMemcpyDeviceToHost));
-    fprintf(stderr, "[gto dbg] step-kernel phases (cycles) P0+P1 %lld | P2 %lld | diag %lld | dense %lld | back %lld | P4 %lld | P5 %lld | P6 %lld | s_dense %lld\n",
-            t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3], t[5] - t[4], t[6] - t[5], t[7] - t[6], t[8] - t[7], t[9]);
-    fprintf(stderr, "[gto dbg] obstacle WG (b=0,t=T-1) cycles: prologue %lld | broad %lld | loop %lld | epilogue %lld | active chunks %lld\n",
-            t[11] - t[10], t[12] - t[11], t[13] - t[12], t[14] - t[13], t[15]);
-    fprintf(stderr, "[gto dbg] prologue split: loads+q %lld | local transforms %lld | chain %lld | vis+screw %lld\n", t[16] - t[10], t[17] - t[16], t[18] - t[17], t[11] - t[18]);
+    fprintf(stderr, "[gto dbg] step-kernel phases (cycles) P0+P1 %lld | P2 %lld | diag %lld | dense %lld | back %lld | P4 %lld | P5 %lld | s_dense %lld\n",
+            t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3], t[5] - t[4], t[6] - t[5], t[7] - t[6], t[9]);
+    fprintf(stderr, "[gto dbg] fk_mfma_tree (cycles): local %lld | rounds %lld %lld %lld %lld | outputs %lld\n", t[21] - t[20], t[22] - t[21], t[23] - t[22], t[24] - t[23], t[25] - t[24], t[27] - t[25]);
+    fprintf(stderr, "[gto dbg] obstacle WG (b=0,t=T-1) cycles: prologue %lld | broad %lld | loop %lld | epilogue %lld | active chunks %lld | prologue up to the chain %lld\n",
+            t[11] - t[10], t[12] - t[11], t[13] - t[12], t[14] - t[13], t[15], t[16] - t[10]);
   }
   if (h->profiling) {
     HIPCHK(h, hipStreamSynchronize(st));
@@ -931,9 +973,16 @@ static int eval_common(gto_handle* h, int B, int n_max, const int32_t* scene_id,
   BatchPtrs bp = make_ptrs(h, (const int32_t*)d_sid, (const double*)d_qc, (const double*)d_goals, (const int32_t*)d_ng,
                            (const double*)d_so, (const double*)d_base, (const double*)d_Q0);
   HIPCHK(h, hipMemsetAsync(bp.n_done, 0, sizeof(int32_t), h->stream));
-  hipLaunchKernelGGL(k_lm_init, dim3(B), dim3(64), 0, h->stream, h->d_rb, bp, sp, B, 1 /* raw: evaluate Q as given */);
+  hipLaunchKernelGGL(k_lm_init, dim3(B), dim3(256), 0, h->stream, h->d_rb, bp, sp, B, 1 /* raw: evaluate Q as given */);
   if ((rc = launch_obstacle(h, h->stream, bp, sp, B, 0, 4, 1, false))) return rc;
-  if ((rc = launch_obstacle(h, h->stream, bp, sp, B, 2, (int)T - 2, 0, false))) return rc;
+  h->last_launches = 0;
+  if ((rc = launch_obstacle(h, h->stream, bp, sp, B, 2, (int)T - 2, 0, h->profiling))) return rc;
+  if (h->profiling) {
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    float ms = 0.f;
+    HIPCHK(h, hipEventElapsedTime(&ms, h->ev[0], h->ev[1]));
+    h->last_ms = ms;
+  }
   states.resize(B);
   blocks.resize((size_t)B * T * BLK_STRIDE);
   ssfixed.resize((size_t)B * 4);

@@ -22,6 +22,12 @@ struct RobotDev {
   int32_t n_frames, ndof, n_opt, n_links, n_points, n_chunks, n_gripper_points;
   int32_t frame_ee, frame_gripper;
   int32_t fk_rounds;  // ceil(log2(depth of the kinematic tree)): pointer-jumping rounds of the parallel FK
+  int32_t opt_frame[GTO_MAX_OPT];  // frame whose joint is optimised joint j
+  // operands of fk_mfma_tree, 16 doubles (entry e = 4*row + col of a 4x4 homogeneous matrix) each:
+  // per frame the origin O, c0 = h + u u^T, c1 = delta - u u^T, K = [u]x (prismatic: the axis in the
+  // translation column); then per link its visual origin; then per optimised joint U = [u;0 | e4]
+  // ... then link_frame [L], opt_frame [n], prismatic flag [n], parent [F] as doubles (packed for the actual F, L, n)
+  double fk_tab[65 * GTO_MAX_FRAMES + 17 * GTO_MAX_LINKS + 18 * GTO_MAX_OPT];
   int32_t parent[GTO_MAX_FRAMES];
   int32_t joint_type[GTO_MAX_FRAMES];
   int32_t q_index[GTO_MAX_FRAMES];

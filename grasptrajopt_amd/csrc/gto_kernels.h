@@ -32,6 +32,7 @@ struct InstState {
 
 struct SolveParams {
   int32_t T, ts, use_standoff, n_max, max_iter, grad_mode;
+  int32_t dbg_cut;  // debug: leave the obstacle kernel after phase k (1 prologue, 2 broad phase, 3 loop); 0 = off
   double dt, alpha, w_obstacle, w_vel, tol_step, tol_rel_f, lambda0;
 };
 
@@ -342,6 +343,127 @@ __device__ inline void screw_of_frame(const RobotDev* rb, int i, const double* F
   }
 }
 
+// quad permutation (4 consecutive lanes) of a double through DPP: no LDS traffic
+template <int P0, int P1, int P2, int P3>
+__device__ inline double quad_perm(double v) {
+  constexpr int ctrl = P0 | (P1 << 2) | (P2 << 4) | (P3 << 6);
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, ctrl, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, ctrl, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+
+// doubles of RobotDev::fk_tab in use: per frame O, c0, c1, K; per link Vo; per optimised joint U (16 each);
+// then link_frame [L], opt_frame [n], prismatic flag [n], parent [F] stored as doubles
+__host__ __device__ inline int fk_tab_doubles(int F, int L, int n) { return 64 * F + 16 * L + 16 * n + L + 2 * n + F; }
+// LDS scratch (doubles) of fk_mfma_tree next to the table: X ping-pong [2][F][16], a dummy store target [64],
+// ancestors [2][GTO_MAX_FRAMES] int
+__host__ __device__ inline int fk_scratch_doubles(int F) { return 32 * F + 64 + GTO_MAX_FRAMES; }
+
+// Forward kinematics of ONE configuration by a 256-thread workgroup on the FP64 matrix cores: visual
+// transforms of the collision links (gto/gto_models.py:92-100) and world screws of the optimised joints.
+//
+// The frame transforms (optas/models.py:826-868) are products of 4x4 homogeneous matrices, and
+// v_mfma_f64_4x4x4f64 computes four independent 4x4x4 FP64 products per instruction (a "block" is 16 lanes;
+// measured lane maps, tools/probes/mfma_f64_probe.hip: A[i][k] in lane 16k + 4 blk + i, B[k][j] in lane
+// 16k + 4 blk + j, D[i][j] in lane 16i + 4 blk + j).  A wave alone on its SIMD issues in order at roughly
+// ten cycles per instruction, and a dependent FP64 result costs 35-50 cycles
+// (tools/probes/fp64_latency_probe.hip): what counts is the number of instructions on the longest
+// dependent path, not flops.  Hence: block = frame, wave = group of four frames, and the chain over the
+// kinematic tree is a parallel prefix (pointer jumping): round r replaces G_f by G_anc(f) G_f and anc(f) by
+// anc(anc(f)); after ceil(log2(depth)) rounds every G_f is global.  A round is one LDS exchange, one MFMA
+// and one barrier.  Everything is kept transposed (X = G^T, so that a D result has the B layout): local
+// X_f = M_f^T O_f^T, round X_f <- X_f X_anc.
+//   M = c0 + cos c1 + sin K entrywise with c0 = h + u u^T, c1 = delta - u u^T, K = [u]x (Rodrigues,
+//   optas/spatialmath.py:90-100); prismatic: sin := q, cos := 1, K = axis in the translation column.
+// Outputs: block = link, V^T = Vo^T X_frame(link); block = optimised joint, [a o]^T = U^T X_frame(joint)
+// with U = [u;0 | e4], screw = (a ; o x a) or (0 ; a) for a prismatic joint.
+//   s_tab  LDS copy of RobotDev::fk_tab       s_sc [F][2] sin, cos | q, 1 | 0, 1 per frame
+//   s_X    [2][F][16] + dummy [64] scratch    s_anc [2][GTO_MAX_FRAMES] scratch
+// Every thread of the workgroup must call it (it contains barriers); the results are visible after it.
+__device__ inline void fk_mfma_tree(const RobotDev* __restrict__ rb, const double* __restrict__ s_tab,
+                                    const double* __restrict__ s_sc, double* __restrict__ s_X, int* __restrict__ s_anc,
+                                    int tid, double* __restrict__ s_vis, double* __restrict__ s_screw,
+                                    long long* dbgp = nullptr) {
+  const int F = rb->n_frames, L = rb->n_links, n = rb->n_opt;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int ra = lane >> 4, rc = lane & 3, blk = (lane >> 2) & 3;
+  const int e = 4 * ra + rc, et = 4 * rc + ra;
+  const double ident = (ra == rc) ? 1.0 : 0.0;
+  const int nGf = (F + 3) >> 2;
+  double* s_dummy = s_X + 32 * F;  // target of the stores of blocks that have nothing to say
+  const double* tVo = s_tab + 64 * F;
+  const double* tU = tVo + 16 * L;
+  const double* tI = tU + 16 * n;  // link_frame [L], opt_frame [n], prismatic flag [n], parent [F] as doubles
+  constexpr int KW = GTO_MAX_FRAMES / 16;  // groups per wave
+  int areg[KW];                            // ancestor of this lane's frame, carried from round to round
+  if (dbgp && tid == 0) dbgp[0] = clock64();
+  // local transforms X_f = (O_f M_f)^T: A operand M^T (lane supplies M[l>>4][l&3]), B operand O^T
+#pragma unroll
+  for (int k = 0; k < KW; ++k) {
+    const int g = wave + 4 * k;
+    if (g >= nGf) continue;  // wave-uniform
+    const int f0 = 4 * g + blk, f = f0 < F ? f0 : F - 1;
+    const double* kt = s_tab + 64 * f;
+    const double sn = s_sc[2 * f], cs = s_sc[2 * f + 1];
+    const double Me = fma(sn, kt[48 + e], fma(cs, kt[32 + e], kt[16 + e]));
+    const double X = __builtin_amdgcn_mfma_f64_4x4x4f64(Me, kt[et], 0.0, 0, 0, 0);
+    areg[k] = (int)tI[L + 2 * n + f];
+    *(f0 < F ? s_X + 16 * f + e : s_dummy + lane) = X;
+    s_anc[f] = areg[k];  // sixteen lanes, one value
+  }
+  __syncthreads();
+  if (dbgp && tid == 0) dbgp[1] = clock64();
+  int cur = 0;
+  for (int rd = 0; rd < rb->fk_rounds; ++rd) {
+    const double* Xc = s_X + cur * 16 * F;
+    double* Xw = s_X + (1 - cur) * 16 * F;
+    const int* Ac = s_anc + cur * GTO_MAX_FRAMES;
+    int* Aw = s_anc + (1 - cur) * GTO_MAX_FRAMES;
+#pragma unroll
+    for (int k = 0; k < KW; ++k) {
+      const int g = wave + 4 * k;
+      if (g >= nGf) continue;
+      const int f0 = 4 * g + blk, f = f0 < F ? f0 : F - 1;
+      const int a = areg[k], ac = a >= 0 ? a : 0;
+      const double Aop = Xc[16 * f + et];  // A[i][k] = X_f[i][k]
+      const double Bx = Xc[16 * ac + e];   // B[k][j] = X_anc[k][j]
+      const int a2x = Ac[ac];
+      const double X = __builtin_amdgcn_mfma_f64_4x4x4f64(Aop, a >= 0 ? Bx : ident, 0.0, 0, 0, 0);
+      areg[k] = a >= 0 ? a2x : -1;
+      *(f0 < F ? Xw + 16 * f + e : s_dummy + lane) = X;
+      Aw[f] = areg[k];
+    }
+    __syncthreads();
+    cur = 1 - cur;
+    if (dbgp && tid == 0) dbgp[2 + rd] = clock64();
+  }
+  const double* Xg = s_X + cur * 16 * F;  // X_f = G_f^T, row-major
+  // output groups: first the links (four per MFMA), then the optimised joints, dealt round-robin to the waves
+  const int nGl = (L + 3) >> 2, nGj = (n + 3) >> 2;
+  for (int og = wave; og < nGl + nGj; og += 4) {
+    if (og < nGl) {
+      // D lane l holds V^T[l>>4][l&3] = V[l&3][l>>4]
+      const int l1 = 4 * og + blk, l = l1 < L ? l1 : L - 1;
+      const double V = __builtin_amdgcn_mfma_f64_4x4x4f64(tVo[16 * l + e], Xg[16 * (int)tI[l] + e], 0.0, 0, 0, 0);
+      *((l1 < L && rc < 3) ? s_vis + 12 * l + 4 * rc + ra : s_dummy + lane) = V;
+    } else {
+      // lanes 0-15 of a block row hold a = R u, lanes 16-31 o = frame origin
+      const int j1 = 4 * (og - nGl) + blk, j = j1 < n ? j1 : n - 1;
+      const bool prism = tI[L + n + j] != 0.0;
+      const double S = __builtin_amdgcn_mfma_f64_4x4x4f64(tU[16 * j + e], Xg[16 * (int)tI[L + j] + e], 0.0, 0, 0, 0);
+      const double av = S, ov = __shfl(S, (lane + 16) & 63, 64);
+      const double a1 = quad_perm<1, 2, 0, 3>(av), a2 = quad_perm<2, 0, 1, 3>(av);
+      const double o1 = quad_perm<1, 2, 0, 3>(ov), o2 = quad_perm<2, 0, 1, 3>(ov);
+      const double cr = o1 * a2 - o2 * a1;
+      const bool w = j1 < n && ra == 0 && rc < 3;
+      *(w ? s_screw + 6 * j + rc : s_dummy + lane) = prism ? 0.0 : av;
+      *(w ? s_screw + 6 * j + 3 + rc : s_dummy + lane) = prism ? av : cr;
+    }
+  }
+  if (dbgp && tid == 0) dbgp[7] = clock64();
+}
+
 // Kinematics of one configuration: visual transforms of the collision links, world screws of the
 // optimised joints and (optionally) the gripper / ee frames. Runs in ONE thread (private scratch).
 __device__ inline void kin_eval(const RobotDev* rb, const double* q, double* vis, double* screw, double* grip_ee) {
@@ -459,16 +581,18 @@ __global__ void k_dist_relax(const uint8_t* __restrict__ in, uint8_t* __restrict
 //   main loop one link-uniform chunk of 64 Morton-sorted surface points per wave step (sparse wrench lists)
 //   epilogue  per-link 6x6 wrench Grams -> J^T J (n x n), J^T r (n), sum c^2 per waypoint
 struct ObsLds {  // dynamic LDS layout (offsets in doubles), computed identically on host and device
-  int q, fr, vis, screw, gram, out, list, active, total_doubles;
+  int q, vis, screw, gram, out, list, active, total_doubles;
   __host__ __device__ ObsLds(int TG, int F, int L, int cap_active) {
     int o = 0;
     q = o;      o += TG * GTO_MAX_DOF;
-    fr = o;     o += TG * F * 12;
     vis = o;    o += TG * L * 12;
     screw = o;  o += TG * GTO_MAX_OPT * 6;
     gram = o;   o += 4 * TG * L * GTO_GRAM;  // one private copy per wave, summed in wave order (deterministic)
     out = o;    o += TG * BLK_STRIDE;
-    list = o;   o += 4 * GTO_LIST_CAP * 8 > TG * F * 12 ? 4 * GTO_LIST_CAP * 8 : TG * F * 12;  // also FK pong buffer / s_u
+    // also, in the prologue: operand table, sin/cos [TG][F][2] and scratch of fk_mfma_tree; in the epilogue
+    // s_u; in the goal workgroups their scratch
+    const int fk = fk_tab_doubles(F, L, GTO_MAX_OPT) + TG * F * 2 + fk_scratch_doubles(F);
+    list = o;   o += 4 * GTO_LIST_CAP * 8 > fk ? 4 * GTO_LIST_CAP * 8 : fk;
     active = o; o += cap_active * 2;  // int4 per entry
     total_doubles = o;
   }
@@ -488,7 +612,6 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
                                                        BatchPtrs bp, SolveParams sp, int B, int t_begin, int nT,
                                                        int fixed_mode, int n_regular, int TG, int cap_active) {
   extern __shared__ __attribute__((aligned(16))) double smem_obs[];
-  __shared__ int s_parent[GTO_MAX_FRAMES], s_parentB[GTO_MAX_FRAMES];
   __shared__ int s_wcount[4];
   __shared__ int s_nactive;
   __shared__ unsigned s_touched[GTO_MAX_TG];  // per waypoint of the group: links whose Gram got a contribution
@@ -498,15 +621,15 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
   const int L = rb->n_links, n = rb->n_opt, T = sp.T, ndof = rb->ndof, F = rb->n_frames;
   const ObsLds lay(TG, F, L, cap_active);
   double* s_q = smem_obs + lay.q;
-  double* s_fr = smem_obs + lay.fr;
   double* s_vis = smem_obs + lay.vis;
   double* s_screw = smem_obs + lay.screw;
   double* s_gram = smem_obs + lay.gram;
   double* s_out = smem_obs + lay.out;
   double* s_list = smem_obs + lay.list;
+  double* s_ktab = s_list;                      // prologue only
+  double* s_sc = s_list + fk_tab_doubles(F, L, n);  // prologue only
   int4* s_active = reinterpret_cast<int4*>(smem_obs + lay.active);
   double* s_u = s_list;    // [L][GTO_MAX_OPT][6] in the epilogue
-  double* s_frB = s_list;  // FK ping-pong buffer in the prologue
 
   // Extra workgroups (blockIdx >= n_regular), one per instance: goal-set terms and velocity term of the
   // trial trajectory.  The step kernel only needs them at its NEXT launch, so they ride in the shadow
@@ -547,6 +670,10 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
     s_q[kq * GTO_MAX_DOF + i] = (j >= 0) ? bp.Qtry[((size_t)b * n + j) * T + t0w + kq]
                                          : bp.Q0[((size_t)b * ndof + i) * T + t0w + kq];
   }
+  {  // operand table of fk_mfma_tree into the (still unused) list region
+    const int nt = fk_tab_doubles(F, L, n);  // rb->fk_tab is packed for exactly this (F, L, n)
+    for (int k = tid; k < nt; k += 256) s_ktab[k] = rb->fk_tab[k];
+  }
   // Temporal culling (exact): if at configuration qref every chunk of this waypoint was at least
   // `margin` voxels clear of any non-zero voxel, and no surface point can have moved further than that
   // since (|dx| <= sum_j |dq_j| reach_j), the waypoint still contributes exact zeros: write them and leave.
@@ -569,111 +696,36 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
       __syncthreads();
     }
   }
-  if (tid < F) s_parent[tid] = rb->parent[tid];
   for (int i = tid; i < 4 * ng * L * GTO_GRAM; i += 256) s_gram[i] = 0.0;
   if (tid < 4 * GTO_MAX_TG) (&s_ssw[0][0])[tid] = 0.0;
   for (int i = tid; i < ng * BLK_STRIDE; i += 256) s_out[i] = 0.0;
   if (tid < GTO_MAX_TG) s_touched[tid] = 0u;
   if (tid == 0) s_nactive = 0;
   __syncthreads();
-  if (dbg_wg && tid == 0) bp.dbg[16] = clock64();
-  // local transforms L_i = origin_i @ joint_motion_i(q) for every (waypoint, frame)
+  // sin/cos of every (waypoint, joint), one lane each; then ONE wavefront runs the frame chain on the FP64
+  // matrix cores (fk_mfma_wave) while the other three have nothing to wait for but the barrier
   for (int idx = tid; idx < ng * F; idx += 256) {
-    const int kq = idx / F, i = idx % F;
+    const int kq = idx / F, i = idx - kq * F;
     const int jt = rb->joint_type[i];
-    const double* O = rb->origin[i];
-    double* Lo = s_fr + (kq * F + i) * 12;
-    if (jt == GTO_JOINT_REVOLUTE) {
-      // Rodrigues about the unit axis u: R = cos*I + sin*[u]x + (1-cos) u u^T (optas/spatialmath.py:90-100)
-      const double th = s_q[kq * GTO_MAX_DOF + rb->q_index[i]];
-      double sn, cs;
-      sincos(th, &sn, &cs);
-      const double c1 = 1.0 - cs, u0 = rb->axis_unit[i][0], u1 = rb->axis_unit[i][1], u2 = rb->axis_unit[i][2];
-      const double R00 = cs + c1 * u0 * u0, R01 = c1 * u0 * u1 - sn * u2, R02 = c1 * u0 * u2 + sn * u1;
-      const double R10 = c1 * u1 * u0 + sn * u2, R11 = cs + c1 * u1 * u1, R12 = c1 * u1 * u2 - sn * u0;
-      const double R20 = c1 * u2 * u0 - sn * u1, R21 = c1 * u2 * u1 + sn * u0, R22 = cs + c1 * u2 * u2;
-#pragma unroll
-      for (int r = 0; r < 3; ++r) {
-        const double o0 = O[4 * r], o1 = O[4 * r + 1], o2 = O[4 * r + 2];
-        Lo[4 * r] = o0 * R00 + o1 * R10 + o2 * R20;
-        Lo[4 * r + 1] = o0 * R01 + o1 * R11 + o2 * R21;
-        Lo[4 * r + 2] = o0 * R02 + o1 * R12 + o2 * R22;
-        Lo[4 * r + 3] = O[4 * r + 3];
-      }
-    } else if (jt == GTO_JOINT_PRISMATIC) {
-      const double qi = s_q[kq * GTO_MAX_DOF + rb->q_index[i]];
-      const double t0 = qi * rb->axis_unit[i][0], t1 = qi * rb->axis_unit[i][1], t2 = qi * rb->axis_unit[i][2];
-#pragma unroll
-      for (int r = 0; r < 3; ++r) {
-        const double o0 = O[4 * r], o1 = O[4 * r + 1], o2 = O[4 * r + 2];
-        Lo[4 * r] = o0;
-        Lo[4 * r + 1] = o1;
-        Lo[4 * r + 2] = o2;
-        Lo[4 * r + 3] = o0 * t0 + o1 * t1 + o2 * t2 + O[4 * r + 3];
-      }
-    } else {
-#pragma unroll
-      for (int k2 = 0; k2 < 12; ++k2) Lo[k2] = O[k2];
-    }
+    double a = 0.0, c = 1.0;
+    if (jt == GTO_JOINT_REVOLUTE) sincos(s_q[kq * GTO_MAX_DOF + rb->q_index[i]], &a, &c);
+    else if (jt == GTO_JOINT_PRISMATIC) a = s_q[kq * GTO_MAX_DOF + rb->q_index[i]];
+    s_sc[2 * idx] = a;
+    s_sc[2 * idx + 1] = c;
   }
   __syncthreads();
-  if (dbg_wg && tid == 0) bp.dbg[17] = clock64();
-  // global transforms by pointer jumping over the kinematic tree (parallel prefix of the chain
-  // products): every round replaces M_i by M_anc(i) @ M_i and anc(i) by anc(anc(i)); after
-  // ceil(log2(depth)) rounds M_i is the global transform of frame i (all waypoints at once).
+  if (dbg_wg && tid == 0) bp.dbg[16] = clock64();
   {
-    double* Ma = s_fr;
-    double* Mb = s_frB;
-    int* Aa = s_parent;
-    int* Ab = s_parentB;
-    const int FE = F * 12;
-    for (int rd = 0; rd < rb->fk_rounds; ++rd) {
-      for (int idx = tid; idx < ng * FE; idx += 256) {
-        const int kq = idx / FE, rem = idx % FE, i = rem / 12, e = rem % 12, rr = e >> 2, cc = e & 3;
-        const int a = Aa[i];
-        const double* Mk = Ma + kq * FE;
-        double v;
-        if (a >= 0) {
-          const double* P = Mk + 12 * a + 4 * rr;
-          const double* Lm = Mk + 12 * i;
-          v = P[0] * Lm[cc] + P[1] * Lm[4 + cc] + P[2] * Lm[8 + cc];
-          if (cc == 3) v += P[3];
-        } else {
-          v = Mk[rem];
-        }
-        Mb[idx] = v;
-        if (kq == 0 && e == 0) Ab[i] = (a >= 0) ? Aa[a] : -1;
-      }
-      __syncthreads();
-      double* tM = Ma;
-      Ma = Mb;
-      Mb = tM;
-      int* tA = Aa;
-      Aa = Ab;
-      Ab = tA;
+    double* s_X = s_sc + 2 * ng * F;
+    for (int kq = 0; kq < ng; ++kq) {
+      fk_mfma_tree(rb, s_ktab, s_sc + 2 * kq * F, s_X, reinterpret_cast<int*>(s_X + 32 * F + 64), tid, s_vis + kq * L * 12,
+                   s_screw + kq * GTO_MAX_OPT * 6, dbg_wg ? bp.dbg + 20 : nullptr);
+      if (kq + 1 < ng) __syncthreads();  // scratch reuse
     }
-    if (Ma != s_fr) {  // odd number of rounds: results live in the pong buffer
-      for (int idx = tid; idx < ng * FE; idx += 256) s_fr[idx] = Ma[idx];
-      __syncthreads();
-    }
-  }
-  if (dbg_wg && tid == 0) bp.dbg[18] = clock64();
-  // visual_tf = link_tf @ visual origin (gto/gto_models.py:92-100)
-  for (int idx = tid; idx < ng * L * 12; idx += 256) {
-    const int kq = idx / (L * 12), rem = idx % (L * 12), l = rem / 12, e = rem % 12, r = e >> 2, c = e & 3;
-    const double* Fr = s_fr + (kq * F + rb->link_frame[l]) * 12 + 4 * r;
-    const double* Vo = rb->vis_origin[l];
-    double v = Fr[0] * Vo[c] + Fr[1] * Vo[4 + c] + Fr[2] * Vo[8 + c];
-    if (c == 3) v += Fr[3];
-    s_vis[idx] = v;
-  }
-  // world screws (a ; o x a) of the optimised joints
-  for (int idx = tid; idx < ng * F; idx += 256) {
-    const int kq = idx / F, i = idx % F, j = rb->opt_of_frame[i];
-    if (j >= 0) screw_of_frame(rb, i, s_fr + (kq * F + i) * 12, s_screw + (kq * GTO_MAX_OPT + j) * 6);
   }
   __syncthreads();
   if (dbg_wg && tid == 0) bp.dbg[11] = clock64();
+  if (sp.dbg_cut == 1) return;
 
   const SceneDev sc = scenes[bp.scene_id[b]];
   const double bx = bp.base_pos[3 * b], by = bp.base_pos[3 * b + 1], bz = bp.base_pos[3 * b + 2];
@@ -752,6 +804,7 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
   // contiguous range of surviving chunks per wave
   const int c0 = (int)(((long)NA * wave) / 4), c1 = (int)(((long)NA * (wave + 1)) / 4);
   if (dbg_wg && tid == 0) bp.dbg[12] = clock64();
+  if (sp.dbg_cut == 2) return;
 
   // Sparse Gram accumulation.  Most surface points are in free space (zero gradient): a lane whose
   // point has a non-zero gradient appends its wrench (y x w, w) and cost c to a small per-wave LDS
@@ -901,6 +954,7 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
 #undef GTO_FLUSH
 #undef GTO_DRAIN
   if (dbg_wg && tid == 0) bp.dbg[13] = clock64();
+  if (sp.dbg_cut == 3) return;
   __syncthreads();
   // fold the four per-wave copies in wave order: the result does not depend on which wave ran first
   {
@@ -1206,15 +1260,15 @@ __device__ inline void trial_goal_terms_wave(const RobotDev* rb, const BatchPtrs
 }
 
 // raw != 0: take Q0's optimised rows as they are (evaluation entry points); otherwise build the seed.
-__global__ __launch_bounds__(64) void k_lm_init(const RobotDev* __restrict__ rb, BatchPtrs bp, SolveParams sp, int B, int raw) {
-  const int b = blockIdx.x, lane = threadIdx.x;
+__global__ __launch_bounds__(256) void k_lm_init(const RobotDev* __restrict__ rb, BatchPtrs bp, SolveParams sp, int B, int raw) {
+  const int b = blockIdx.x, tid = threadIdx.x;
   __shared__ double s_gaff[48];
   __shared__ double s_gscr[2 * GTO_MAX_OPT * 6];
   __shared__ double s_q[2 * GTO_MAX_DOF];
   __shared__ double s_fr[2 * GTO_MAX_FRAMES * 12];
   const int T = sp.T, n = rb->n_opt;
   InstState* st = bp.state + b;
-  if (lane == 0) {
+  if (tid == 0) {
     st->f = INFINITY;
     st->lambda = sp.lambda0;
     st->nu = 2.0;
@@ -1226,12 +1280,12 @@ __global__ __launch_bounds__(64) void k_lm_init(const RobotDev* __restrict__ rb,
     st->evals = 0;
     st->argmin_cur = 0;
   }
-  for (int t = lane; t < T; t += 64) bp.margin[(size_t)b * T + t] = -1;
+  for (int t = tid; t < T; t += 256) bp.margin[(size_t)b * T + t] = -1;
   // seed: optimised rows of Q0, first two waypoints pinned to qc, the rest clipped into the bounds
   const double* Q0b = bp.Q0 + (size_t)b * rb->ndof * T;
   double* Qt = bp.Qtry + (size_t)b * n * T;
   double* Qc = bp.Qcur + (size_t)b * n * T;
-  for (int idx = lane; idx < n * T; idx += 64) {
+  for (int idx = tid; idx < n * T; idx += 256) {
     const int j = idx / T, t = idx % T;
     double v = Q0b[(size_t)rb->opt_index[j] * T + t];
     if (!raw) {
@@ -1242,7 +1296,7 @@ __global__ __launch_bounds__(64) void k_lm_init(const RobotDev* __restrict__ rb,
     Qc[idx] = v;
   }
   __syncthreads();
-  trial_goal_terms_wave(rb, bp, sp, B, b, lane, 1, st, s_q, s_fr, s_gaff, s_gscr);
+  if (tid < 64) trial_goal_terms_wave(rb, bp, sp, B, b, tid, 1, st, s_q, s_fr, s_gaff, s_gscr);
 }
 
 // 1/x to full double precision: hardware seed + two Newton steps (no IEEE division sequence)
@@ -1253,8 +1307,8 @@ __device__ inline double fast_rcp(double x) {
   return r;
 }
 
-// dynamic LDS layout of k_lm_step (doubles): Z [m][64] | A [m][64] | bfull [m][8] | y [m][8] | e [m][8] |
-// x [m][8] | Q [8][T] | gaff [48] | gscr [96] | q [64] | frames [2*32*12] | red [16] ; then int act [m][8].
+// dynamic LDS layout of k_lm_step (doubles): Z [m][64] | y [m][8] | e [m][8] | A [m][64] | bfull [m][8] |
+// x [m][8] | Q [8][T] | gaff [16] | red [16] ; then int act [m][8] ; then the kinematics scratch of
 // One workgroup of four wavefronts per instance.  Lane (r,c) = (lane>>3, lane&7) of a wave owns entry
 // (r,c) of the 8x8 blocks; the data-parallel phases (assembly, projected step, predicted decrease) are
 // spread over the four waves by waypoint, the serial block recursion runs on wave 0.
@@ -1265,17 +1319,14 @@ __global__ __launch_bounds__(256) void k_lm_step(const RobotDev* __restrict__ rb
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int T = sp.T, n = rb->n_opt, m = T - 2;
   double* s_Z = smem;
-  double* s_A = s_Z + (size_t)m * 64;
-  double* s_b = s_A + (size_t)m * 64;
-  double* s_y = s_b + m * 8;
+  double* s_y = s_Z + (size_t)m * 64;
   double* s_e = s_y + m * 8;
-  double* s_x = s_e + m * 8;
+  double* s_A = s_e + m * 8;
+  double* s_b = s_A + (size_t)m * 64;
+  double* s_x = s_b + m * 8;
   double* s_Q = s_x + m * 8;
   double* s_gaff = s_Q + 8 * T;
-  double* s_gscr = s_gaff + 48;
-  double* s_q = s_gscr + 2 * GTO_MAX_OPT * 6;
-  double* s_fr = s_q + 2 * GTO_MAX_DOF;
-  double* s_red = s_fr + 2 * GTO_MAX_FRAMES * 12;  // [16] cross-wave scratch
+  double* s_red = s_gaff + 16;  // [16] cross-wave scratch
   int* s_act = (int*)(s_red + 16);                 // [m][8]
   unsigned long long* s_dmask = (unsigned long long*)(s_red + 8);
 
