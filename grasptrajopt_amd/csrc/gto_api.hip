@@ -37,7 +37,7 @@ struct gto_handle {
   SceneDev* d_scenes = nullptr;
   size_t d_scenes_cap = 0;
   // solve workspace (grown on demand)
-  DevBuf state, Qcur, Qtry, vis, screw, blocks, goalblk, ssfixed, ndone, qref, margin;
+  DevBuf state, Qcur, Qtry, vis, screw, blocks, goalblk, ssfixed, ndone, qref, margin, qf;
   int32_t* h_ndone = nullptr;  // pinned
   int check_every = 8;
   int dbg_cut = 0;  // GTO_DEBUG_CUT: timing experiments only, results are garbage
@@ -419,7 +419,7 @@ void gto_destroy(gto_handle* h) {
   (void)hipFree(h->d_plink);
   (void)hipFree(h->d_perm);
   (void)hipFree(h->d_chunks);
-  DevBuf* bufs[] = {&h->state, &h->Qcur, &h->Qtry, &h->vis, &h->screw, &h->blocks, &h->goalblk, &h->ssfixed, &h->ndone, &h->qref, &h->margin};
+  DevBuf* bufs[] = {&h->state, &h->Qcur, &h->Qtry, &h->vis, &h->screw, &h->blocks, &h->goalblk, &h->ssfixed, &h->ndone, &h->qref, &h->margin, &h->qf};
   if (h->h_ndone) (void)hipHostFree(h->h_ndone);
   for (int g = 0; g < GTO_MAX_GROUPS; ++g) {
     if (h->gstream[g]) (void)hipStreamDestroy(h->gstream[g]);
@@ -631,6 +631,7 @@ static int ensure_workspace(gto_handle* h, int B) {
   if ((rc = ensure(h, h->goalblk, (size_t)2 * B * 2 * BLK_STRIDE * sizeof(double)))) return rc;
   if ((rc = ensure(h, h->ssfixed, (size_t)B * 4 * sizeof(double)))) return rc;
   if ((rc = ensure(h, h->ndone, 64))) return rc;
+  if ((rc = ensure(h, h->qf, (size_t)B * T * rb.n_frames * sizeof(double)))) return rc;
   if ((rc = ensure(h, h->qref, (size_t)B * T * GTO_MAX_OPT * sizeof(double)))) return rc;
   if ((rc = ensure(h, h->margin, (size_t)B * T * sizeof(int32_t)))) return rc;
   if (!h->h_ndone) HIPCHK(h, hipHostMalloc((void**)&h->h_ndone, 64));
@@ -654,6 +655,7 @@ static BatchPtrs make_ptrs(gto_handle* h, const int32_t* scene_id, const double*
   bp.goalblk = (double*)h->goalblk.p;
   bp.ss_fixed = (double*)h->ssfixed.p;
   bp.n_done = (int32_t*)h->ndone.p;
+  bp.qf = (double*)h->qf.p;
   bp.qref = (double*)h->qref.p;
   bp.margin = (int32_t*)h->margin.p;
   bp.dbg = h->dbg;
@@ -755,6 +757,7 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
     gr.bp.goalblk += 2 * o * 2 * BLK_STRIDE;
     gr.bp.ss_fixed += o * 4;
     gr.bp.n_done += g;
+    gr.bp.qf += o * T * h->rb.n_frames;
     gr.bp.qref += o * T * GTO_MAX_OPT;
     gr.bp.margin += o * T;
     if (G > 1) HIPCHK(h, hipStreamWaitEvent(gr.st, h->ev_fork, 0));

@@ -53,6 +53,7 @@ struct BatchPtrs {
   double* goalblk;   // [2][B][2][BLK_STRIDE]
   double* ss_fixed;  // [B][4]  sum c^2 of the two pinned waypoints; of the static links under c_all / c_obs
   int32_t* n_done;   // [1]     instances that have finished
+  double* qf;        // [B][T][F] joint value of every frame of the trial trajectory (0 for fixed joints)
   double* qref;      // [B][T][GTO_MAX_OPT] configuration at which `margin` was measured
   int32_t* margin;   // [B][T] voxels of clearance left at qref when the whole waypoint was in free space, else -1
   long long* dbg;    // optional: phase timestamps of instance 0's step kernel (GTO_DEBUG_TIMING)
@@ -581,10 +582,9 @@ __global__ void k_dist_relax(const uint8_t* __restrict__ in, uint8_t* __restrict
 //   main loop one link-uniform chunk of 64 Morton-sorted surface points per wave step (sparse wrench lists)
 //   epilogue  per-link 6x6 wrench Grams -> J^T J (n x n), J^T r (n), sum c^2 per waypoint
 struct ObsLds {  // dynamic LDS layout (offsets in doubles), computed identically on host and device
-  int q, vis, screw, gram, out, list, active, total_doubles;
+  int vis, screw, gram, out, list, active, total_doubles;
   __host__ __device__ ObsLds(int TG, int F, int L, int cap_active) {
     int o = 0;
-    q = o;      o += TG * GTO_MAX_DOF;
     vis = o;    o += TG * L * 12;
     screw = o;  o += TG * GTO_MAX_OPT * 6;
     gram = o;   o += 4 * TG * L * GTO_GRAM;  // one private copy per wave, summed in wave order (deterministic)
@@ -620,7 +620,6 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
   const int bid = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int L = rb->n_links, n = rb->n_opt, T = sp.T, ndof = rb->ndof, F = rb->n_frames;
   const ObsLds lay(TG, F, L, cap_active);
-  double* s_q = smem_obs + lay.q;
   double* s_vis = smem_obs + lay.vis;
   double* s_screw = smem_obs + lay.screw;
   double* s_gram = smem_obs + lay.gram;
@@ -653,7 +652,6 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
   const int grp_id = kb % nG;
   if (b >= B) return;
   const InstState* st = bp.state + b;
-  if (st->done) return;
   // fixed mode evaluates four "virtual waypoints": 0,1 = the two pinned waypoints (all links, value only);
   // 2,3 = the links no optimised joint moves, under c_all and under c_obs (their sum of c^2 is the same
   // at every waypoint and every iteration, so the solve loop never touches those points again)
@@ -664,55 +662,65 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
   const bool dbg_wg = bp.dbg && b == 0 && grp_id == nG - 1;
   if (dbg_wg && tid == 0) bp.dbg[10] = clock64();
 
-  // ---- prologue.  Every global load it needs is issued up front: ONE memory round trip.
-  for (int idx = tid; idx < ng * ndof; idx += 256) {
-    const int kq = idx / ndof, i = idx % ndof, j = rb->opt_of_dof[i];
-    s_q[kq * GTO_MAX_DOF + i] = (j >= 0) ? bp.Qtry[((size_t)b * n + j) * T + t0w + kq]
-                                         : bp.Q0[((size_t)b * ndof + i) * T + t0w + kq];
+  // ---- prologue.  Every global load it needs is issued here, before the first branch that depends on one
+  // of them: ONE memory round trip for the instance state, the culling inputs, the joint values of the
+  // frames (bp.qf, written by the step kernel) and the operand table of fk_mfma_tree.
+  const int done = st->done, slot_cur = st->slot;
+  const bool cull_try = TG == 1 && !fixed_mode;
+  const int mg = cull_try ? bp.margin[(size_t)b * T + t0w] : -1;
+  double dq_try = 0.0, dq_ref = 0.0;
+  if (cull_try && tid < n) {
+    dq_try = bp.Qtry[((size_t)b * n + tid) * T + t0w];
+    dq_ref = bp.qref[((size_t)b * T + t0w) * GTO_MAX_OPT + tid];
   }
-  {  // operand table of fk_mfma_tree into the (still unused) list region
-    const int nt = fk_tab_doubles(F, L, n);  // rb->fk_tab is packed for exactly this (F, L, n)
-    for (int k = tid; k < nt; k += 256) s_ktab[k] = rb->fk_tab[k];
-  }
+  const double qfv = tid < ng * F ? bp.qf[((size_t)b * T + t0w) * F + tid] : 0.0;
+  const int jtv = tid < ng * F ? rb->joint_type[tid % F] : GTO_JOINT_FIXED;
+  const int nt = fk_tab_doubles(F, L, n);  // rb->fk_tab is packed for exactly this (F, L, n)
+  double tabv[6];
+#pragma unroll
+  for (int u = 0; u < 6; ++u) tabv[u] = tid + 256 * u < nt ? rb->fk_tab[tid + 256 * u] : 0.0;
+  if (done) return;
+#pragma unroll
+  for (int u = 0; u < 6; ++u)
+    if (tid + 256 * u < nt) s_ktab[tid + 256 * u] = tabv[u];
+  for (int k = tid + 256 * 6; k < nt; k += 256) s_ktab[k] = rb->fk_tab[k];  // very large robots
   // Temporal culling (exact): if at configuration qref every chunk of this waypoint was at least
   // `margin` voxels clear of any non-zero voxel, and no surface point can have moved further than that
   // since (|dx| <= sum_j |dq_j| reach_j), the waypoint still contributes exact zeros: write them and leave.
-  if (TG == 1 && !fixed_mode) {
-    const int mg = bp.margin[(size_t)b * T + t0w];
-    if (mg >= 0) {  // block-uniform
-      double dsum = 0.0;
-      if (tid < n) {
-        const double dq = bp.Qtry[((size_t)b * n + tid) * T + t0w] - bp.qref[((size_t)b * T + t0w) * GTO_MAX_OPT + tid];
-        dsum = fabs(dq) * rb->reach[tid];
-      }
-      if (tid < 64) dsum = wave_sum(dsum);
-      if (tid == 0) s_nactive = (rb->reach[0] >= 0.0 && (int)ceil(dsum * scenes[bp.scene_id[b]].rinv) <= mg) ? 1 : 0;
-      __syncthreads();
-      if (s_nactive) {
-        double* out = bp.blocks + (((size_t)(1 - st->slot) * B + b) * T + t0w) * BLK_STRIDE;
-        if (tid < BLK_STRIDE) out[tid] = (tid == BLK_SS) ? bp.ss_fixed[4 * b + (t0w < sp.ts ? 2 : 3)] : 0.0;
-        return;
-      }
-      __syncthreads();
+  if (mg >= 0) {  // block-uniform
+    double dsum = tid < n ? fabs(dq_try - dq_ref) * rb->reach[tid] : 0.0;
+    if (tid < 64) dsum = wave_sum(dsum);
+    if (tid == 0) s_nactive = (rb->reach[0] >= 0.0 && (int)ceil(dsum * scenes[bp.scene_id[b]].rinv) <= mg) ? 1 : 0;
+    __syncthreads();
+    if (s_nactive) {
+      double* out = bp.blocks + (((size_t)(1 - slot_cur) * B + b) * T + t0w) * BLK_STRIDE;
+      if (tid < BLK_STRIDE) out[tid] = (tid == BLK_SS) ? bp.ss_fixed[4 * b + (t0w < sp.ts ? 2 : 3)] : 0.0;
+      return;
     }
+    __syncthreads();
+  }
+  // sin/cos of every (waypoint, joint), one lane each
+  if (tid < ng * F) {
+    double a = 0.0, c = 1.0;
+    if (jtv == GTO_JOINT_REVOLUTE) sincos(qfv, &a, &c);
+    else if (jtv == GTO_JOINT_PRISMATIC) a = qfv;
+    s_sc[2 * tid] = a;
+    s_sc[2 * tid + 1] = c;
+  }
+  for (int idx = tid + 256; idx < ng * F; idx += 256) {  // waypoint groups of very large robots
+    const int jt = rb->joint_type[idx % F];
+    const double qv = bp.qf[((size_t)b * T + t0w) * F + idx];
+    double a = 0.0, c = 1.0;
+    if (jt == GTO_JOINT_REVOLUTE) sincos(qv, &a, &c);
+    else if (jt == GTO_JOINT_PRISMATIC) a = qv;
+    s_sc[2 * idx] = a;
+    s_sc[2 * idx + 1] = c;
   }
   for (int i = tid; i < 4 * ng * L * GTO_GRAM; i += 256) s_gram[i] = 0.0;
   if (tid < 4 * GTO_MAX_TG) (&s_ssw[0][0])[tid] = 0.0;
   for (int i = tid; i < ng * BLK_STRIDE; i += 256) s_out[i] = 0.0;
   if (tid < GTO_MAX_TG) s_touched[tid] = 0u;
   if (tid == 0) s_nactive = 0;
-  __syncthreads();
-  // sin/cos of every (waypoint, joint), one lane each; then ONE wavefront runs the frame chain on the FP64
-  // matrix cores (fk_mfma_wave) while the other three have nothing to wait for but the barrier
-  for (int idx = tid; idx < ng * F; idx += 256) {
-    const int kq = idx / F, i = idx - kq * F;
-    const int jt = rb->joint_type[i];
-    double a = 0.0, c = 1.0;
-    if (jt == GTO_JOINT_REVOLUTE) sincos(s_q[kq * GTO_MAX_DOF + rb->q_index[i]], &a, &c);
-    else if (jt == GTO_JOINT_PRISMATIC) a = s_q[kq * GTO_MAX_DOF + rb->q_index[i]];
-    s_sc[2 * idx] = a;
-    s_sc[2 * idx + 1] = c;
-  }
   __syncthreads();
   if (dbg_wg && tid == 0) bp.dbg[16] = clock64();
   {
@@ -795,7 +803,7 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
     for (int o = 32; o > 0; o >>= 1) ms = min(ms, __shfl_xor(ms, o, 64));
     if (lane == 0) s_wcount[wave] = ms;
     __syncthreads();
-    if (tid < n) bp.qref[((size_t)b * T + t0w) * GTO_MAX_OPT + tid] = s_q[rb->opt_index[tid]];
+    if (tid < n) bp.qref[((size_t)b * T + t0w) * GTO_MAX_OPT + tid] = dq_try;
     if (tid == 0) {
       const int mall = min(min(s_wcount[0], s_wcount[1]), min(s_wcount[2], s_wcount[3]));
       bp.margin[(size_t)b * T + t0w] = (NA == 0 && mall >= 2) ? mall - 2 : -1;
@@ -1031,7 +1039,7 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
     // add the constant contribution of the static links (measured once at init)
     if (tid < ng) s_out[tid * BLK_STRIDE + BLK_SS] += bp.ss_fixed[4 * b + ((t0w + tid) < sp.ts ? 2 : 3)];
     __syncthreads();
-    double* out = bp.blocks + (((size_t)(1 - st->slot) * B + b) * T + t0w) * BLK_STRIDE;
+    double* out = bp.blocks + (((size_t)(1 - slot_cur) * B + b) * T + t0w) * BLK_STRIDE;
     for (int i = tid; i < ng * BLK_STRIDE; i += 256) out[i] = s_out[i];
   }
 }
@@ -1296,6 +1304,19 @@ __global__ __launch_bounds__(256) void k_lm_init(const RobotDev* __restrict__ rb
     Qc[idx] = v;
   }
   __syncthreads();
+  {  // joint value of every frame at every waypoint (parameter joints never change afterwards)
+    const int F = rb->n_frames;
+    double* qf = bp.qf + (size_t)b * T * F;
+    for (int idx = tid; idx < T * F; idx += 256) {
+      const int t = idx / F, i = idx - t * F, dq = rb->q_index[i];
+      double v = 0.0;
+      if (dq >= 0) {
+        const int j = rb->opt_of_dof[dq];
+        v = j >= 0 ? Qt[(size_t)j * T + t] : Q0b[(size_t)dq * T + t];
+      }
+      qf[idx] = v;
+    }
+  }
   if (tid < 64) trial_goal_terms_wave(rb, bp, sp, B, b, tid, 1, st, s_q, s_fr, s_gaff, s_gscr);
 }
 
@@ -1333,6 +1354,9 @@ __global__ __launch_bounds__(256) void k_lm_step(const RobotDev* __restrict__ rb
   const int r = lane >> 3, c = lane & 7;
   const int trial = 1 - st->slot;
   const long long t_dbg0 = bp.dbg ? clock64() : 0;
+  // P4 writes joint (tid & 7) of some waypoints: its frame, looked up long before it is needed
+  const int nF = rb->n_frames, my_frame = (tid & 7) < n ? rb->opt_frame[tid & 7] : 0;
+  double* __restrict__ qfb = bp.qf + (size_t)b * T * nF;
 
   // ---- P0: objective of the trial point (every wave computes it: cheaper than a broadcast)
   double fo = 0.0;
@@ -1599,6 +1623,7 @@ __global__ __launch_bounds__(256) void k_lm_step(const RobotDev* __restrict__ rb
       double v = q0 + s_x[idx];
       v = fmin(fmax(v, rb->lower[i]), rb->upper[i]);
       Qt[(size_t)i * T + t] = v;
+      qfb[(size_t)t * nF + my_frame] = v;  // the obstacle kernel reads joint values by frame
       s_Q[i * T + t] = v;
       sv = v - q0;
     }
