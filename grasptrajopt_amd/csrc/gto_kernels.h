@@ -387,7 +387,7 @@ __device__ inline void fk_mfma_tree(const RobotDev* __restrict__ rb, const doubl
                                     int tid, double* __restrict__ s_vis, double* __restrict__ s_screw,
                                     long long* dbgp = nullptr) {
   const int F = rb->n_frames, L = rb->n_links, n = rb->n_opt;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: the compiler must see it as wave-uniform
   const int ra = lane >> 4, rc = lane & 3, blk = (lane >> 2) & 3;
   const int e = 4 * ra + rc, et = 4 * rc + ra;
   const double ident = (ra == rc) ? 1.0 : 0.0;
@@ -617,7 +617,7 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
   __shared__ unsigned s_touched[GTO_MAX_TG];  // per waypoint of the group: links whose Gram got a contribution
   __shared__ double s_ssw[4][GTO_MAX_TG];     // per wave: sum of c^2 of each waypoint of the group
 
-  const int bid = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int bid = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int L = rb->n_links, n = rb->n_opt, T = sp.T, ndof = rb->ndof, F = rb->n_frames;
   const ObsLds lay(TG, F, L, cap_active);
   double* s_vis = smem_obs + lay.vis;
@@ -1334,7 +1334,7 @@ __device__ inline double fast_rcp(double x) {
 // (r,c) of the 8x8 blocks; the data-parallel phases (assembly, projected step, predicted decrease) are
 // spread over the four waves by waypoint, the serial block recursion runs on wave 0.
 __global__ __launch_bounds__(256) void k_lm_step(const RobotDev* __restrict__ rb, BatchPtrs bp, SolveParams sp, int B) {
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   InstState* st = bp.state + b;
   if (st->done) return;
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -1348,7 +1348,7 @@ __global__ __launch_bounds__(256) void k_lm_step(const RobotDev* __restrict__ rb
   double* s_Q = s_x + m * 8;
   double* s_gaff = s_Q + 8 * T;
   double* s_red = s_gaff + 16;  // [16] cross-wave scratch
-  int* s_act = (int*)(s_red + 16);                 // [m][8]
+  int* s_actm = (int*)(s_red + 16);                // [m] frozen-joint bit masks (room for [m][8])
   unsigned long long* s_dmask = (unsigned long long*)(s_red + 8);
 
   const int r = lane >> 3, c = lane & 7;
@@ -1471,6 +1471,7 @@ __global__ __launch_bounds__(256) void k_lm_step(const RobotDev* __restrict__ rb
   }
   if (tid == 0) *s_dmask = 0ull;
   __syncthreads();
+  int actv[2] = {1, 1};
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
     const int idx = tid + 256 * u;
@@ -1489,37 +1490,59 @@ __global__ __launch_bounds__(256) void k_lm_step(const RobotDev* __restrict__ rb
         act = (qt <= rb->lower[i] && bv > 0.0) || (qt >= rb->upper[i] && bv < 0.0);
       }
       s_b[idx] = bv;
-      s_act[idx] = act;
+      actv[u] = act;
     }
   }
+  // frozen variables of a waypoint as a bit mask (bit i = joint i): eight lanes of a ballot per waypoint
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int idx = tid + 256 * u;
+    const unsigned long long bal = __ballot(idx < m * 8 && actv[u] != 0);
+    if (idx < m * 8 && (idx & 7) == 0) s_actm[idx >> 3] = (int)((bal >> (lane & 56)) & 0xffull);
+  }
   __syncthreads();
-  // undamped blocks -> s_A, damped / frozen system -> s_Z; remember which blocks are purely diagonal
+  // undamped blocks -> s_A, damped / frozen system -> s_Z; remember which blocks are purely diagonal.
+  // Everything that depends on the lane only is hoisted; the two waypoints that carry goal terms are
+  // patched afterwards by the wave that owns them, so the loop body is a dozen instructions.
+  const bool diagl = r == c;
+  const double dadd = (inb && diagl) ? 2.0 * alpha : 0.0;  // velocity term of an interior waypoint
+  const double idv = diagl ? 1.0 : 0.0, dmul = diagl ? 1.0 + lambda : 1.0;
+  const int lane_bits = (1 << r) | (1 << c);
+  constexpr unsigned long long kOffDiag = ~0x8040201008040201ull;  // lanes (r,c) with r != c
   {
     unsigned long long dm = 0ull;
 #pragma unroll
     for (int kk = 0; kk < KMAX; ++kk) {
       const int s = wave + 4 * kk;
-      if (s < m) {
-        const int t = s + 2;
-        double a = sp.w_obstacle * av[kk];
-        if (t == T - 1) a += gA0;
-        if (t == sp.ts) a += gA1;
-        if (inb && r == c) a += (t < T - 1) ? 2.0 * alpha : alpha;
+      if (s < m) {  // wave-uniform
+        const double a = fma(sp.w_obstacle, av[kk], dadd);
+        const bool frozen = (s_actm[s] & lane_bits) != 0;
+        const double v = frozen ? idv : a * dmul;
         s_A[(size_t)s * 64 + lane] = a;
-        const int ar = s_act[s * 8 + r], ac = s_act[s * 8 + c];
-        double v = a;
-        if (ar || ac) v = (r == c) ? 1.0 : 0.0;
-        else if (r == c) v *= (1.0 + lambda);
         s_Z[(size_t)s * 64 + lane] = v;
-        if (__any(r != c && v != 0.0)) dm |= 1ull << s;
+        if (__ballot(v != 0.0) & kOffDiag) dm |= 1ull << s;
       }
+    }
+    // goal waypoints: T-1 (also: its velocity term is alpha, not 2 alpha) and the standoff waypoint
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+      const int s = (which == 0 ? T - 1 : sp.ts) - 2;
+      if (which == 1 && !sp.use_standoff) continue;
+      if ((s & 3) != wave || s < 0 || s >= m) continue;  // wave-uniform
+      double a = s_A[(size_t)s * 64 + lane] + (which == 0 ? gA0 : gA1);
+      if (which == 0 && inb && diagl) a -= alpha;
+      const bool frozen = (s_actm[s] & lane_bits) != 0;
+      const double v = frozen ? idv : a * dmul;
+      s_A[(size_t)s * 64 + lane] = a;
+      s_Z[(size_t)s * 64 + lane] = v;
+      if (__ballot(v != 0.0) & kOffDiag) dm |= 1ull << s;
     }
     if (lane == 0 && dm) atomicOr(s_dmask, dm);
   }
   for (int idx = tid; idx < m * 8; idx += 256) {
-    const int sI = idx >> 3;
-    const int a0 = s_act[idx];
-    const int a1 = (sI < m - 1) ? s_act[idx + 8] : 1;
+    const int sI = idx >> 3, i = idx & 7;
+    const int a0 = (s_actm[sI] >> i) & 1;
+    const int a1 = (sI < m - 1) ? (s_actm[sI + 1] >> i) & 1 : 1;
     s_e[idx] = (a0 || a1) ? 0.0 : -alpha;
     s_y[idx] = a0 ? 0.0 : -s_b[idx];  // right-hand side
   }
@@ -1528,18 +1551,60 @@ __global__ __launch_bounds__(256) void k_lm_step(const RobotDev* __restrict__ rb
   const int s_dense = dense_mask ? (__ffsll((long long)dense_mask) - 1) : m;
 
   if (bp.dbg && b == 0 && tid == 0) bp.dbg[2] = clock64();
-  // ---- P3 (wave 0): block-tridiagonal solve by the inverse-based Schur recursion
-  //   S_s = D_s - E_{s-1} Z_{s-1} E_{s-1},  Z_s = S_s^{-1},  z_s = rhs_s - E_{s-1} y_{s-1},  y_s = Z_s z_s
-  //   x_s = y_s - Z_s E_s x_{s+1}
+  // ---- P3: block-tridiagonal solve by the inverse-based Schur recursion, run from BOTH ends (twisted
+  // factorisation): wave 0 eliminates downwards from waypoint 0, wave 1 upwards from the last waypoint,
+  // they meet at block `mid`, and the two back-substitutions run outwards from there, again in parallel.
+  // No extra arithmetic is needed and the serial chain of dense 8x8 inversions is roughly halved.
+  //   down: S_s = D_s - E_{s-1} Z_{s-1} E_{s-1}, Z_s = S_s^{-1}, y_s = Z_s (rhs_s - E_{s-1} y_{s-1})
+  //   up:   S_s = D_s - E_s Z_{s+1} E_s,         Z_s = S_s^{-1}, y_s = Z_s (rhs_s - E_s y_{s+1})
+  //   mid:  S = D - E_{mid-1} Z_{mid-1} E_{mid-1} - E_mid Z_{mid+1} E_mid, x_mid = S^{-1}(rhs - E y - E y)
+  //   back: x_s = y_s - Z_s E_s x_{s+1} (s < mid),  x_s = y_s - Z_s E_{s-1} x_{s-1} (s > mid)
   // Leading diagonal stretch (free-space waypoints carry only the velocity term, so S stays diagonal
   // until the first dense block): a scalar recurrence on the diagonal lanes.  Dense blocks:
   // Gauss-Jordan without pivoting (SPD) with the pivot row/column moved by cross-lane shuffles and the
   // mat-vec reductions done in registers; no LDS round trip, no barrier.
+  // Meeting block: a diagonal step of the downward sweep costs about a tenth of a dense block, and every
+  // block of the upward sweep is dense (it starts at the goal waypoint); balance the two chains.
+  int mid;
+  {
+    const int sd = s_dense < m ? s_dense : m - 1;
+    const int m2 = (10 * (m - 1) + 9 * sd) / 20;  // sd + 10 (mid - sd) = 10 (m - 1 - mid)
+    const int m1 = (10 * (m - 1)) / 11;           // mid = 10 (m - 1 - mid)
+    mid = m2 >= sd ? m2 : (m1 < sd ? m1 : sd);
+    mid = mid < 0 ? 0 : (mid > m - 1 ? m - 1 : mid);
+  }
+  // Gauss-Jordan inverse of the 8x8 block held one entry per lane; returns 1 if a pivot is not positive
+  auto gj_invert = [&](double& S) -> int {
+    int bad = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const double pjj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(S), j * 9),
+                                          __builtin_amdgcn_readlane(__double2loint(S), j * 9));
+      const double prj = __shfl(S, (lane & 56) | j, 64);
+      const double pjc = __shfl(S, j * 8 + c, 64);
+      if (!(pjj > 0.0)) bad = 1;
+      const double piv = fast_rcp(pjj);
+      const double tcol = -prj * piv;
+      const double in_row = (c == j) ? piv : pjc * piv;           // pivot row
+      const double off_row = (c == j) ? tcol : fma(tcol, pjc, S);  // other rows
+      S = (r == j) ? in_row : off_row;  // selects, not branches
+    }
+    return bad;
+  };
+  // y[r] = sum_c Z[r][c] z[c] for lane (r,c); every lane of row r ends up with y[r]
+  auto matvec = [&](double Z, double zc) -> double {
+    double pr = Z * zc;
+    pr += __shfl_xor(pr, 1, 64);
+    pr += __shfl_xor(pr, 2, 64);
+    pr += __shfl_xor(pr, 4, 64);
+    return pr;
+  };
   if (wave == 0) {
     int fail = 0;
     double zp = 0.0, yp = 0.0;
+    const int nd = s_dense < mid ? s_dense : mid;  // diagonal stretch of the downward sweep
     if (r == c) {
-      for (int s = 0; s < s_dense; ++s) {
+      for (int s = 0; s < nd; ++s) {
         const double ep = (s > 0) ? s_e[(s - 1) * 8 + r] : 0.0;
         const double S = s_Z[(size_t)s * 64 + lane] - ep * ep * zp;
         if (!(S > 0.0)) fail = 1;
@@ -1554,8 +1619,8 @@ __global__ __launch_bounds__(256) void k_lm_step(const RobotDev* __restrict__ rb
     wave_sync();
     if (bp.dbg && b == 0 && tid == 0) bp.dbg[3] = clock64();
     double Zprev = (r == c) ? zp : 0.0;
-    double yprev_c = (s_dense > 0) ? s_x[(s_dense - 1) * 8 + c] : 0.0;  // y_{s-1}[c] for lane (r,c)
-    for (int s = s_dense; s < m; ++s) {
+    double yprev_c = (nd > 0) ? s_x[(nd - 1) * 8 + c] : 0.0;  // y_{s-1}[c] for lane (r,c)
+    for (int s = nd; s < mid; ++s) {
       double S = s_Z[(size_t)s * 64 + lane];
       double zc = s_y[s * 8 + c];
       if (s > 0) {
@@ -1563,54 +1628,82 @@ __global__ __launch_bounds__(256) void k_lm_step(const RobotDev* __restrict__ rb
         S -= er * ec * Zprev;
         zc -= ec * yprev_c;
       }
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const double pjj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(S), j * 9),
-                                            __builtin_amdgcn_readlane(__double2loint(S), j * 9));
-        const double prj = __shfl(S, (lane & 56) | j, 64);
-        const double pjc = __shfl(S, j * 8 + c, 64);
-        if (!(pjj > 0.0)) fail = 1;
-        const double piv = fast_rcp(pjj);
-        if (r == j && c == j) S = piv;
-        else if (r == j) S = pjc * piv;
-        else if (c == j) S = -prj * piv;
-        else S = fma(-prj * piv, pjc, S);
-      }
+      fail |= gj_invert(S);
       s_Z[(size_t)s * 64 + lane] = S;  // Z_s
       Zprev = S;
-      double pr = S * zc;  // y_s[r] = sum_c Z[r][c] z[c]
-      pr += __shfl_xor(pr, 1, 64);
-      pr += __shfl_xor(pr, 2, 64);
-      pr += __shfl_xor(pr, 4, 64);
+      const double pr = matvec(S, zc);
       if (c == 0) s_x[s * 8 + r] = pr;
       yprev_c = __shfl(pr, c << 3, 64);  // transpose: lane (r,c) picks y_s[c] from row c
     }
-    wave_sync();
-    if (bp.dbg && b == 0 && tid == 0) bp.dbg[4] = clock64();
-    if (!__any(fail)) {
-      // backward sweep; xr = x_{s+1}[r] (row copy), xc = x_{s+1}[c] (column copy) per lane
-      double xr = s_x[(m - 1) * 8 + r], xc = s_x[(m - 1) * 8 + c];
-      for (int s = m - 2; s >= s_dense; --s) {  // dense blocks
-        double pr = s_Z[(size_t)s * 64 + lane] * (s_e[s * 8 + c] * xc);
-        pr += __shfl_xor(pr, 1, 64);
-        pr += __shfl_xor(pr, 2, 64);
-        pr += __shfl_xor(pr, 4, 64);
-        xr = s_x[s * 8 + r] - pr;
-        if (c == 0) s_x[s * 8 + r] = xr;
-        xc = __shfl(xr, c << 3, 64);
+    if (lane == 0) s_red[0] = __any(fail) ? 1.0 : 0.0;
+  } else if (wave == 1) {
+    int fail = 0;
+    double Zprev = 0.0, yprev_c = 0.0;
+    for (int s = m - 1; s > mid; --s) {
+      double S = s_Z[(size_t)s * 64 + lane];
+      double zc = s_y[s * 8 + c];
+      if (s < m - 1) {
+        const double er = s_e[s * 8 + r], ec = s_e[s * 8 + c];
+        S -= er * ec * Zprev;
+        zc -= ec * yprev_c;
       }
-      if (r == c) {  // diagonal stretch
-        const int top = (s_dense < m - 1 ? s_dense : m - 1) - 1;
-        for (int s = top; s >= 0; --s) {
-          xr = s_x[s * 8 + r] - s_Z[(size_t)s * 64 + lane] * (s_e[s * 8 + r] * xr);
-          s_x[s * 8 + r] = xr;
-        }
-      }
+      fail |= gj_invert(S);
+      s_Z[(size_t)s * 64 + lane] = S;
+      Zprev = S;
+      const double pr = matvec(S, zc);
+      if (c == 0) s_x[s * 8 + r] = pr;
+      yprev_c = __shfl(pr, c << 3, 64);
     }
+    if (lane == 0) s_red[1] = __any(fail) ? 1.0 : 0.0;
+  }
+  __syncthreads();
+  if (bp.dbg && b == 0 && tid == 0) bp.dbg[4] = clock64();
+  if (wave == 0) {  // the meeting block
+    int fail = (s_red[0] != 0.0) || (mid < m - 1 && s_red[1] != 0.0);
+    double S = s_Z[(size_t)mid * 64 + lane];
+    double zc = s_y[mid * 8 + c];
+    if (mid > 0) {
+      const double er = s_e[(mid - 1) * 8 + r], ec = s_e[(mid - 1) * 8 + c];
+      S -= er * ec * s_Z[(size_t)(mid - 1) * 64 + lane];
+      zc -= ec * s_x[(mid - 1) * 8 + c];
+    }
+    if (mid < m - 1) {
+      const double er = s_e[mid * 8 + r], ec = s_e[mid * 8 + c];
+      S -= er * ec * s_Z[(size_t)(mid + 1) * 64 + lane];
+      zc -= ec * s_x[(mid + 1) * 8 + c];
+    }
+    fail |= gj_invert(S);
+    const double pr = matvec(S, zc);
+    if (c == 0) s_x[mid * 8 + r] = pr;  // x_mid
     if (lane == 0) s_red[0] = __any(fail) ? 1.0 : 0.0;
   }
   __syncthreads();
   if (s_red[0] != 0.0) GTO_FINISH(GTO_STATUS_NUMERICAL);
+  if (wave == 0) {  // outwards to waypoint 0
+    const int nd = s_dense < mid ? s_dense : mid;
+    double xr = s_x[mid * 8 + r], xc = s_x[mid * 8 + c];
+    for (int s = mid - 1; s >= nd; --s) {  // dense blocks
+      const double pr = matvec(s_Z[(size_t)s * 64 + lane], s_e[s * 8 + c] * xc);
+      xr = s_x[s * 8 + r] - pr;
+      if (c == 0) s_x[s * 8 + r] = xr;
+      xc = __shfl(xr, c << 3, 64);
+    }
+    if (r == c) {  // diagonal stretch
+      for (int s = nd - 1; s >= 0; --s) {
+        xr = s_x[s * 8 + r] - s_Z[(size_t)s * 64 + lane] * (s_e[s * 8 + r] * xr);
+        s_x[s * 8 + r] = xr;
+      }
+    }
+  } else if (wave == 1) {  // outwards to the last waypoint
+    double xc = s_x[mid * 8 + c];
+    for (int s = mid + 1; s < m; ++s) {
+      const double pr = matvec(s_Z[(size_t)s * 64 + lane], s_e[(s - 1) * 8 + c] * xc);
+      const double xr = s_x[s * 8 + r] - pr;
+      if (c == 0) s_x[s * 8 + r] = xr;
+      xc = __shfl(xr, c << 3, 64);
+    }
+  }
+  __syncthreads();
 
   if (bp.dbg && b == 0 && tid == 0) bp.dbg[5] = clock64();
   // ---- P4: projected trial point; the LDS copy of Q becomes the trial, s_x the projected step
@@ -1638,21 +1731,17 @@ __global__ __launch_bounds__(256) void k_lm_step(const RobotDev* __restrict__ rb
   if (maxstep < sp.tol_step) GTO_FINISH(GTO_STATUS_CONVERGED);
 
   if (bp.dbg && b == 0 && tid == 0) bp.dbg[6] = clock64();
-  // ---- P5: predicted decrease of the undamped model: -(2 b.s + s^T A s), waypoints split over waves
+  // ---- P5: predicted decrease of the undamped model: -(2 b.s + s^T A s), waypoints split over waves.
+  // Lane (r,c) adds A[r][c] s_r s_c; the lanes of column 0 also add the terms that are linear in s_r
+  // (2 b_r s_r and the coupling -2 alpha s_r s'_r with the next waypoint), folded in as a lane constant.
   {
+    const double c0 = (c == 0) ? 2.0 : 0.0;
     double part = 0.0;
-#pragma unroll
-    for (int kk = 0; kk < KMAX; ++kk) {
-      const int s = wave + 4 * kk;
-      if (s < m) {
-        const double sr = s_x[s * 8 + r], scv = s_x[s * 8 + c];
-        double v = s_A[(size_t)s * 64 + lane] * sr * scv;
-        if (c == 0) {
-          v += 2.0 * s_b[s * 8 + r] * sr;
-          if (s < m - 1) v += 2.0 * (-alpha) * sr * s_x[(s + 1) * 8 + r];
-        }
-        part += v;
-      }
+    for (int s = wave; s < m; s += 4) {
+      const double sr = s_x[s * 8 + r], scv = s_x[s * 8 + c];
+      const double xn = (s < m - 1) ? s_x[(s + 1) * 8 + r] : 0.0;
+      const double lin = c0 * fma(-alpha, xn, s_b[s * 8 + r]);
+      part = fma(sr, fma(s_A[(size_t)s * 64 + lane], scv, lin), part);
     }
     part = wave_sum(part);
     if (lane == 0) s_red[8 + wave] = part;
