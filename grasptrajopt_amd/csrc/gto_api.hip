@@ -39,7 +39,8 @@ struct gto_handle {
   // solve workspace (grown on demand)
   DevBuf state, Qcur, Qtry, vis, screw, blocks, goalblk, ssfixed, ndone, qref, margin, qf;
   int32_t* h_ndone = nullptr;  // pinned
-  int check_every = 8;
+  int check_every = 4;
+  hipEvent_t ev_chk[2][GTO_MAX_GROUPS] = {{nullptr}};
   int dbg_cut = 0;  // GTO_DEBUG_CUT: timing experiments only, results are garbage
   int n_groups = 1;
   int obs_tg = 1;  // waypoints per workgroup of the obstacle kernel (grouping measured slower: DESIGN.md section 7)
@@ -424,6 +425,8 @@ void gto_destroy(gto_handle* h) {
   for (int g = 0; g < GTO_MAX_GROUPS; ++g) {
     if (h->gstream[g]) (void)hipStreamDestroy(h->gstream[g]);
     if (h->ev_join[g]) (void)hipEventDestroy(h->ev_join[g]);
+    for (int p = 0; p < 2; ++p)
+      if (h->ev_chk[p][g]) (void)hipEventDestroy(h->ev_chk[p][g]);
   }
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   for (DevBuf* b : bufs) (void)hipFree(b->p);
@@ -634,7 +637,10 @@ static int ensure_workspace(gto_handle* h, int B) {
   if ((rc = ensure(h, h->qf, (size_t)B * T * rb.n_frames * sizeof(double)))) return rc;
   if ((rc = ensure(h, h->qref, (size_t)B * T * GTO_MAX_OPT * sizeof(double)))) return rc;
   if ((rc = ensure(h, h->margin, (size_t)B * T * sizeof(int32_t)))) return rc;
-  if (!h->h_ndone) HIPCHK(h, hipHostMalloc((void**)&h->h_ndone, 64));
+  if (!h->h_ndone) HIPCHK(h, hipHostMalloc((void**)&h->h_ndone, 2 * GTO_MAX_GROUPS * sizeof(int32_t) + 64));
+  for (int p = 0; p < 2; ++p)
+    for (int g = 0; g < GTO_MAX_GROUPS; ++g)
+      if (!h->ev_chk[p][g]) HIPCHK(h, hipEventCreateWithFlags(&h->ev_chk[p][g], hipEventDisableTiming));
   return GTO_OK;
 }
 
@@ -766,7 +772,7 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
   }
   // one round = evaluate the trial trajectory (obstacle kernel) + accept/solve/new trial (step kernel);
   // instances that are done exit both kernels immediately
-  int n_live = G;
+  int n_live = G, n_checks = 0;
   for (int k = 0; k <= sp.max_iter && n_live > 0; ++k) {
     for (int g = 0; g < G; ++g) {
       Group& gr = grp[g];
@@ -775,19 +781,30 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
       if ((rc = launch_obstacle(h, gr.st, gr.bp, sp, gr.n, 2, T - 2, 0, h->profiling, k > 0))) return rc;
       hipLaunchKernelGGL(k_lm_step, dim3(gr.n), dim3(256), h->lm_lds, gr.st, h->d_rb, gr.bp, sp, gr.n);
     }
-    // early exit: every few rounds look at the finished-instance counters (4-byte read-backs)
+    // Early exit.  Every few rounds the finished-instance counters are copied back (4 bytes) and an event
+    // is recorded, but the host only LOOKS at the copy of the previous check: by then the GPU has long
+    // passed that point, so the host never waits on the GPU's critical path and the queue never drains
+    // (a blocking read-back every 8 rounds cost 25-30 us of idle GPU each).  The price is a few rounds of
+    // empty launches after the last instance finishes.
     if (h->check_every > 0 && (k % h->check_every) == h->check_every - 1 && k < sp.max_iter) {
-      for (int g = 0; g < G; ++g)
-        if (grp[g].live)
-          HIPCHK(h, hipMemcpyAsync(h->h_ndone + g, grp[g].bp.n_done, sizeof(int32_t), hipMemcpyDeviceToHost, grp[g].st));
+      const int p = n_checks & 1;
       for (int g = 0; g < G; ++g) {
         if (!grp[g].live) continue;
-        HIPCHK(h, hipStreamSynchronize(grp[g].st));
-        if (h->h_ndone[g] >= grp[g].n) {
-          grp[g].live = false;
-          --n_live;
+        HIPCHK(h, hipMemcpyAsync(h->h_ndone + p * GTO_MAX_GROUPS + g, grp[g].bp.n_done, sizeof(int32_t),
+                                 hipMemcpyDeviceToHost, grp[g].st));
+        HIPCHK(h, hipEventRecord(h->ev_chk[p][g], grp[g].st));
+      }
+      if (n_checks > 0) {
+        for (int g = 0; g < G; ++g) {
+          if (!grp[g].live) continue;
+          HIPCHK(h, hipEventSynchronize(h->ev_chk[1 - p][g]));
+          if (h->h_ndone[(1 - p) * GTO_MAX_GROUPS + g] >= grp[g].n) {
+            grp[g].live = false;
+            --n_live;
+          }
         }
       }
+      ++n_checks;
     }
   }
   for (int g = 0; g < G; ++g) {
