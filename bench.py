@@ -32,10 +32,10 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s sp
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="goal grasps (instances) per GPU per step")
-    ap.add_argument("--pipeline", type=int, default=3, help="batches (steps) in flight per GPU: solver handles/streams")
+    ap.add_argument("--pipeline", type=int, default=4, help="batches (steps) in flight per GPU: solver handles/streams")
     ap.add_argument("--max-iter", type=int, default=100, help="iteration cap (reference IPOPT cap: 100)")
     ap.add_argument("--robot", default="panda_5k")
     ap.add_argument("--grid", type=int, default=128)

@@ -41,7 +41,8 @@ struct gto_handle {
   int32_t* h_ndone = nullptr;  // pinned
   int check_every = 4;
   hipEvent_t ev_chk[2][GTO_MAX_GROUPS] = {{nullptr}};
-  int dbg_cut = 0;  // GTO_DEBUG_CUT: timing experiments only, results are garbage
+  int dbg_cut = 0;
+  size_t dbg_extra_lds = 0;  // GTO_DEBUG_EXTRA_LDS: occupancy experiments  // GTO_DEBUG_CUT: timing experiments only, results are garbage
   int n_groups = 1;
   int obs_tg = 1;  // waypoints per workgroup of the obstacle kernel (grouping measured slower: DESIGN.md section 7)
   long long* dbg = nullptr;
@@ -150,6 +151,7 @@ int gto_create(const gto_robot_desc* d, const gto_solver_opts* opts, int device,
   if (const char* e = getenv("GTO_GROUPS")) h->n_groups = std::max(1, std::min(GTO_MAX_GROUPS, atoi(e)));
   if (const char* e = getenv("GTO_CHECK_EVERY")) h->check_every = atoi(e);
   if (const char* e = getenv("GTO_DEBUG_CUT")) h->dbg_cut = atoi(e);
+  if (const char* e = getenv("GTO_DEBUG_EXTRA_LDS")) h->dbg_extra_lds = (size_t)atoi(e);
   if (const char* e = getenv("GTO_OBS_TG")) h->obs_tg = std::max(1, std::min(GTO_MAX_TG, atoi(e)));
   if (getenv("GTO_DEBUG_TIMING")) { (void)hipMalloc((void**)&h->dbg, 32 * sizeof(long long)); (void)hipMemset(h->dbg, 0, 32 * sizeof(long long)); }
   RobotDev& rb = h->rb;
@@ -385,7 +387,8 @@ int gto_create(const gto_robot_desc* d, const gto_solver_opts* opts, int device,
     const ObsLds lay(GTO_MAX_TG, rb.n_frames, rb.n_links, GTO_MAX_TG * rb.n_chunks);
     const size_t lds = (size_t)lay.total_doubles * sizeof(double);
     if (lds > 150 * 1024) { gto_destroy(h); return fail(nullptr, GTO_ERR_UNSUPPORTED, "robot too large for the obstacle kernel's LDS"); }
-    if (hipFuncSetAttribute((const void*)k_obstacle_gram, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+    if (hipFuncSetAttribute((const void*)k_obstacle_gram, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)std::min<size_t>(lds + h->dbg_extra_lds, 160 * 1024)) != hipSuccess) {
       gto_destroy(h);
       return fail(nullptr, GTO_ERR_HIP, "hipFuncSetAttribute(k_obstacle_gram) failed");
     }
@@ -690,7 +693,7 @@ static int launch_obstacle(gto_handle* h, hipStream_t st, const BatchPtrs& bp, c
   const int n_regular = obstacle_grid(B, nG);
   const int cap_active = TG * h->rb.n_chunks;
   const ObsLds lay(TG, h->rb.n_frames, h->rb.n_links, cap_active);
-  const size_t lds = (size_t)lay.total_doubles * sizeof(double);
+  const size_t lds = (size_t)lay.total_doubles * sizeof(double) + h->dbg_extra_lds;
   hipLaunchKernelGGL(k_obstacle_gram, dim3(n_regular + (with_goal_terms ? B : 0)), dim3(256), lds, st, h->d_rb, h->d_px, h->d_py,
                      h->d_pz, h->d_chunks, h->d_scenes, bp, sp, B, t_begin, nT, fixed_mode, n_regular, TG, cap_active);
   if (timed) {
