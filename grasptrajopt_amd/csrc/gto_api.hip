@@ -105,7 +105,7 @@ const char* gto_last_error(const gto_handle* h) { return h ? h->err.c_str() : g_
 
 static int validate_opts(const gto_solver_opts* o, std::string& why) {
   if (o->T < 4) { why = "T must be >= 4"; return 0; }
-  if (o->T > GTO_MAX_T) { why = "T must be <= 64 (GTO_MAX_T)"; return 0; }
+  if (o->T > GTO_MAX_T) { why = "T must be <= 96 (GTO_MAX_T)"; return 0; }
   if (!(o->Tmax > 0)) { why = "Tmax must be positive"; return 0; }
   if (o->max_iter < 0) { why = "max_iter must be >= 0"; return 0; }
   int ts = o->T + o->standoff_offset;

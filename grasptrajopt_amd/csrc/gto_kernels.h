@@ -19,7 +19,7 @@
 #define BLK_STRIDE 80  // doubles per (instance, waypoint) block: 8x8 J^T J, 8 J^T r, sum c^2, pad
 #define GTO_MAX_ACTIVE 256   // chunks per robot (16 K surface points)
 #define GTO_MAX_TG 8         // waypoints per workgroup of the obstacle kernel
-#define GTO_MAX_T 64         // waypoints the step kernel's register-resident phases are unrolled for
+#define GTO_MAX_T 96         // waypoints the step kernel's register-resident phases are unrolled for (and its LDS holds)
 #ifndef GTO_LIST_CAP
 #define GTO_LIST_CAP 80      // wrench-list entries (8 doubles) per wave: a full chunk (64) fits after a drain
 #endif
@@ -1349,7 +1349,7 @@ __global__ __launch_bounds__(256) void k_lm_step(const RobotDev* __restrict__ rb
   double* s_gaff = s_Q + 8 * T;
   double* s_red = s_gaff + 16;  // [16] cross-wave scratch
   int* s_actm = (int*)(s_red + 16);                // [m] frozen-joint bit masks (room for [m][8])
-  unsigned long long* s_dmask = (unsigned long long*)(s_red + 8);
+  int* s_first_dense = (int*)(s_red + 8);  // first waypoint block with an off-diagonal entry
 
   const int r = lane >> 3, c = lane & 7;
   const int trial = 1 - st->slot;
@@ -1407,14 +1407,15 @@ __global__ __launch_bounds__(256) void k_lm_step(const RobotDev* __restrict__ rb
   // current iterate into LDS (rows >= n are padding); on accept it is the trial
   {
     const double* __restrict__ src = accept ? Qt : Qc;
-    double v[2];
+    constexpr int NQ = (8 * GTO_MAX_T + 255) / 256;
+    double v[NQ];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < NQ; ++u) {
       const int idx = tid + 256 * u;
       v[u] = (idx < n * T) ? src[idx] : 0.0;
     }
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < NQ; ++u) {
       const int idx = tid + 256 * u;
       if (idx < 8 * T) s_Q[idx] = v[u];
       if (accept && idx < n * T) Qc[idx] = v[u];
@@ -1451,15 +1452,16 @@ __global__ __launch_bounds__(256) void k_lm_step(const RobotDev* __restrict__ rb
   const double alpha = sp.alpha;
   const bool inb = (r < n) && (c < n);
   constexpr int KMAX = (GTO_MAX_T - 2 + 3) / 4;
+  constexpr int NU = (8 * GTO_MAX_T + 255) / 256;  // (waypoint, joint) items per thread
   double av[KMAX];  // undamped obstacle J^T J entry (r,c) of this wave's waypoints
 #pragma unroll
   for (int kk = 0; kk < KMAX; ++kk) {
     const int s = wave + 4 * kk;
     av[kk] = (inb && s < m) ? oblk[(size_t)(s + 2) * BLK_STRIDE + BLK_JTJ + lane] : 0.0;
   }
-  double jv[2];  // obstacle J^T r of this thread's (waypoint, joint) items
+  double jv[NU];  // obstacle J^T r of this thread's (waypoint, joint) items
 #pragma unroll
-  for (int u = 0; u < 2; ++u) {
+  for (int u = 0; u < NU; ++u) {
     const int idx = tid + 256 * u, i = idx & 7;
     jv[u] = (idx < m * 8 && i < n) ? oblk[(size_t)((idx >> 3) + 2) * BLK_STRIDE + BLK_JTR + i] : 0.0;
   }
@@ -1469,11 +1471,13 @@ __global__ __launch_bounds__(256) void k_lm_step(const RobotDev* __restrict__ rb
     const int w = tid >> 3, i = tid & 7;
     s_gaff[tid] = (i < n && (w == 0 || sp.use_standoff)) ? gblk[w * BLK_STRIDE + BLK_JTR + i] : 0.0;
   }
-  if (tid == 0) *s_dmask = 0ull;
+  if (tid == 0) *s_first_dense = m;
   __syncthreads();
-  int actv[2] = {1, 1};
+  int actv[NU];
 #pragma unroll
-  for (int u = 0; u < 2; ++u) {
+  for (int u = 0; u < NU; ++u) actv[u] = 1;
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
     const int idx = tid + 256 * u;
     if (idx < m * 8) {
       const int sI = idx >> 3, i = idx & 7, t = sI + 2;
@@ -1495,7 +1499,7 @@ __global__ __launch_bounds__(256) void k_lm_step(const RobotDev* __restrict__ rb
   }
   // frozen variables of a waypoint as a bit mask (bit i = joint i): eight lanes of a ballot per waypoint
 #pragma unroll
-  for (int u = 0; u < 2; ++u) {
+  for (int u = 0; u < NU; ++u) {
     const int idx = tid + 256 * u;
     const unsigned long long bal = __ballot(idx < m * 8 && actv[u] != 0);
     if (idx < m * 8 && (idx & 7) == 0) s_actm[idx >> 3] = (int)((bal >> (lane & 56)) & 0xffull);
@@ -1510,7 +1514,7 @@ __global__ __launch_bounds__(256) void k_lm_step(const RobotDev* __restrict__ rb
   const int lane_bits = (1 << r) | (1 << c);
   constexpr unsigned long long kOffDiag = ~0x8040201008040201ull;  // lanes (r,c) with r != c
   {
-    unsigned long long dm = 0ull;
+    int first = m;  // first dense block seen by this wave
 #pragma unroll
     for (int kk = 0; kk < KMAX; ++kk) {
       const int s = wave + 4 * kk;
@@ -1520,7 +1524,7 @@ __global__ __launch_bounds__(256) void k_lm_step(const RobotDev* __restrict__ rb
         const double v = frozen ? idv : a * dmul;
         s_A[(size_t)s * 64 + lane] = a;
         s_Z[(size_t)s * 64 + lane] = v;
-        if (__ballot(v != 0.0) & kOffDiag) dm |= 1ull << s;
+        if ((__ballot(v != 0.0) & kOffDiag) && s < first) first = s;
       }
     }
     // goal waypoints: T-1 (also: its velocity term is alpha, not 2 alpha) and the standoff waypoint
@@ -1535,9 +1539,9 @@ __global__ __launch_bounds__(256) void k_lm_step(const RobotDev* __restrict__ rb
       const double v = frozen ? idv : a * dmul;
       s_A[(size_t)s * 64 + lane] = a;
       s_Z[(size_t)s * 64 + lane] = v;
-      if (__ballot(v != 0.0) & kOffDiag) dm |= 1ull << s;
+      if ((__ballot(v != 0.0) & kOffDiag) && s < first) first = s;
     }
-    if (lane == 0 && dm) atomicOr(s_dmask, dm);
+    if (lane == 0 && first < m) atomicMin(s_first_dense, first);
   }
   for (int idx = tid; idx < m * 8; idx += 256) {
     const int sI = idx >> 3, i = idx & 7;
@@ -1547,8 +1551,7 @@ __global__ __launch_bounds__(256) void k_lm_step(const RobotDev* __restrict__ rb
     s_y[idx] = a0 ? 0.0 : -s_b[idx];  // right-hand side
   }
   __syncthreads();
-  const unsigned long long dense_mask = *s_dmask;
-  const int s_dense = dense_mask ? (__ffsll((long long)dense_mask) - 1) : m;
+  const int s_dense = *s_first_dense;
 
   if (bp.dbg && b == 0 && tid == 0) bp.dbg[2] = clock64();
   // ---- P3: block-tridiagonal solve by the inverse-based Schur recursion, run from BOTH ends (twisted

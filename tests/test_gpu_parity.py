@@ -295,3 +295,21 @@ def test_pipelined_batches_equal_serial_solves(capi, oracle_mod):
     np.testing.assert_array_equal(again[0], serial[0][0])
     for h in hs:
         h.close()
+
+
+@pytest.mark.parametrize("T,offset", [(4, -1), (5, -2), (30, -10), (64, -10), (80, -10), (96, -20)])
+def test_other_horizons_match_oracle(capi, oracle_mod, T, offset):
+    """The reference fixes T = 50 (gto/gto_planner.py:25); BASELINE.json also names 30- and 80-waypoint
+    variants.  Shortest legal horizon, the old 64 limit, and the current maximum (96)."""
+    prob = Problem("panda", B=3, scene_seed=4, T=T)
+    h, o = make_pair(capi, oracle_mod, prob, T=T, standoff_offset=offset, max_iter=10)
+    Qg, dQg, fg, itg, stg = h.solve_batch(*prob.solve_args())
+    Qo, dQo, fo, ito, sto = o.solve_batch(*prob.solve_args())
+    np.testing.assert_array_equal(itg, ito)
+    np.testing.assert_array_equal(stg, sto)
+    np.testing.assert_allclose(Qg, Qo, rtol=0, atol=1e-6)
+    np.testing.assert_allclose(fg, fo, rtol=1e-8)
+    h.close()
+    with pytest.raises(capi.GTOError, match="T must be"):
+        capi.SolverHandle(prob.desc, prob.cfg["link_ee"], prob.cfg["link_gripper"],
+                          oracle_mod.reference_opts(T=97, standoff_offset=-10), device=0)
