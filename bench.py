@@ -72,7 +72,8 @@ def main():
     from grasptrajopt_amd.parallel import BatchPipeline, shard_range
     from grasptrajopt_amd.robot_desc import load_builtin
 
-    cfg = json.load(open(os.path.join(ROOT, "grasptrajopt_amd", "data", "panda_cfg.json")))
+    fetch = args.robot.startswith("fetch")  # BASELINE configs[2]: --robot fetch --batch 256 (shelf-height table)
+    cfg = json.load(open(os.path.join(ROOT, "grasptrajopt_amd", "data", f"{args.robot.split('_')[0]}_cfg.json")))
     desc = load_builtin(args.robot)
     opts = _capi.default_opts()
     opts.max_iter = args.max_iter
@@ -84,7 +85,8 @@ def main():
     assert hi - lo == B
     scene_seed = lo // B
     res = 2.24 / args.grid  # covers the 2.24 m reach box (0.0175 m at 128^3)
-    sc = syn.make_scene(scene_seed, n=args.grid, res=res)
+    sc = syn.make_scene(scene_seed, n=args.grid, res=res, origin=(-0.3, -1.12, 0.0) if fetch else (-0.4, -1.12, -0.4),
+                        table_z=0.45 if fetch else -0.03)
 
     # D pipeline lanes: each one solver handle bound to ONE stream of its own, with its own copy of the
     # batch in HBM and its own outputs (grasptrajopt_amd.parallel.BatchPipeline runs them concurrently)
@@ -119,7 +121,8 @@ def main():
         _, _, val, _ = h.eval_points(0, q, [0.0, 0.0, 0.0], use_obs=True)
         return (val * moving[None, :]).sum(axis=1)
 
-    RT, qg = syn.make_goals(desc, h.eval_fk, cfg["link_ee"], B, seed=scene_seed, collision_cost=goal_collision_cost)
+    RT, qg = syn.make_goals(desc, h.eval_fk, cfg["link_ee"], B, seed=scene_seed, collision_cost=goal_collision_cost,
+                            zlim=(0.55, 1.2) if fetch else (0.08, 0.7))
     qc = np.tile(np.array(cfg["default_pose"]), (B, 1))
     Q0 = np.stack([syn.make_seed(qc[b], qg[b], T, desc.param_index) for b in range(B)])
     S = np.tile(syn.standoff_pose(-0.1, cfg["axis_standoff"]).reshape(1, 16), (B, 1))
@@ -216,7 +219,7 @@ def main():
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
         traffic = args.traffic
         tj = os.path.join(ROOT, "profiles", "traffic.json")
-        if traffic is None and os.path.exists(tj):
+        if traffic is None and os.path.exists(tj) and (args.robot, args.grid, B) == ("panda_5k", 128, 64):  # measured on this workload only
             traffic = json.load(open(tj)).get("k_obstacle_gram_hbm_bytes_per_launch")
         roofline = {"bound": "hbm", "kernel": "k_obstacle_gram", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
@@ -256,7 +259,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: Panda 7-DoF, 1 scene x 64 goal grasps per GPU, T=50, "
+            "config": {"workload": (f"BASELINE configs[2]-like: Fetch arm, 1 scene x {B} goal grasps per GPU, T={int(T)}, " if fetch else
+                                    f"BASELINE configs[1]: Panda 7-DoF, 1 scene x {B} goal grasps per GPU, T={int(T)}, ") +
                                    f"{P} surface points, {args.grid}^3 f32 SDF cost field",
                        "batch_per_gpu": B, "T": int(T), "surface_points": int(P), "grid": args.grid,
                        "max_iter": args.max_iter, "pipeline_depth": D,
