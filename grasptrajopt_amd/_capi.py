@@ -140,9 +140,10 @@ def load_library(path: Optional[str] = None):
     lib.gto_eval_objective.argtypes = [H, C.c_int32, C.c_int32, _pi, _pd, _pi, _pd, _pd, _pd, _pd, _pd, _pd, _pi]
     lib.gto_eval_obstacle_normal_eq.argtypes = [H, C.c_int32, _pi, _pd, _pd, _pd, _pd, _pd]
     lib.gto_plan_cost.argtypes = [H, C.c_int32, C.c_int32, _pd, _pd, _pd, _pd]
+    lib.gto_solve_ik_batch.argtypes = [H, C.c_int32, _pi, _pd, _pd, _pd, C.c_int32, _pd, _pd, _pi, _pi]
     for fn in ("gto_create", "gto_set_opts", "gto_set_scene", "gto_drop_scene", "gto_solve_batch",
                "gto_solve_batch_device", "gto_last_kernel_time", "gto_set_profiling", "gto_set_stream", "gto_eval_fk",
-               "gto_eval_points", "gto_eval_objective", "gto_eval_obstacle_normal_eq", "gto_plan_cost"):
+               "gto_eval_points", "gto_eval_objective", "gto_eval_obstacle_normal_eq", "gto_plan_cost", "gto_solve_ik_batch"):
         getattr(lib, fn).restype = C.c_int
     if path is None:
         _lib = lib
@@ -153,7 +154,7 @@ EXPORTED_SYMBOLS = (
     "gto_default_opts", "gto_version", "gto_create", "gto_destroy", "gto_last_error", "gto_set_opts",
     "gto_set_scene", "gto_drop_scene", "gto_solve_batch", "gto_solve_batch_device",
     "gto_last_kernel_time", "gto_set_profiling", "gto_set_stream", "gto_eval_fk", "gto_eval_points",
-    "gto_eval_objective", "gto_eval_obstacle_normal_eq", "gto_plan_cost",
+    "gto_eval_objective", "gto_eval_obstacle_normal_eq", "gto_plan_cost", "gto_solve_ik_batch",
 )
 
 
@@ -327,6 +328,23 @@ class SolverHandle:
                                                          _p(Q, _pd), _p(JtJ, _pd), _p(Jtr, _pd), _p(ss, _pd)),
                     "gto_eval_obstacle_normal_eq")
         return JtJ, Jtr, ss
+
+    def solve_ik_batch(self, scene_id, q0, goals, base_pos=None, max_iter=50):
+        """IK for B goal poses (gto/ik_solver.py:78-110); scene_id None = no collision term.
+        Returns (q (B,ndof), cost (B,), iters (B,), status (B,))."""
+        d = self.desc
+        q0 = _f64(q0).reshape(-1, d.ndof)
+        B = q0.shape[0]
+        goals = _f64(goals).reshape(B, 16)
+        sid = None if scene_id is None else _i32(np.broadcast_to(np.asarray(scene_id), (B,)))
+        base = None if base_pos is None else _f64(np.broadcast_to(_f64(base_pos).reshape(-1, 3), (B, 3)))
+        q, cost = np.empty((B, d.ndof)), np.empty(B)
+        iters, status = np.empty(B, dtype=np.int32), np.empty(B, dtype=np.int32)
+        if B:
+            self._check(self.lib.gto_solve_ik_batch(self._h, B, _p(sid, _pi), _p(q0, _pd), _p(goals, _pd), _p(base, _pd),
+                                                    int(max_iter), _p(q, _pd), _p(cost, _pd), _p(iters, _pi), _p(status, _pi)),
+                        "gto_solve_ik_batch")
+        return q, cost, iters, status
 
     def plan_cost(self, scene_id, plans, base_pos):
         d, T = self.desc, self.T

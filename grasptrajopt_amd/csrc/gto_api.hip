@@ -56,6 +56,7 @@ struct gto_handle {
   double last_ms = 0.0;
   int last_launches = 0;
   size_t lm_lds = 0;
+  bool ik_attr_set = false;
 };
 
 #define HIPCHK(h, call)                                                                              \
@@ -867,6 +868,52 @@ static int stage_out(gto_handle* h, int slot, const void* host, size_t bytes, vo
 static int fetch_out(gto_handle* h, int slot, void* host, size_t bytes) {
   if (!host) return GTO_OK;
   HIPCHK(h, hipMemcpyAsync(host, h->out[slot].p, bytes, hipMemcpyDeviceToHost, h->stream));
+  return GTO_OK;
+}
+
+int gto_solve_ik_batch(gto_handle* h, int32_t B, const int32_t* scene_id, const double* q0, const double* goals,
+                       const double* base_pos, int32_t max_iter, double* q_out, double* cost_out, int32_t* iters_out,
+                       int32_t* status_out) {
+  if (!h) return GTO_ERR_INVALID_ARG;
+  if (B < 0 || max_iter < 0) return fail(h, GTO_ERR_INVALID_ARG, "B and max_iter must be >= 0");
+  if (B == 0) return GTO_OK;
+  if (!q0 || !goals || !q_out) return fail(h, GTO_ERR_INVALID_ARG, "null input array");
+  int rc;
+  if (scene_id && (rc = check_scene_ids_host(h, scene_id, B))) return rc;
+  HIPCHK(h, hipSetDevice(h->device));
+  const size_t ndof = h->rb.ndof;
+  std::vector<double> zeros;
+  if (scene_id && !base_pos) {
+    zeros.assign((size_t)B * 3, 0.0);
+    base_pos = zeros.data();
+  }
+  const void *d_sid = nullptr, *d_q0, *d_goals, *d_base = nullptr;
+  void *d_q, *d_cost, *d_it, *d_stat;
+  if (scene_id && (rc = stage_in(h, 0, scene_id, B * sizeof(int32_t), &d_sid))) return rc;
+  if ((rc = stage_in(h, 1, q0, B * ndof * sizeof(double), &d_q0))) return rc;
+  if ((rc = stage_in(h, 2, goals, (size_t)B * 16 * sizeof(double), &d_goals))) return rc;
+  if (scene_id && (rc = stage_in(h, 5, base_pos, (size_t)B * 3 * sizeof(double), &d_base))) return rc;
+  if ((rc = stage_out(h, 0, q_out, B * ndof * sizeof(double), &d_q))) return rc;
+  if ((rc = stage_out(h, 2, cost_out, B * sizeof(double), &d_cost))) return rc;
+  if ((rc = stage_out(h, 3, iters_out, B * sizeof(int32_t), &d_it))) return rc;
+  if ((rc = stage_out(h, 4, status_out, B * sizeof(int32_t), &d_stat))) return rc;
+  SolveParams sp = make_params(h, 1, false);
+  sp.max_iter = max_iter;
+  const size_t lds = (size_t)ik_lds_doubles(h->rb.n_frames, h->rb.n_links, h->rb.n_opt) * sizeof(double);
+  if (lds > 150 * 1024) return fail(h, GTO_ERR_UNSUPPORTED, "robot too large for the IK kernel's LDS");
+  if (!h->ik_attr_set) {
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_ik_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    h->ik_attr_set = true;
+  }
+  hipLaunchKernelGGL(k_ik_solve, dim3(B), dim3(256), lds, h->stream, h->d_rb, h->d_px, h->d_py, h->d_pz, h->d_chunks,
+                     h->d_scenes, (const int32_t*)d_sid, (const double*)d_q0, (const double*)d_goals, (const double*)d_base, sp,
+                     B, (double*)d_q, (double*)d_cost, (int32_t*)d_it, (int32_t*)d_stat);
+  HIPCHK(h, hipGetLastError());
+  if ((rc = fetch_out(h, 0, q_out, B * ndof * sizeof(double)))) return rc;
+  if ((rc = fetch_out(h, 2, cost_out, B * sizeof(double)))) return rc;
+  if ((rc = fetch_out(h, 3, iters_out, B * sizeof(int32_t)))) return rc;
+  if ((rc = fetch_out(h, 4, status_out, B * sizeof(int32_t)))) return rc;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
   return GTO_OK;
 }
 

@@ -1328,6 +1328,34 @@ __device__ inline double fast_rcp(double x) {
   return r;
 }
 
+// Gauss-Jordan inverse (no pivoting: SPD) of an 8x8 block held one entry per lane, lane = 8 r + c; pivot
+// row/column moved by cross-lane shuffles; returns 1 if a pivot is not positive
+__device__ inline int gj_invert8(double& S, int lane, int r, int c) {
+  int bad = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const double pjj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(S), j * 9),
+                                        __builtin_amdgcn_readlane(__double2loint(S), j * 9));
+    const double prj = __shfl(S, (lane & 56) | j, 64);
+    const double pjc = __shfl(S, j * 8 + c, 64);
+    if (!(pjj > 0.0)) bad = 1;
+    const double piv = fast_rcp(pjj);
+    const double tcol = -prj * piv;
+    const double in_row = (c == j) ? piv : pjc * piv;           // pivot row
+    const double off_row = (c == j) ? tcol : fma(tcol, pjc, S);  // other rows
+    S = (r == j) ? in_row : off_row;  // selects, not branches
+  }
+  return bad;
+}
+// y[r] = sum_c Z[r][c] z[c] for lane (r,c); every lane of row r ends up with y[r]
+__device__ inline double matvec8(double Z, double zc) {
+  double pr = Z * zc;
+  pr += __shfl_xor(pr, 1, 64);
+  pr += __shfl_xor(pr, 2, 64);
+  pr += __shfl_xor(pr, 4, 64);
+  return pr;
+}
+
 // dynamic LDS layout of k_lm_step (doubles): Z [m][64] | y [m][8] | e [m][8] | A [m][64] | bfull [m][8] |
 // x [m][8] | Q [8][T] | gaff [16] | red [16] ; then int act [m][8] ; then the kinematics scratch of
 // One workgroup of four wavefronts per instance.  Lane (r,c) = (lane>>3, lane&7) of a wave owns entry
@@ -1576,32 +1604,8 @@ __global__ __launch_bounds__(256) void k_lm_step(const RobotDev* __restrict__ rb
     mid = m2 >= sd ? m2 : (m1 < sd ? m1 : sd);
     mid = mid < 0 ? 0 : (mid > m - 1 ? m - 1 : mid);
   }
-  // Gauss-Jordan inverse of the 8x8 block held one entry per lane; returns 1 if a pivot is not positive
-  auto gj_invert = [&](double& S) -> int {
-    int bad = 0;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const double pjj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(S), j * 9),
-                                          __builtin_amdgcn_readlane(__double2loint(S), j * 9));
-      const double prj = __shfl(S, (lane & 56) | j, 64);
-      const double pjc = __shfl(S, j * 8 + c, 64);
-      if (!(pjj > 0.0)) bad = 1;
-      const double piv = fast_rcp(pjj);
-      const double tcol = -prj * piv;
-      const double in_row = (c == j) ? piv : pjc * piv;           // pivot row
-      const double off_row = (c == j) ? tcol : fma(tcol, pjc, S);  // other rows
-      S = (r == j) ? in_row : off_row;  // selects, not branches
-    }
-    return bad;
-  };
-  // y[r] = sum_c Z[r][c] z[c] for lane (r,c); every lane of row r ends up with y[r]
-  auto matvec = [&](double Z, double zc) -> double {
-    double pr = Z * zc;
-    pr += __shfl_xor(pr, 1, 64);
-    pr += __shfl_xor(pr, 2, 64);
-    pr += __shfl_xor(pr, 4, 64);
-    return pr;
-  };
+  auto gj_invert = [&](double& S) -> int { return gj_invert8(S, lane, r, c); };
+  auto matvec = [&](double Z, double zc) -> double { return matvec8(Z, zc); };
   if (wave == 0) {
     int fail = 0;
     double zp = 0.0, yp = 0.0;
@@ -1770,6 +1774,263 @@ __global__ __launch_bounds__(256) void k_lm_step(const RobotDev* __restrict__ rb
     bp.dbg[8] = clock64();
     bp.dbg[9] = s_dense;
     bp.dbg[0] = t_dbg0;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Inverse kinematics (gto/ik_solver.py:30-110): T = 1,
+//   min_q sum_k ||T_g(q) p_k - RT G p_k||^2 + w_obstacle sum_pts c_obs[off(x(q))],  lo <= q <= hi.
+// One workgroup per goal pose runs the WHOLE projected Levenberg-Marquardt loop (same rules as the
+// trajectory solve, oracle: solve_ik_instance): the problem has n <= 8 unknowns, so nothing leaves the
+// chip between iterations.  Per evaluation: FK on the matrix cores (fk_mfma_tree), pose term in closed
+// form in the gripper-cloud moments (goal_terms_wave with a one-goal set), collision term by the four
+// waves over the link-uniform chunks of surface points: per link the sum of the cost and of the gradient
+// wrenches (y x w, w), folded per wave and then in wave order (bit-reproducible); the collision term is
+// the PLAIN sum of the cost and enters the gradient only: b = J^T r + (w/2) sum_l sum_{j in anc(l)} s_j . v_l.
+__host__ __device__ inline int ik_lds_doubles(int F, int L, int n) {
+  return fk_tab_doubles(F, L, n) + 2 * F + fk_scratch_doubles(F) + L * 12 + GTO_MAX_OPT * 6 + 24 + 2 * BLK_STRIDE + 4 * L * 8 +
+         2 * 64 + 2 * 8 + 8 + 8 + 8 + GTO_MAX_DOF + 16;
+}
+
+__global__ __launch_bounds__(256) void k_ik_solve(const RobotDev* __restrict__ rb, const double* __restrict__ px,
+                                                  const double* __restrict__ py, const double* __restrict__ pz,
+                                                  const Chunk* __restrict__ chunks, const SceneDev* __restrict__ scenes,
+                                                  const int32_t* __restrict__ scene_id, const double* __restrict__ q0,
+                                                  const double* __restrict__ goals, const double* __restrict__ base_pos,
+                                                  SolveParams sp, int B, double* __restrict__ q_out,
+                                                  double* __restrict__ cost_out, int32_t* __restrict__ iters_out,
+                                                  int32_t* __restrict__ status_out) {
+  extern __shared__ __attribute__((aligned(16))) double smem_ik[];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int F = rb->n_frames, L = rb->n_links, n = rb->n_opt, ndof = rb->ndof;
+  double* s_tab = smem_ik;
+  double* s_sc = s_tab + fk_tab_doubles(F, L, n);
+  double* s_X = s_sc + 2 * F;
+  double* s_vis = s_X + fk_scratch_doubles(F);
+  double* s_screw = s_vis + L * 12;
+  double* s_gaff = s_screw + GTO_MAX_OPT * 6;  // gripper and ee affines
+  double* s_gblk = s_gaff + 24;                // pose-term blocks (BLK_JTJ, BLK_JTR); goal_terms_wave clears a second one
+  double* s_acc = s_gblk + 2 * BLK_STRIDE;     // [4 waves][L][8]: wrench sum (6), cost sum, -
+  double* s_A = s_acc + 4 * L * 8;             // [2][64]
+  double* s_b = s_A + 2 * 64;                  // [2][8]
+  double* s_x = s_b + 2 * 8;                   // current iterate (optimised joints)
+  double* s_xt = s_x + 8;                      // trial
+  double* s_step = s_xt + 8;                   // projected step
+  double* s_qf = s_step + 8;                   // full configuration (parameter joints as given)
+  double* s_red = s_qf + GTO_MAX_DOF;          // [16]
+  const bool collide = scene_id != nullptr;
+  {
+    const int nt = fk_tab_doubles(F, L, n);
+    for (int k = tid; k < nt; k += 256) s_tab[k] = rb->fk_tab[k];
+    if (tid < ndof) s_qf[tid] = q0[(size_t)b * ndof + tid];
+    if (tid < 8) {
+      double v = 0.0;
+      if (tid < n) v = fmin(fmax(q0[(size_t)b * ndof + rb->opt_index[tid]], rb->lower[tid]), rb->upper[tid]);
+      s_xt[tid] = v;
+      s_x[tid] = v;
+    }
+  }
+  SceneDev sc = {};
+  double bx = 0.0, by = 0.0, bz = 0.0, cx = 0.0, cy = 0.0, cz = 0.0;
+  if (collide) {
+    sc = scenes[scene_id[b]];
+    bx = base_pos[3 * b], by = base_pos[3 * b + 1], bz = base_pos[3 * b + 2];
+    cx = (bx - sc.ox) * sc.rinv, cy = (by - sc.oy) * sc.rinv, cz = (bz - sc.oz) * sc.rinv;
+  }
+  SolveParams sp1 = sp;
+  sp1.use_standoff = 0;
+  const int r = lane >> 3, c = lane & 7;
+  double f = INFINITY, lambda = sp.lambda0, nu = 2.0, pred = 0.0;
+  int first = 1, k = 0, status = GTO_STATUS_MAX_ITER, slot = 0;  // slot: which of s_A/s_b holds the current iterate
+  __syncthreads();
+  for (;; ++k) {
+    // ---- evaluate the trial configuration
+    if (tid < F) {
+      const int jt = rb->joint_type[tid], dq = rb->q_index[tid];
+      double a = 0.0, cs = 1.0;
+      if (dq >= 0) {
+        const int j = rb->opt_of_dof[dq];
+        const double qv = j >= 0 ? s_xt[j] : s_qf[dq];
+        if (jt == GTO_JOINT_REVOLUTE) sincos(qv, &a, &cs);
+        else if (jt == GTO_JOINT_PRISMATIC) a = qv;
+      }
+      s_sc[2 * tid] = a;
+      s_sc[2 * tid + 1] = cs;
+    }
+    for (int i = tid; i < 4 * L * 8; i += 256) s_acc[i] = 0.0;
+    __syncthreads();
+    fk_mfma_tree(rb, s_tab, s_sc, s_X, reinterpret_cast<int*>(s_X + 32 * F + 64), tid, s_vis, s_screw);
+    if (tid < 24) {  // gripper and ee frames from the transposed results X_f = G_f^T (row-major)
+      const double* Xg = s_X + (rb->fk_rounds & 1) * 16 * F;
+      const int fsel = tid < 12 ? rb->frame_gripper : rb->frame_ee, e = tid % 12;
+      s_gaff[tid] = Xg[16 * fsel + 4 * (e & 3) + (e >> 2)];
+    }
+    __syncthreads();
+    double f_pos = 0.0;
+    if (wave == 0) {
+      const GoalOut go = goal_terms_wave(rb, sp1, goals + (size_t)b * 16, 1, nullptr, s_gaff, s_screw, s_gblk, lane);
+      f_pos = go.f_goal;
+      if (lane == 0) s_red[0] = f_pos;
+    }
+    if (collide) {
+      const int nC = rb->n_chunks;
+      const int c0 = (int)(((long)nC * wave) / 4), c1 = (int)(((long)nC * (wave + 1)) / 4);
+      const bool need_grad = sp.grad_mode == GTO_GRAD_CENTRAL_DIFF;
+      double a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0, a6 = 0;
+      int cur_link = -1;
+      auto flush = [&]() {
+        const double t0 = wave_sum(a0), t1 = wave_sum(a1), t2 = wave_sum(a2), t3 = wave_sum(a3), t4 = wave_sum(a4),
+                     t5 = wave_sum(a5), t6 = wave_sum(a6);
+        if (lane == 0) {
+          double* dst = s_acc + (wave * L + cur_link) * 8;
+          dst[0] += t0, dst[1] += t1, dst[2] += t2, dst[3] += t3, dst[4] += t4, dst[5] += t5, dst[6] += t6;
+        }
+        a0 = a1 = a2 = a3 = a4 = a5 = a6 = 0.0;
+      };
+      for (int ci = c0; ci < c1; ++ci) {
+        const int link = chunks[ci].link, start = chunks[ci].start, count = chunks[ci].count;
+        if (link != cur_link) {
+          if (cur_link >= 0) flush();
+          cur_link = link;
+        }
+        if (lane < count) {
+          const double x0 = px[start + lane], x1 = py[start + lane], x2 = pz[start + lane];
+          const double* V = s_vis + link * 12;
+          const double y0 = V[0] * x0 + V[1] * x1 + V[2] * x2 + V[3];
+          const double y1 = V[4] * x0 + V[5] * x1 + V[6] * x2 + V[7];
+          const double y2 = V[8] * x0 + V[9] * x1 + V[10] * x2 + V[11];
+          const int ix = voxel_axis_fast(y0, cx, bx, sc.ox, sc.res, sc.rinv, sc.nx);
+          const int iy = voxel_axis_fast(y1, cy, by, sc.oy, sc.res, sc.rinv, sc.ny);
+          const int iz = voxel_axis_fast(y2, cz, bz, sc.oz, sc.res, sc.rinv, sc.nz);
+          const int off = iz + sc.nz * (iy + sc.ny * ix);
+          const double4 lo4 = *reinterpret_cast<const double4*>(&sc.r_obs[off]);
+          a6 += (double)__builtin_bit_cast(float, (unsigned)__double2loint(lo4.w));
+          if (need_grad) {
+            const double w0 = lo4.x * sc.inv2r, w1 = lo4.y * sc.inv2r, w2 = lo4.z * sc.inv2r;
+            a0 += y1 * w2 - y2 * w1;
+            a1 += y2 * w0 - y0 * w2;
+            a2 += y0 * w1 - y1 * w0;
+            a3 += w0;
+            a4 += w1;
+            a5 += w2;
+          }
+        }
+      }
+      if (cur_link >= 0) flush();
+    }
+    __syncthreads();
+    // ---- fold: normal equations and objective of the trial into slot 1 - slot
+    const int ts_ = first ? slot : 1 - slot;
+    if (tid < 64) s_A[ts_ * 64 + tid] = s_gblk[BLK_JTJ + tid];
+    if (tid >= 64 && tid < 72) {
+      const int i = tid - 64;
+      double g = 0.0;
+      if (i < n && collide) {
+        const double* si = s_screw + 6 * i;
+        for (int l = 0; l < L; ++l) {
+          if (!((rb->link_anc[l] >> i) & 1u)) continue;
+          double v[6];
+#pragma unroll
+          for (int e = 0; e < 6; ++e) v[e] = ((s_acc[(0 * L + l) * 8 + e] + s_acc[(1 * L + l) * 8 + e]) + s_acc[(2 * L + l) * 8 + e]) + s_acc[(3 * L + l) * 8 + e];
+          g += si[0] * v[0] + si[1] * v[1] + si[2] * v[2] + si[3] * v[3] + si[4] * v[4] + si[5] * v[5];
+        }
+      }
+      s_b[ts_ * 8 + i] = (i < n) ? s_gblk[BLK_JTR + i] + 0.5 * sp.w_obstacle * g : 0.0;
+    }
+    if (tid == 72) {
+      double csum = 0.0;
+      if (collide)
+        for (int l = 0; l < L; ++l)
+          csum += ((s_acc[(0 * L + l) * 8 + 6] + s_acc[(1 * L + l) * 8 + 6]) + s_acc[(2 * L + l) * 8 + 6]) + s_acc[(3 * L + l) * 8 + 6];
+      s_red[1] = sp.w_obstacle * csum;
+    }
+    __syncthreads();
+    const double f_try = s_red[0] + s_red[1];
+    // ---- accept / reject (block-uniform)
+    int done = 0;
+    if (first) {
+      first = 0;
+      f = f_try;
+      if (tid < 8) s_x[tid] = s_xt[tid];
+    } else if (f_try < f && pred > 0.0) {
+      const double df = f - f_try, rho = df / pred;
+      f = f_try;
+      slot = 1 - slot;
+      if (tid < 8) s_x[tid] = s_xt[tid];
+      const double sg = 2.0 * rho - 1.0;
+      double fac = 1.0 - sg * sg * sg;
+      fac = fmax(fac, 1.0 / 3.0);
+      lambda = fmax(lambda * fac, 1e-12);
+      nu = 2.0;
+      if (df <= sp.tol_rel_f * (1.0 + f)) {
+        status = GTO_STATUS_CONVERGED;
+        done = 1;
+      }
+    } else {
+      lambda *= nu;
+      nu *= 2.0;
+      if (lambda > 1e15) {
+        status = GTO_STATUS_CONVERGED;
+        done = 1;
+      }
+    }
+    if (done) break;
+    if (k >= sp.max_iter) {
+      status = GTO_STATUS_MAX_ITER;
+      break;
+    }
+    __syncthreads();  // s_x visible
+    // ---- step at the current iterate (wave 0): active set, damped system, Gauss-Jordan, projected trial
+    if (wave == 0) {
+      const double* A = s_A + slot * 64;
+      const double* bb = s_b + slot * 8;
+      const bool inb = r < n && c < n;
+      const double xr = s_x[r], xc = s_x[c], br = bb[r], bc = bb[c];
+      const bool ar = r >= n || (xr <= rb->lower[r < n ? r : 0] && br > 0.0) || (xr >= rb->upper[r < n ? r : 0] && br < 0.0);
+      const bool ac = c >= n || (xc <= rb->lower[c < n ? c : 0] && bc > 0.0) || (xc >= rb->upper[c < n ? c : 0] && bc < 0.0);
+      const double a = inb ? A[lane] : 0.0;
+      double S = a;
+      if (ar || ac) S = (r == c) ? 1.0 : 0.0;
+      else if (r == c) S *= (1.0 + lambda);
+      const int bad = gj_invert8(S, lane, r, c);
+      const double dr = matvec8(S, ac ? 0.0 : -bc);  // delta[r]
+      double v = fmin(fmax(xr + dr, rb->lower[r < n ? r : 0]), rb->upper[r < n ? r : 0]);
+      if (r >= n) v = 0.0;
+      const double sr = v - xr;
+      const double sc_ = __shfl(sr, c << 3, 64);  // step[c]
+      double part = a * sr * sc_;
+      if (c == 0) part += 2.0 * br * sr;
+      part = wave_sum(part);
+      double ms = (c == 0 && r < n) ? fabs(sr) : 0.0;
+      ms = wave_max(ms);
+      if (c == 0) s_xt[r] = v;
+      if (lane == 0) {
+        s_red[2] = -part;
+        s_red[3] = ms;
+        s_red[4] = __any(bad) ? 1.0 : 0.0;
+      }
+      if (lane == 0 && __any(bad)) s_red[4] = 1.0;
+    }
+    __syncthreads();
+    if (s_red[4] != 0.0) {
+      status = GTO_STATUS_NUMERICAL;
+      break;
+    }
+    if (s_red[3] < sp.tol_step) {
+      status = GTO_STATUS_CONVERGED;
+      break;
+    }
+    pred = s_red[2];
+  }
+  __syncthreads();
+  if (tid < ndof) {
+    const int j = rb->opt_of_dof[tid];
+    q_out[(size_t)b * ndof + tid] = j >= 0 ? s_x[j] : s_qf[tid];
+  }
+  if (tid == 0) {
+    if (cost_out) cost_out[b] = f;
+    if (iters_out) iters_out[b] = k;
+    if (status_out) status_out[b] = status;
   }
 }
 

@@ -168,6 +168,26 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
                            int32_t* status_out, void* stream);
 
 /*
+ * Inverse kinematics for B goal poses of link_ee: the pre-step that produces the
+ * q_solutions of plan_goalset.  T = 1 problem of gto/ik_solver.py:30-110:
+ *   min_q sum_k ||T_g(q) p_k - RT G p_k||^2 + w_obstacle * sum_pts c_obs[off(x(q))],  lo <= q <= hi,
+ * seeded at q0 (parameter joints of q0 are kept), solved by the same projected Levenberg-Marquardt as the
+ * trajectory problem; the whole iteration runs on the GPU, one workgroup per goal.
+ *   scene_id  [B] or NULL.  NULL = no collision term (IKSolver(collision_avoidance=False), :63)
+ *   q0        [B][ndof]     seed configurations (:79)
+ *   goals     [B][16]       RT of link_ee, row-major 4x4 (:83)
+ *   base_pos  [B][3] or NULL (zeros)
+ *   max_iter  iteration cap (reference IPOPT cap: 50, :76)
+ * Outputs (host, may be NULL except q_out): q_out [B][ndof], cost_out [B] objective value, iters_out,
+ * status_out as in gto_solve_batch.  The reference's err_pos / err_rot / plan cost (:88-97) follow from
+ * gto_eval_fk and gto_plan_cost.
+ * Replaces: IKSolver.setup_optimization + solve_ik (gto/ik_solver.py:30-110).
+ */
+int gto_solve_ik_batch(gto_handle* h, int32_t B, const int32_t* scene_id, const double* q0, const double* goals,
+                       const double* base_pos, int32_t max_iter, double* q_out, double* cost_out, int32_t* iters_out,
+                       int32_t* status_out);
+
+/*
  * Bind the handle to the caller's HIP stream (e.g. torch.cuda.current_stream().cuda_stream): every
  * launch and copy of every entry point then goes to that stream and the handle creates none of its
  * own.  NULL gives the handle a private non-blocking stream again (the state after gto_create).

@@ -921,6 +921,220 @@ int orc_solve_batch(const gto_robot_desc* d, const gto_solver_opts* o, const orc
   return GTO_OK;
 }
 
+/* ------------------------------------------------------------------ inverse kinematics
+ * gto/ik_solver.py:30-110 — the pre-step that produces q_solutions for plan_goalset: T = 1,
+ *   min_q  sum_k || T_g(q) p_k - RT G p_k ||^2  +  w_obstacle * sum_pts c_obs[off(x(q))]      (:47-70)
+ *   s.t.   lo <= q <= hi on the optimised joints                                               (:73)
+ * with p_k the gripper surface points, G = gripper_tf (link_gripper in the link_ee frame), the collision
+ * term the PLAIN sum of the cost (not squared, :70) over every collision link, the field shifted by
+ * base_position.  Same projected Levenberg-Marquardt as the trajectory solve, one dense block: the pose
+ * term is least squares (A = J^T J, b = J^T r); the collision term has no curvature model and enters the
+ * gradient only, 2 b = grad f, i.e. b += (w/2) sum J_pt^T grad c (central differences,
+ * gto/sdf_callback.py:90-114; zero in GTO_GRAD_ZERO mode, which is what CasADi AD sees). */
+typedef struct ik_eval {
+  double f_pos, f_obs;
+  double A[NMAX * NMAX], b[NMAX];
+} ik_eval;
+
+static void ik_evaluate(const gto_robot_desc* d, const gto_solver_opts* o, const orc_field* fld, const double* base,
+                        const double* q, const double* RT16, int want_deriv, ik_eval* ev) {
+  const int n = d->n_opt;
+  orc_kin* k = (orc_kin*)malloc(sizeof(orc_kin));
+  kin_compute(d, q, k);
+  memset(ev->A, 0, sizeof ev->A);
+  memset(ev->b, 0, sizeof ev->b);
+  /* pose term: gripper points against their goal positions */
+  const double* Ag = k->frames + 12 * d->frame_gripper;
+  const unsigned ancg = k->anc[d->frame_gripper];
+  double Y[12];
+  goal_target(k, d, RT16, NULL, Y);
+  double fp = 0.0;
+  for (int p = 0; p < d->n_gripper_points; ++p) {
+    double xa[3], xb[3], r[3];
+    aff_apply(Ag, d->gripper_points + 3 * p, xa);
+    aff_apply(Y, d->gripper_points + 3 * p, xb);
+    for (int c = 0; c < 3; ++c) {
+      r[c] = xa[c] - xb[c];
+      fp += r[c] * r[c];
+    }
+    if (want_deriv) {
+      double J[3][NMAX];
+      for (int j = 0; j < n; ++j) {
+        double col[3] = {0, 0, 0};
+        if (ancg >> j & 1u) point_jac_col(k, j, xa, col);
+        J[0][j] = col[0];
+        J[1][j] = col[1];
+        J[2][j] = col[2];
+      }
+      for (int i = 0; i < n; ++i) {
+        ev->b[i] += J[0][i] * r[0] + J[1][i] * r[1] + J[2][i] * r[2];
+        for (int j = 0; j < n; ++j) ev->A[i * n + j] += J[0][i] * J[0][j] + J[1][i] * J[1][j] + J[2][i] * J[2][j];
+      }
+    }
+  }
+  ev->f_pos = fp;
+  /* collision term */
+  double fo = 0.0;
+  if (fld) {
+    double gsum[NMAX];
+    for (int j = 0; j < n; ++j) gsum[j] = 0.0;
+    for (int p = 0; p < d->n_points; ++p) {
+      int l = d->point_link[p];
+      double y[3], x[3];
+      aff_apply(k->vis + 12 * l, d->points + 3 * p, y);
+      for (int c = 0; c < 3; ++c) x[c] = y[c] + base[c];
+      int32_t idx[3];
+      voxel_index(fld, x, idx);
+      fo += field_value(fld, fld->c_obs, idx);
+      if (want_deriv && o->grad_mode == GTO_GRAD_CENTRAL_DIFF) {
+        double g[3];
+        field_grad(fld, fld->c_obs, idx, g);
+        if (g[0] != 0.0 || g[1] != 0.0 || g[2] != 0.0) {
+          unsigned anc = k->anc[d->link_frame[l]];
+          for (int j = 0; j < n; ++j)
+            if (anc >> j & 1u) {
+              double col[3];
+              point_jac_col(k, j, y, col);
+              gsum[j] += g[0] * col[0] + g[1] * col[1] + g[2] * col[2];
+            }
+        }
+      }
+    }
+    if (want_deriv)
+      for (int j = 0; j < n; ++j) ev->b[j] += 0.5 * o->w_obstacle * gsum[j];
+  }
+  ev->f_obs = o->w_obstacle * fo;
+  free(k);
+}
+
+static void solve_ik_instance(const gto_robot_desc* d, const gto_solver_opts* o, const orc_field* fld,
+                              const double* base, const double* q0, const double* RT16, double* q_out,
+                              double* cost_out, int32_t* iters_out, int32_t* status_out) {
+  const int n = d->n_opt;
+  double qtry[GTO_MAX_DOF], x[NMAX], xtry[NMAX];
+  for (int i = 0; i < d->ndof; ++i) qtry[i] = q0[i];
+  for (int j = 0; j < n; ++j) {
+    double v = q0[d->opt_index[j]];
+    if (v < d->lower[j]) v = d->lower[j];
+    if (v > d->upper[j]) v = d->upper[j];
+    xtry[j] = v;
+  }
+  ik_eval cur, tri;
+  double lambda = o->lambda0, nu = 2.0, f = INFINITY, pred = 0.0;
+  int status = GTO_STATUS_MAX_ITER, first = 1, k = 0;
+  for (;; ++k) {
+    for (int j = 0; j < n; ++j) qtry[d->opt_index[j]] = xtry[j];
+    ik_evaluate(d, o, fld, base, qtry, RT16, 1, &tri);
+    const double f_try = tri.f_pos + tri.f_obs;
+    int done = 0;
+    if (first) {
+      first = 0;
+      memcpy(x, xtry, sizeof x);
+      f = f_try;
+      cur = tri;
+    } else if (f_try < f && pred > 0.0) {
+      double df = f - f_try, rho = df / pred;
+      memcpy(x, xtry, sizeof x);
+      f = f_try;
+      cur = tri;
+      double s = 2.0 * rho - 1.0, fac = 1.0 - s * s * s;
+      if (fac < 1.0 / 3.0) fac = 1.0 / 3.0;
+      lambda *= fac;
+      if (lambda < 1e-12) lambda = 1e-12;
+      nu = 2.0;
+      if (df <= o->tol_rel_f * (1.0 + f)) {
+        status = GTO_STATUS_CONVERGED;
+        done = 1;
+      }
+    } else {
+      lambda *= nu;
+      nu *= 2.0;
+      if (lambda > 1e15) {
+        status = GTO_STATUS_CONVERGED;
+        done = 1;
+      }
+    }
+    if (done) break;
+    if (k >= o->max_iter) {
+      status = GTO_STATUS_MAX_ITER;
+      break;
+    }
+    int act[NMAX];
+    double D[NMAX * NMAX], rhs[NMAX], dx[NMAX], e[NMAX], L[NMAX * NMAX], C[NMAX * NMAX];
+    for (int i = 0; i < n; ++i) act[i] = (x[i] <= d->lower[i] && cur.b[i] > 0.0) || (x[i] >= d->upper[i] && cur.b[i] < 0.0);
+    for (int i = 0; i < n; ++i) {
+      for (int j = 0; j < n; ++j) {
+        double v = cur.A[i * n + j];
+        if (act[i] || act[j]) v = (i == j) ? 1.0 : 0.0;
+        else if (i == j) v *= (1.0 + lambda);
+        D[i * n + j] = v;
+      }
+      rhs[i] = act[i] ? 0.0 : -cur.b[i];
+      e[i] = 0.0;
+    }
+    if (!block_tridiag_solve(1, n, D, e, rhs, dx, L, C)) {
+      status = GTO_STATUS_NUMERICAL;
+      break;
+    }
+    double maxstep = 0.0;
+    for (int i = 0; i < n; ++i) {
+      double v = x[i] + dx[i];
+      if (v < d->lower[i]) v = d->lower[i];
+      if (v > d->upper[i]) v = d->upper[i];
+      xtry[i] = v;
+      dx[i] = v - x[i];
+      if (fabs(dx[i]) > maxstep) maxstep = fabs(dx[i]);
+    }
+    if (maxstep < o->tol_step) {
+      status = GTO_STATUS_CONVERGED;
+      break;
+    }
+    double bts = 0.0, sAs = 0.0;
+    for (int i = 0; i < n; ++i) {
+      bts += cur.b[i] * dx[i];
+      double r = 0.0;
+      for (int j = 0; j < n; ++j) r += cur.A[i * n + j] * dx[j];
+      sAs += dx[i] * r;
+    }
+    pred = -(2.0 * bts + sAs);
+  }
+  for (int i = 0; i < d->ndof; ++i) q_out[i] = q0[i]; /* parameter joints as given (optas/solver.py:139-157) */
+  for (int j = 0; j < n; ++j) q_out[d->opt_index[j]] = x[j];
+  if (cost_out) *cost_out = f;
+  if (iters_out) *iters_out = k;
+  if (status_out) *status_out = status;
+}
+
+/* Same contract as gto_solve_ik_batch.  scene_id NULL: no collision term (collision_avoidance=False). */
+int orc_solve_ik_batch(const gto_robot_desc* d, const gto_solver_opts* o, const orc_scene* scenes, int32_t B,
+                       const int32_t* scene_id, const double* q0, const double* goals, const double* base_pos,
+                       double* q_out, double* cost_out, int32_t* iters_out, int32_t* status_out, int32_t n_threads) {
+  if (d->n_opt > NMAX || d->n_frames > GTO_MAX_FRAMES || d->n_links > GTO_MAX_LINKS || d->ndof > GTO_MAX_DOF)
+    return GTO_ERR_UNSUPPORTED;
+#ifdef _OPENMP
+  if (n_threads > 0) omp_set_num_threads(n_threads);
+#pragma omp parallel for schedule(dynamic, 1)
+#endif
+  for (int b = 0; b < B; ++b) {
+    orc_field fld;
+    const orc_field* pf = NULL;
+    double base[3] = {0, 0, 0};
+    if (scene_id) {
+      const orc_scene* sc = scenes + scene_id[b];
+      fld.c_all = sc->c_all;
+      fld.c_obs = sc->c_obs ? sc->c_obs : sc->c_all;
+      memcpy(fld.shape, sc->shape, sizeof sc->shape);
+      memcpy(fld.origin, sc->origin, sizeof sc->origin);
+      fld.res = sc->res;
+      pf = &fld;
+      if (base_pos) memcpy(base, base_pos + 3 * (size_t)b, sizeof base);
+    }
+    solve_ik_instance(d, o, pf, base, q0 + (size_t)b * d->ndof, goals + (size_t)b * 16, q_out + (size_t)b * d->ndof,
+                      cost_out ? cost_out + b : NULL, iters_out ? iters_out + b : NULL, status_out ? status_out + b : NULL);
+  }
+  return GTO_OK;
+}
+
 /* Objective terms at given trajectories (same contract as gto_eval_objective). */
 int orc_eval_objective(const gto_robot_desc* d, const gto_solver_opts* o, const orc_scene* scenes,
                        int32_t B, int32_t n_max, const int32_t* scene_id, const double* goals,

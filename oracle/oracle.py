@@ -253,6 +253,29 @@ class Oracle:
             return Q, dQ, cost, iters, status, ftr
         return Q, dQ, cost, iters, status
 
+    def solve_ik_batch(self, scene_id, q0, goals, base_pos=None, max_iter=50, n_threads=0):
+        """IK for B goal poses (gto/ik_solver.py:78-110).  scene_id None: no collision term.
+        Returns (q (B,ndof), cost (B,), iters (B,), status (B,))."""
+        d = self.desc
+        q0 = _f64(q0).reshape(-1, d.ndof)
+        B = q0.shape[0]
+        goals = _f64(goals).reshape(B, 16)
+        sid = None if scene_id is None else _i32(np.broadcast_to(np.asarray(scene_id), (B,)))
+        base = _f64(np.broadcast_to(_f64([0, 0, 0] if base_pos is None else base_pos).reshape(-1, 3), (B, 3)))
+        q, cost = np.empty((B, d.ndof)), np.empty(B)
+        iters, status = np.empty(B, dtype=np.int32), np.empty(B, dtype=np.int32)
+        opts = CSolverOpts.from_buffer_copy(self.opts)
+        opts.max_iter = max_iter
+        f = self.lib.orc_solve_ik_batch
+        f.argtypes = [C.POINTER(CRobotDesc), C.POINTER(CSolverOpts), C.POINTER(CScene), C.c_int32, _pi, _pd, _pd, _pd,
+                      _pd, _pd, _pi, _pi, C.c_int32]
+        f.restype = C.c_int
+        rc = f(C.byref(self._cdesc), C.byref(opts), self._scene_array(), B, _p(sid, _pi), _p(q0, _pd), _p(goals, _pd),
+               _p(base, _pd), _p(q, _pd), _p(cost, _pd), _p(iters, _pi), _p(status, _pi), n_threads)
+        if rc != 0:
+            raise RuntimeError(f"orc_solve_ik_batch failed ({rc})")
+        return q, cost, iters, status
+
     def eval_objective(self, scene_id, goals, n_goals, standoff, base_pos, Q):
         d, T = self.desc, self.T
         Q = _f64(Q).reshape(-1, d.ndof, T)

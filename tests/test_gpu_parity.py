@@ -313,3 +313,30 @@ def test_other_horizons_match_oracle(capi, oracle_mod, T, offset):
     with pytest.raises(capi.GTOError, match="T must be"):
         capi.SolverHandle(prob.desc, prob.cfg["link_ee"], prob.cfg["link_gripper"],
                           oracle_mod.reference_opts(T=97, standoff_offset=-10), device=0)
+
+
+@pytest.mark.parametrize("robot,collide,grad_mode", [("panda", False, 0), ("panda", True, 0), ("panda", True, 1),
+                                                      ("fetch", True, 0), ("fetch", False, 0)])
+def test_ik_matches_oracle(capi, oracle_mod, robot, collide, grad_mode):
+    """gto_solve_ik_batch (one workgroup per goal, whole LM loop on the GPU) against the CPU restatement of
+    gto/ik_solver.py: same iteration counts and status, q within 1e-6 rad, objective to 1e-8 relative."""
+    prob = Problem(robot, B=12, scene_seed=5)
+    h, o = make_pair(capi, oracle_mod, prob, grad_mode=grad_mode)
+    rng = np.random.default_rng(1)
+    q0 = np.tile(np.array(prob.cfg["default_pose"]), (12, 1))
+    oi = prob.desc.opt_index
+    q0[6:, oi] = prob.qgoal[6:, 0][:, oi] + rng.uniform(-0.3, 0.3, size=(6, len(oi)))  # half far, half near seeds
+    sid = 0 if collide else None
+    qg, fg, itg, stg = h.solve_ik_batch(sid, q0, prob.goals[:, 0], prob.base, max_iter=50)
+    qo, fo, ito, sto = o.solve_ik_batch(sid, q0, prob.goals[:, 0], prob.base, max_iter=50)
+    np.testing.assert_array_equal(itg, ito)
+    np.testing.assert_array_equal(stg, sto)
+    np.testing.assert_allclose(qg, qo, rtol=0, atol=1e-6)
+    np.testing.assert_allclose(fg, fo, rtol=1e-8, atol=1e-12)
+    # max_iter = 0 returns the clipped seed
+    q1, _, it1, st1 = h.solve_ik_batch(sid, q0, prob.goals[:, 0], prob.base, max_iter=0)
+    assert (it1 == 0).all() and (st1 == 1).all()
+    np.testing.assert_allclose(q1[:, oi], np.clip(q0[:, oi], prob.desc.lower[oi], prob.desc.upper[oi]), atol=0)
+    with pytest.raises(capi.GTOError, match="scene"):
+        h.solve_ik_batch(7, q0, prob.goals[:, 0], prob.base)
+    h.close()

@@ -118,3 +118,40 @@ def test_fetch_planner_and_surface_points(oracle_mod):
     co, do = orc.plan_cost(0, plan[None], [0.0, 0.1, 0.0])
     np.testing.assert_allclose([cost, dist], [co[0], do[0]], rtol=1e-12)
     robot.close()
+
+
+def test_ik_solver_surface_matches_oracle(oracle_mod):
+    """IKSolver called the way examples/pybullet_gto_planning.py:142,245,260 calls the reference:
+    solve_ik(q0 (ndof,1), RT, sdf_cost_obstacle, base_position) -> (q, err_pos, err_rot, cost); then the
+    batched form over all candidate grasps, which then feed plan_goalset as q_solutions."""
+    rng = np.random.default_rng(5)
+    cfg, robot, planner, orc, c_all, c_obs, RT, qsol = _setup("panda", oracle_mod, 6, rng)
+    ik = g.IKSolver(robot, cfg["link_ee"], cfg["link_gripper"], collision_avoidance=True)
+    ik.setup_optimization()
+    qc = np.array(cfg["default_pose"])
+    base = np.zeros(3)
+    q, err_pos, err_rot, cost = ik.solve_ik(qc.reshape(-1, 1), RT[0], c_obs, base)
+    qo, fo, ito, sto = orc.solve_ik_batch(0, qc[None], RT[0].reshape(1, 16), base, max_iter=50)
+    assert q.shape == (robot.ndof,)
+    np.testing.assert_allclose(q, qo[0], atol=1e-6)
+    fe = robot.desc.frame_index(cfg["link_ee"])
+    Tf = orc.eval_fk(qo)[0, fe]
+    assert err_pos == pytest.approx(np.linalg.norm(RT[0][:3, 3] - Tf[:3, 3]), abs=1e-7)
+    assert 0.0 <= err_rot <= 180.0
+    _, _, val, _ = orc.eval_points(0, qo, base, use_obs=True)
+    assert cost == pytest.approx(val.sum(), rel=1e-9, abs=1e-12)
+    np.testing.assert_allclose(ik.solve_fk(q), orc.eval_fk(q[None])[0, fe], atol=1e-12)
+    # all candidates at once, then the planner consumes the solutions that meet the reference's thresholds
+    qb, ep, er, cb, it, st = ik.solve_ik_batch(qc, RT, c_obs, base)
+    qob, _, itob, stob = orc.solve_ik_batch(0, np.tile(qc, (6, 1)), RT.reshape(6, 16), base, max_iter=50)
+    np.testing.assert_array_equal(it, itob)
+    np.testing.assert_allclose(qb, qob, atol=1e-6)
+    ok = (ep < 0.01) & (er < 5)  # examples/pybullet_gto_planning.py:262
+    assert ok.any()
+    plan, dQ, c = planner.plan_goalset(qc, RT[ok], c_all, c_obs, base, qb[ok].T.astype(np.float32))
+    assert plan.shape == (robot.ndof, 50) and np.isfinite(c).all()
+    # no collision term: sdf not needed
+    ik2 = g.IKSolver(robot, cfg["link_ee"], cfg["link_gripper"], collision_avoidance=False)
+    q2, ep2, er2, c2 = ik2.solve_ik(qc, RT[1])
+    assert c2 == 0.0 and q2.shape == (robot.ndof,)
+    robot.close()

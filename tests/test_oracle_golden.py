@@ -108,3 +108,38 @@ def test_stored_plan_invariants():
     viol = np.maximum(d.lower[o, None] - plans[:, o], plans[:, o] - d.upper[o, None]).max()
     assert viol <= 1.0e-8 + 1e-12
     assert np.ptp(plans[:, d.param_index, :], axis=2).max() == 0.0
+
+
+def test_ik_oracle_recovers_reachable_poses(oracle_mod):
+    """IK restatement (gto/ik_solver.py:30-110): goal poses generated by FK of in-limit configurations are
+    reached from a nearby seed; the objective at the solution is the collision term alone; a goal-free
+    field only shifts the value, never the minimiser, in GTO_GRAD_ZERO mode (what CasADi AD sees)."""
+    from helpers import Problem
+    prob = Problem("panda", B=6, scene_seed=2)
+    o = oracle_mod.Oracle(prob.desc, prob.cfg["link_ee"], prob.cfg["link_gripper"], oracle_mod.reference_opts())
+    prob.finish(o.eval_fk)
+    o.set_scene(*prob.scene_args())
+    rng = np.random.default_rng(0)
+    q_goal = prob.qgoal[:, 0]
+    q0 = q_goal.copy()
+    oi = prob.desc.opt_index
+    q0[:, oi] += rng.uniform(-0.2, 0.2, size=(6, len(oi)))
+    q0[:, oi] = np.clip(q0[:, oi], prob.desc.lower[oi], prob.desc.upper[oi])
+    q, f, it, st = o.solve_ik_batch(None, q0, prob.goals[:, 0], max_iter=50, n_threads=1)
+    fe = prob.desc.frame_index(prob.cfg["link_ee"])
+    Tf = o.eval_fk(q)[:, fe]
+    RT = prob.goals[:, 0].reshape(6, 4, 4)
+    assert np.abs(Tf[:, :3, 3] - RT[:, :3, 3]).max() < 1e-5
+    assert np.abs(Tf[:, :3, :3] - RT[:, :3, :3]).max() < 1e-4
+    assert (f < 1e-8).all() and (st == 0).all() and (it <= 50).all()
+    # parameter joints are returned as given, optimised joints stay inside their limits
+    pi = prob.desc.param_index
+    np.testing.assert_array_equal(q[:, pi], q0[:, pi])
+    assert (q[:, oi] >= prob.desc.lower[oi]).all() and (q[:, oi] <= prob.desc.upper[oi]).all()
+    # collision term with zero gradient: same minimiser, objective shifted by w * sum(c)
+    oz = oracle_mod.Oracle(prob.desc, prob.cfg["link_ee"], prob.cfg["link_gripper"], oracle_mod.reference_opts(grad_mode=1))
+    oz.set_scene(*prob.scene_args())
+    qz, fz, itz, _ = oz.solve_ik_batch(0, q0, prob.goals[:, 0], prob.base, max_iter=50, n_threads=1)
+    np.testing.assert_allclose(qz, q, atol=1e-4)  # the constant shift moves the relative-decrease stop a little
+    _, _, val, _ = oz.eval_points(0, qz, prob.base, use_obs=True)
+    np.testing.assert_allclose(fz, 10.0 * val.sum(axis=1), rtol=1e-6, atol=1e-7)
