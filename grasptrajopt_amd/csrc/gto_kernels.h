@@ -236,7 +236,7 @@ __device__ inline void wave_sync() {
 
 // Forward kinematics of TWO configurations at once by one wavefront: lanes 0-31 work on s_q[0..],
 // s_fr[0..], lanes 32-63 on s_q[GTO_MAX_DOF..], s_fr[GTO_MAX_FRAMES*12..] (same math as fk_block).
-__device__ inline void fk_pair_wave(const RobotDev* rb, const double* s_q2, double* s_fr2, int lane) {
+__device__ __forceinline__ void fk_pair_wave(const RobotDev* rb, const double* s_q2, double* s_fr2, int lane) {
   const int half = lane >> 5, l = lane & 31;
   const double* s_q = s_q2 + half * GTO_MAX_DOF;
   double* s_fr = s_fr2 + half * GTO_MAX_FRAMES * 12;
@@ -382,7 +382,7 @@ __host__ __device__ inline int fk_scratch_doubles(int F) { return 32 * F + 64 + 
 //   s_tab  LDS copy of RobotDev::fk_tab       s_sc [F][2] sin, cos | q, 1 | 0, 1 per frame
 //   s_X    [2][F][16] + dummy [64] scratch    s_anc [2][GTO_MAX_FRAMES] scratch
 // Every thread of the workgroup must call it (it contains barriers); the results are visible after it.
-__device__ inline void fk_mfma_tree(const RobotDev* __restrict__ rb, const double* __restrict__ s_tab,
+__device__ __forceinline__ void fk_mfma_tree(const RobotDev* __restrict__ rb, const double* __restrict__ s_tab,
                                     const double* __restrict__ s_sc, double* __restrict__ s_X, int* __restrict__ s_anc,
                                     int tid, double* __restrict__ s_vis, double* __restrict__ s_screw,
                                     long long* dbgp = nullptr) {
@@ -599,7 +599,7 @@ struct ObsLds {  // dynamic LDS layout (offsets in doubles), computed identicall
 };
 
 struct InstState;
-__device__ inline void trial_goal_terms_wave(const RobotDev* rb, const BatchPtrs& bp, const SolveParams& sp, int B,
+__device__ __forceinline__ void trial_goal_terms_wave(const RobotDev* rb, const BatchPtrs& bp, const SolveParams& sp, int B,
                                              int b, int lane, int trial, InstState* st, double* s_q, double* s_fr,
                                              double* s_gaff, double* s_gscr);
 
@@ -1053,7 +1053,7 @@ struct GoalOut {
   int argmin;
 };
 
-__device__ inline void goal_target(const double* grip_ee, const double* RT16, const double* S16, double* Y) {
+__device__ __forceinline__ void goal_target(const double* grip_ee, const double* RT16, const double* S16, double* Y) {
   const double* Tg = grip_ee;
   const double* Te = grip_ee + 12;
   double inv[12], G[12], RT[12];
@@ -1072,7 +1072,7 @@ __device__ inline void goal_target(const double* grip_ee, const double* RT16, co
 }
 
 // sum_k || A p_k - Y p_k ||^2 = tr(D M D^T) + 2 d.(D mu) + K |d|^2, D = R_A - R_Y, d = t_A - t_Y
-__device__ inline double goal_cost_moments(const RobotDev* rb, const double* A, const double* Y) {
+__device__ __forceinline__ double goal_cost_moments(const RobotDev* rb, const double* A, const double* Y) {
   double D[9], d[3];
   for (int r = 0; r < 3; ++r) {
     for (int c = 0; c < 3; ++c) D[3 * r + c] = A[4 * r + c] - Y[4 * r + c];
@@ -1091,7 +1091,7 @@ __device__ inline double goal_cost_moments(const RobotDev* rb, const double* A, 
 }
 
 // 6x6 Gram sum X^T X (packed upper, 21) and gradient sum X^T r (6) of the point-matching residuals
-__device__ inline void goal_gram_moments(const RobotDev* rb, const double* A, const double* Y, double* W21, double* v6) {
+__device__ __forceinline__ void goal_gram_moments(const RobotDev* rb, const double* A, const double* Y, double* W21, double* v6) {
   const double K = rb->grip_count;
   double R[9], t[3], D[9], d[3];
   for (int r = 0; r < 3; ++r) {
@@ -1146,7 +1146,7 @@ __device__ inline void goal_gram_moments(const RobotDev* rb, const double* A, co
 }
 
 // One wavefront.  s_gaff [2][24], s_gscr [2][GTO_MAX_OPT*6] in LDS.  goalblk_out: [2][BLK_STRIDE] or null.
-__device__ inline GoalOut goal_terms_wave(const RobotDev* rb, const SolveParams& sp, const double* goals, int n_goals,
+__device__ __forceinline__ GoalOut goal_terms_wave(const RobotDev* rb, const SolveParams& sp, const double* goals, int n_goals,
                                           const double* standoff, const double* s_gaff, const double* s_gscr,
                                           double* goalblk_out, int lane) {
   // cost of every goal in the set, lanes stride over goals
@@ -1222,7 +1222,7 @@ __device__ inline GoalOut goal_terms_wave(const RobotDev* rb, const SolveParams&
 // Goal terms + velocity term of the trial trajectory; one wavefront per instance.  Forward kinematics
 // is needed at two waypoints only (final and standoff); the obstacle kernel does its own.
 // s_q [GTO_MAX_DOF], s_fr [GTO_MAX_FRAMES*12], s_gaff [48], s_gscr [2*GTO_MAX_OPT*6] are LDS scratch.
-__device__ inline void trial_goal_terms_wave(const RobotDev* rb, const BatchPtrs& bp, const SolveParams& sp, int B,
+__device__ __forceinline__ void trial_goal_terms_wave(const RobotDev* rb, const BatchPtrs& bp, const SolveParams& sp, int B,
                                              int b, int lane, int trial, InstState* st, double* s_q, double* s_fr,
                                              double* s_gaff, double* s_gscr) {
   const int T = sp.T, n = rb->n_opt, ndof = rb->ndof;
@@ -1321,7 +1321,7 @@ __global__ __launch_bounds__(256) void k_lm_init(const RobotDev* __restrict__ rb
 }
 
 // 1/x to full double precision: hardware seed + two Newton steps (no IEEE division sequence)
-__device__ inline double fast_rcp(double x) {
+__device__ __forceinline__ double fast_rcp(double x) {
   double r = __builtin_amdgcn_rcp(x);
   r = fma(fma(-x, r, 1.0), r, r);
   r = fma(fma(-x, r, 1.0), r, r);
@@ -1330,7 +1330,7 @@ __device__ inline double fast_rcp(double x) {
 
 // Gauss-Jordan inverse (no pivoting: SPD) of an 8x8 block held one entry per lane, lane = 8 r + c; pivot
 // row/column moved by cross-lane shuffles; returns 1 if a pivot is not positive
-__device__ inline int gj_invert8(double& S, int lane, int r, int c) {
+__device__ __forceinline__ int gj_invert8(double& S, int lane, int r, int c) {
   int bad = 0;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
@@ -1348,7 +1348,7 @@ __device__ inline int gj_invert8(double& S, int lane, int r, int c) {
   return bad;
 }
 // y[r] = sum_c Z[r][c] z[c] for lane (r,c); every lane of row r ends up with y[r]
-__device__ inline double matvec8(double Z, double zc) {
+__device__ __forceinline__ double matvec8(double Z, double zc) {
   double pr = Z * zc;
   pr += __shfl_xor(pr, 1, 64);
   pr += __shfl_xor(pr, 2, 64);
@@ -1384,6 +1384,8 @@ __global__ __launch_bounds__(256) void k_lm_step(const RobotDev* __restrict__ rb
   const long long t_dbg0 = bp.dbg ? clock64() : 0;
   // P4 writes joint (tid & 7) of some waypoints: its frame, looked up long before it is needed
   const int nF = rb->n_frames, my_frame = (tid & 7) < n ? rb->opt_frame[tid & 7] : 0;
+  // ... and its limits: every (waypoint, joint) item of this thread has joint index tid & 7
+  const double my_lo = (tid & 7) < n ? rb->lower[tid & 7] : 0.0, my_hi = (tid & 7) < n ? rb->upper[tid & 7] : 0.0;
   double* __restrict__ qfb = bp.qf + (size_t)b * T * nF;
 
   // ---- P0: objective of the trial point (every wave computes it: cheaper than a broadcast)
@@ -1519,7 +1521,7 @@ __global__ __launch_bounds__(256) void k_lm_step(const RobotDev* __restrict__ rb
         bv += alpha * (qt - qm);
         if (t < T - 1) bv -= alpha * (s_Q[i * T + t + 1] - qt);
         // active set: on a bound with the descent direction pointing outward
-        act = (qt <= rb->lower[i] && bv > 0.0) || (qt >= rb->upper[i] && bv < 0.0);
+        act = (qt <= my_lo && bv > 0.0) || (qt >= my_hi && bv < 0.0);
       }
       s_b[idx] = bv;
       actv[u] = act;
@@ -1721,7 +1723,7 @@ __global__ __launch_bounds__(256) void k_lm_step(const RobotDev* __restrict__ rb
     if (i < n) {
       const double q0 = s_Q[i * T + t];
       double v = q0 + s_x[idx];
-      v = fmin(fmax(v, rb->lower[i]), rb->upper[i]);
+      v = fmin(fmax(v, my_lo), my_hi);
       Qt[(size_t)i * T + t] = v;
       qfb[(size_t)t * nF + my_frame] = v;  // the obstacle kernel reads joint values by frame
       s_Q[i * T + t] = v;
