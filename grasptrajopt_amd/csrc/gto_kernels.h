@@ -1434,22 +1434,50 @@ __global__ __launch_bounds__(256) void k_lm_step(const RobotDev* __restrict__ rb
     slot = trial;
   }
   const int argmin_cur = accept ? argmin_try : argmin_cur0;
-  // current iterate into LDS (rows >= n are padding); on accept it is the trial
+  // the iterate that is current from here on: loaded first (loads return in order), copied below
+  constexpr int NQ = (8 * GTO_MAX_T + 255) / 256;
+  double qv[NQ];
   {
     const double* __restrict__ src = accept ? Qt : Qc;
-    constexpr int NQ = (8 * GTO_MAX_T + 255) / 256;
-    double v[NQ];
 #pragma unroll
     for (int u = 0; u < NQ; ++u) {
       const int idx = tid + 256 * u;
-      v[u] = (idx < n * T) ? src[idx] : 0.0;
+      qv[u] = (idx < n * T) ? src[idx] : 0.0;
     }
+  }
+  // global loads of P2 (normal equations at the iterate that is current from here on), issued now so that
+  // their latency overlaps the trajectory copy below; wave w assembles waypoints s = w, w+4, ...
+  const double* __restrict__ oblk = bp.blocks + ((size_t)slot * B + b) * T * BLK_STRIDE;
+  const double* __restrict__ gblk = bp.goalblk + ((size_t)slot * B + b) * 2 * BLK_STRIDE;
+  const double alpha = sp.alpha;
+  const bool inb = (r < n) && (c < n);
+  constexpr int KMAX = (GTO_MAX_T - 2 + 3) / 4;
+  constexpr int NU = (8 * GTO_MAX_T + 255) / 256;  // (waypoint, joint) items per thread
+  double av[KMAX];  // undamped obstacle J^T J entry (r,c) of this wave's waypoints
 #pragma unroll
-    for (int u = 0; u < NQ; ++u) {
-      const int idx = tid + 256 * u;
-      if (idx < 8 * T) s_Q[idx] = v[u];
-      if (accept && idx < n * T) Qc[idx] = v[u];
-    }
+  for (int kk = 0; kk < KMAX; ++kk) {
+    const int s = wave + 4 * kk;
+    av[kk] = (inb && s < m) ? oblk[(size_t)(s + 2) * BLK_STRIDE + BLK_JTJ + lane] : 0.0;
+  }
+  double jv[NU];  // obstacle J^T r of this thread's (waypoint, joint) items
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    const int idx = tid + 256 * u, i = idx & 7;
+    jv[u] = (idx < m * 8 && i < n) ? oblk[(size_t)((idx >> 3) + 2) * BLK_STRIDE + BLK_JTR + i] : 0.0;
+  }
+  const double gA0 = inb ? gblk[BLK_JTJ + lane] : 0.0;
+  const double gA1 = (inb && sp.use_standoff) ? gblk[BLK_STRIDE + BLK_JTJ + lane] : 0.0;
+  double gjv = 0.0;  // goal J^T r of both goal waypoints (threads 0..15), parked in LDS in P2
+  if (tid < 16) {
+    const int w = tid >> 3, i = tid & 7;
+    if (i < n && (w == 0 || sp.use_standoff)) gjv = gblk[w * BLK_STRIDE + BLK_JTR + i];
+  }
+  // current iterate into LDS (rows >= n are padding); on accept it is the trial
+#pragma unroll
+  for (int u = 0; u < NQ; ++u) {
+    const int idx = tid + 256 * u;
+    if (idx < 8 * T) s_Q[idx] = qv[u];
+    if (accept && idx < n * T) Qc[idx] = qv[u];
   }
   if (!done && k >= sp.max_iter) {
     status = GTO_STATUS_MAX_ITER;
@@ -1475,34 +1503,12 @@ __global__ __launch_bounds__(256) void k_lm_step(const RobotDev* __restrict__ rb
   if (done) GTO_FINISH(status);
 
   if (bp.dbg && b == 0 && tid == 0) bp.dbg[1] = clock64();
-  // ---- P2: normal equations at the current iterate (A = J^T J, b = J^T r; f = sum r^2)
-  // wave w assembles waypoints s = w, w+4, ...; all global loads of the phase are issued up front.
-  const double* __restrict__ oblk = bp.blocks + ((size_t)slot * B + b) * T * BLK_STRIDE;
-  const double* __restrict__ gblk = bp.goalblk + ((size_t)slot * B + b) * 2 * BLK_STRIDE;
-  const double alpha = sp.alpha;
-  const bool inb = (r < n) && (c < n);
-  constexpr int KMAX = (GTO_MAX_T - 2 + 3) / 4;
-  constexpr int NU = (8 * GTO_MAX_T + 255) / 256;  // (waypoint, joint) items per thread
-  double av[KMAX];  // undamped obstacle J^T J entry (r,c) of this wave's waypoints
-#pragma unroll
-  for (int kk = 0; kk < KMAX; ++kk) {
-    const int s = wave + 4 * kk;
-    av[kk] = (inb && s < m) ? oblk[(size_t)(s + 2) * BLK_STRIDE + BLK_JTJ + lane] : 0.0;
-  }
-  double jv[NU];  // obstacle J^T r of this thread's (waypoint, joint) items
-#pragma unroll
-  for (int u = 0; u < NU; ++u) {
-    const int idx = tid + 256 * u, i = idx & 7;
-    jv[u] = (idx < m * 8 && i < n) ? oblk[(size_t)((idx >> 3) + 2) * BLK_STRIDE + BLK_JTR + i] : 0.0;
-  }
-  const double gA0 = inb ? gblk[BLK_JTJ + lane] : 0.0;
-  const double gA1 = (inb && sp.use_standoff) ? gblk[BLK_STRIDE + BLK_JTJ + lane] : 0.0;
-  if (tid < 16) {  // goal J^T r of both goal waypoints -> LDS (s_gaff is free until P6)
-    const int w = tid >> 3, i = tid & 7;
-    s_gaff[tid] = (i < n && (w == 0 || sp.use_standoff)) ? gblk[w * BLK_STRIDE + BLK_JTR + i] : 0.0;
-  }
+  // ---- P2: normal equations at the current iterate (A = J^T J, b = J^T r; f = sum r^2); its global loads
+  // were issued in P1, as soon as the slot was known
+  if (tid < 16) s_gaff[tid] = gjv;
   if (tid == 0) *s_first_dense = m;
   __syncthreads();
+  if (bp.dbg && b == 0 && tid == 0) bp.dbg[28] = clock64();
   int actv[NU];
 #pragma unroll
   for (int u = 0; u < NU; ++u) actv[u] = 1;
@@ -1535,6 +1541,7 @@ __global__ __launch_bounds__(256) void k_lm_step(const RobotDev* __restrict__ rb
     if (idx < m * 8 && (idx & 7) == 0) s_actm[idx >> 3] = (int)((bal >> (lane & 56)) & 0xffull);
   }
   __syncthreads();
+  if (bp.dbg && b == 0 && tid == 0) bp.dbg[29] = clock64();
   // undamped blocks -> s_A, damped / frozen system -> s_Z; remember which blocks are purely diagonal.
   // Everything that depends on the lane only is hoisted; the two waypoints that carry goal terms are
   // patched afterwards by the wave that owns them, so the loop body is a dozen instructions.
@@ -1573,6 +1580,7 @@ __global__ __launch_bounds__(256) void k_lm_step(const RobotDev* __restrict__ rb
     }
     if (lane == 0 && first < m) atomicMin(s_first_dense, first);
   }
+  if (bp.dbg && b == 0 && tid == 0) bp.dbg[30] = clock64();
   for (int idx = tid; idx < m * 8; idx += 256) {
     const int sI = idx >> 3, i = idx & 7;
     const int a0 = (s_actm[sI] >> i) & 1;
