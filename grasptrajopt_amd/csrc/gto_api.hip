@@ -44,7 +44,7 @@ struct gto_handle {
   int dbg_cut = 0;
   size_t dbg_extra_lds = 0;  // GTO_DEBUG_EXTRA_LDS: occupancy experiments  // GTO_DEBUG_CUT: timing experiments only, results are garbage
   int n_groups = 1;
-  int obs_tg = 1;  // waypoints per workgroup of the obstacle kernel (grouping measured slower: DESIGN.md section 7)
+  int obs_tg = 2;  // waypoints per workgroup of the obstacle kernel: two share the table staging, the FK barriers and the launch overhead
   long long* dbg = nullptr;
   hipStream_t gstream[GTO_MAX_GROUPS] = {nullptr};
   hipEvent_t ev_fork = nullptr, ev_join[GTO_MAX_GROUPS] = {nullptr};
@@ -154,7 +154,7 @@ int gto_create(const gto_robot_desc* d, const gto_solver_opts* opts, int device,
   if (const char* e = getenv("GTO_DEBUG_CUT")) h->dbg_cut = atoi(e);
   if (const char* e = getenv("GTO_DEBUG_EXTRA_LDS")) h->dbg_extra_lds = (size_t)atoi(e);
   if (const char* e = getenv("GTO_OBS_TG")) h->obs_tg = std::max(1, std::min(GTO_MAX_TG, atoi(e)));
-  if (getenv("GTO_DEBUG_TIMING")) { (void)hipMalloc((void**)&h->dbg, 32 * sizeof(long long)); (void)hipMemset(h->dbg, 0, 32 * sizeof(long long)); }
+  if (getenv("GTO_DEBUG_TIMING")) { (void)hipMalloc((void**)&h->dbg, 48 * sizeof(long long)); (void)hipMemset(h->dbg, 0, 48 * sizeof(long long)); }
   RobotDev& rb = h->rb;
   memset(&rb, 0, sizeof rb);
   rb.n_frames = d->n_frames;
@@ -729,6 +729,7 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
   const int T = sp.T;
   h->last_launches = 0;
   h->last_ms = 0.0;
+  if (h->dbg) HIPCHK(h, hipMemsetAsync(h->dbg + 40, 0, 8 * sizeof(long long), st));
 
   // The batch is split into up to GTO_MAX_GROUPS independent groups, each with its own HIP stream: the
   // step kernel of one group (latency-bound, few workgroups) overlaps the obstacle kernel of the
@@ -826,11 +827,12 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
   HIPCHK(h, hipGetLastError());
   if (h->dbg) {
     HIPCHK(h, hipStreamSynchronize(st));
-    long long t[32];
+    long long t[48];
     HIPCHK(h, hipMemcpy(t, h->dbg, sizeof t, hipMemcpyDeviceToHost));
     fprintf(stderr, "[gto dbg] step-kernel phases (cycles) P0+P1 %lld | P2 %lld | diag %lld | dense %lld | back %lld | P4 %lld | P5 %lld | s_dense %lld\n",
             t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3], t[5] - t[4], t[6] - t[5], t[7] - t[6], t[9]);
     fprintf(stderr, "[gto dbg] P2 split (cycles): loads+barrier %lld | b-vector+masks %lld | blocks %lld | e,y+barrier %lld\n", t[28] - t[1], t[29] - t[28], t[30] - t[29], t[2] - t[30]);
+    fprintf(stderr, "[gto dbg] obstacle workgroups of active instances: %lld, with a margin %lld, culled %lld (over the whole solve)\n", t[40], t[41] + t[42], t[41]);
     fprintf(stderr, "[gto dbg] fk_mfma_tree (cycles): local %lld | rounds %lld %lld %lld %lld | outputs %lld\n", t[21] - t[20], t[22] - t[21], t[23] - t[22], t[24] - t[23], t[25] - t[24], t[27] - t[25]);
     fprintf(stderr, "[gto dbg] obstacle WG (b=0,t=T-1) cycles: prologue %lld | broad %lld | loop %lld | epilogue %lld | active chunks %lld | prologue up to the chain %lld\n",
             t[11] - t[10], t[12] - t[11], t[13] - t[12], t[14] - t[13], t[15], t[16] - t[10]);

@@ -359,7 +359,7 @@ __device__ inline double quad_perm(double v) {
 __host__ __device__ inline int fk_tab_doubles(int F, int L, int n) { return 64 * F + 16 * L + 16 * n + L + 2 * n + F; }
 // LDS scratch (doubles) of fk_mfma_tree next to the table: X ping-pong [2][F][16], a dummy store target [64],
 // ancestors [2][GTO_MAX_FRAMES] int
-__host__ __device__ inline int fk_scratch_doubles(int F) { return 32 * F + 64 + GTO_MAX_FRAMES; }
+__host__ __device__ inline int fk_scratch_doubles(int F, int ng = 1) { return ng * 32 * F + 64 + GTO_MAX_FRAMES; }
 
 // Forward kinematics of ONE configuration by a 256-thread workgroup on the FP64 matrix cores: visual
 // transforms of the collision links (gto/gto_models.py:92-100) and world screws of the optimised joints.
@@ -382,17 +382,20 @@ __host__ __device__ inline int fk_scratch_doubles(int F) { return 32 * F + 64 + 
 //   s_tab  LDS copy of RobotDev::fk_tab       s_sc [F][2] sin, cos | q, 1 | 0, 1 per frame
 //   s_X    [2][F][16] + dummy [64] scratch    s_anc [2][GTO_MAX_FRAMES] scratch
 // Every thread of the workgroup must call it (it contains barriers); the results are visible after it.
-__device__ __forceinline__ void fk_mfma_tree(const RobotDev* __restrict__ rb, const double* __restrict__ s_tab,
+__device__ __forceinline__ void fk_mfma_tree(const RobotDev* __restrict__ rb, const double* __restrict__ s_tab, int ng,
                                     const double* __restrict__ s_sc, double* __restrict__ s_X, int* __restrict__ s_anc,
                                     int tid, double* __restrict__ s_vis, double* __restrict__ s_screw,
                                     long long* dbgp = nullptr) {
+  // `ng` configurations are advanced together, stage by stage, so that they share the barriers:
+  // s_sc [ng][F][2], s_X [ng][2][F][16] then a dummy store target [64], s_anc [2][GTO_MAX_FRAMES] (the
+  // ancestors do not depend on the configuration), s_vis [ng][L][12], s_screw [ng][GTO_MAX_OPT][6]
   const int F = rb->n_frames, L = rb->n_links, n = rb->n_opt;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: the compiler must see it as wave-uniform
   const int ra = lane >> 4, rc = lane & 3, blk = (lane >> 2) & 3;
   const int e = 4 * ra + rc, et = 4 * rc + ra;
   const double ident = (ra == rc) ? 1.0 : 0.0;
   const int nGf = (F + 3) >> 2;
-  double* s_dummy = s_X + 32 * F;  // target of the stores of blocks that have nothing to say
+  double* s_dummy = s_X + ng * 32 * F;  // target of the stores of blocks that have nothing to say
   const double* tVo = s_tab + 64 * F;
   const double* tU = tVo + 16 * L;
   const double* tI = tU + 16 * n;  // link_frame [L], opt_frame [n], prismatic flag [n], parent [F] as doubles
@@ -406,19 +409,20 @@ __device__ __forceinline__ void fk_mfma_tree(const RobotDev* __restrict__ rb, co
     if (g >= nGf) continue;  // wave-uniform
     const int f0 = 4 * g + blk, f = f0 < F ? f0 : F - 1;
     const double* kt = s_tab + 64 * f;
-    const double sn = s_sc[2 * f], cs = s_sc[2 * f + 1];
-    const double Me = fma(sn, kt[48 + e], fma(cs, kt[32 + e], kt[16 + e]));
-    const double X = __builtin_amdgcn_mfma_f64_4x4x4f64(Me, kt[et], 0.0, 0, 0, 0);
+    const double c0 = kt[16 + e], c1 = kt[32 + e], K = kt[48 + e], Ot = kt[et];
     areg[k] = (int)tI[L + 2 * n + f];
-    *(f0 < F ? s_X + 16 * f + e : s_dummy + lane) = X;
+    for (int kq = 0; kq < ng; ++kq) {
+      const double sn = s_sc[2 * (kq * F + f)], cs = s_sc[2 * (kq * F + f) + 1];
+      const double Me = fma(sn, K, fma(cs, c1, c0));
+      const double X = __builtin_amdgcn_mfma_f64_4x4x4f64(Me, Ot, 0.0, 0, 0, 0);
+      *(f0 < F ? s_X + kq * 32 * F + 16 * f + e : s_dummy + lane) = X;
+    }
     s_anc[f] = areg[k];  // sixteen lanes, one value
   }
   __syncthreads();
   if (dbgp && tid == 0) dbgp[1] = clock64();
   int cur = 0;
   for (int rd = 0; rd < rb->fk_rounds; ++rd) {
-    const double* Xc = s_X + cur * 16 * F;
-    double* Xw = s_X + (1 - cur) * 16 * F;
     const int* Ac = s_anc + cur * GTO_MAX_FRAMES;
     int* Aw = s_anc + (1 - cur) * GTO_MAX_FRAMES;
 #pragma unroll
@@ -427,39 +431,53 @@ __device__ __forceinline__ void fk_mfma_tree(const RobotDev* __restrict__ rb, co
       if (g >= nGf) continue;
       const int f0 = 4 * g + blk, f = f0 < F ? f0 : F - 1;
       const int a = areg[k], ac = a >= 0 ? a : 0;
-      const double Aop = Xc[16 * f + et];  // A[i][k] = X_f[i][k]
-      const double Bx = Xc[16 * ac + e];   // B[k][j] = X_anc[k][j]
       const int a2x = Ac[ac];
-      const double X = __builtin_amdgcn_mfma_f64_4x4x4f64(Aop, a >= 0 ? Bx : ident, 0.0, 0, 0, 0);
+      for (int kq = 0; kq < ng; ++kq) {
+        const double* Xc = s_X + kq * 32 * F + cur * 16 * F;
+        double* Xw = s_X + kq * 32 * F + (1 - cur) * 16 * F;
+        const double Aop = Xc[16 * f + et];  // A[i][k] = X_f[i][k]
+        const double Bx = Xc[16 * ac + e];   // B[k][j] = X_anc[k][j]
+        const double X = __builtin_amdgcn_mfma_f64_4x4x4f64(Aop, a >= 0 ? Bx : ident, 0.0, 0, 0, 0);
+        *(f0 < F ? Xw + 16 * f + e : s_dummy + lane) = X;
+      }
       areg[k] = a >= 0 ? a2x : -1;
-      *(f0 < F ? Xw + 16 * f + e : s_dummy + lane) = X;
       Aw[f] = areg[k];
     }
     __syncthreads();
     cur = 1 - cur;
     if (dbgp && tid == 0) dbgp[2 + rd] = clock64();
   }
-  const double* Xg = s_X + cur * 16 * F;  // X_f = G_f^T, row-major
   // output groups: first the links (four per MFMA), then the optimised joints, dealt round-robin to the waves
   const int nGl = (L + 3) >> 2, nGj = (n + 3) >> 2;
   for (int og = wave; og < nGl + nGj; og += 4) {
     if (og < nGl) {
       // D lane l holds V^T[l>>4][l&3] = V[l&3][l>>4]
       const int l1 = 4 * og + blk, l = l1 < L ? l1 : L - 1;
-      const double V = __builtin_amdgcn_mfma_f64_4x4x4f64(tVo[16 * l + e], Xg[16 * (int)tI[l] + e], 0.0, 0, 0, 0);
-      *((l1 < L && rc < 3) ? s_vis + 12 * l + 4 * rc + ra : s_dummy + lane) = V;
+      const double Vo = tVo[16 * l + e];
+      const int fl = (int)tI[l];
+      for (int kq = 0; kq < ng; ++kq) {
+        const double* Xg = s_X + kq * 32 * F + cur * 16 * F;  // X_f = G_f^T, row-major
+        const double V = __builtin_amdgcn_mfma_f64_4x4x4f64(Vo, Xg[16 * fl + e], 0.0, 0, 0, 0);
+        *((l1 < L && rc < 3) ? s_vis + (kq * L + l) * 12 + 4 * rc + ra : s_dummy + lane) = V;
+      }
     } else {
       // lanes 0-15 of a block row hold a = R u, lanes 16-31 o = frame origin
       const int j1 = 4 * (og - nGl) + blk, j = j1 < n ? j1 : n - 1;
       const bool prism = tI[L + n + j] != 0.0;
-      const double S = __builtin_amdgcn_mfma_f64_4x4x4f64(tU[16 * j + e], Xg[16 * (int)tI[L + j] + e], 0.0, 0, 0, 0);
-      const double av = S, ov = __shfl(S, (lane + 16) & 63, 64);
-      const double a1 = quad_perm<1, 2, 0, 3>(av), a2 = quad_perm<2, 0, 1, 3>(av);
-      const double o1 = quad_perm<1, 2, 0, 3>(ov), o2 = quad_perm<2, 0, 1, 3>(ov);
-      const double cr = o1 * a2 - o2 * a1;
+      const double U = tU[16 * j + e];
+      const int fj = (int)tI[L + j];
       const bool w = j1 < n && ra == 0 && rc < 3;
-      *(w ? s_screw + 6 * j + rc : s_dummy + lane) = prism ? 0.0 : av;
-      *(w ? s_screw + 6 * j + 3 + rc : s_dummy + lane) = prism ? av : cr;
+      for (int kq = 0; kq < ng; ++kq) {
+        const double* Xg = s_X + kq * 32 * F + cur * 16 * F;
+        const double S = __builtin_amdgcn_mfma_f64_4x4x4f64(U, Xg[16 * fj + e], 0.0, 0, 0, 0);
+        const double av = S, ov = __shfl(S, (lane + 16) & 63, 64);
+        const double a1 = quad_perm<1, 2, 0, 3>(av), a2 = quad_perm<2, 0, 1, 3>(av);
+        const double o1 = quad_perm<1, 2, 0, 3>(ov), o2 = quad_perm<2, 0, 1, 3>(ov);
+        const double cr = o1 * a2 - o2 * a1;
+        double* sv = s_screw + (kq * GTO_MAX_OPT + j) * 6;
+        *(w ? sv + rc : s_dummy + lane) = prism ? 0.0 : av;
+        *(w ? sv + 3 + rc : s_dummy + lane) = prism ? av : cr;
+      }
     }
   }
   if (dbgp && tid == 0) dbgp[7] = clock64();
@@ -591,7 +609,7 @@ struct ObsLds {  // dynamic LDS layout (offsets in doubles), computed identicall
     out = o;    o += TG * BLK_STRIDE;
     // also, in the prologue: operand table, sin/cos [TG][F][2] and scratch of fk_mfma_tree; in the epilogue
     // s_u; in the goal workgroups their scratch
-    const int fk = fk_tab_doubles(F, L, GTO_MAX_OPT) + TG * F * 2 + fk_scratch_doubles(F);
+    const int fk = fk_tab_doubles(F, L, GTO_MAX_OPT) + TG * F * 2 + fk_scratch_doubles(F, TG);
     list = o;   o += 4 * GTO_LIST_CAP * 8 > fk ? 4 * GTO_LIST_CAP * 8 : fk;
     active = o; o += cap_active * 2;  // int4 per entry
     total_doubles = o;
@@ -665,6 +683,7 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
   // ---- prologue.  Every global load it needs is issued here, before the first branch that depends on one
   // of them: ONE memory round trip for the instance state, the culling inputs, the joint values of the
   // frames (bp.qf, written by the step kernel) and the operand table of fk_mfma_tree.
+  if (sp.dbg_cut == 6) return;
   const int done = st->done, slot_cur = st->slot;
   const bool cull_try = TG == 1 && !fixed_mode;
   const int mg = cull_try ? bp.margin[(size_t)b * T + t0w] : -1;
@@ -687,11 +706,13 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
   // Temporal culling (exact): if at configuration qref every chunk of this waypoint was at least
   // `margin` voxels clear of any non-zero voxel, and no surface point can have moved further than that
   // since (|dx| <= sum_j |dq_j| reach_j), the waypoint still contributes exact zeros: write them and leave.
+  if (bp.dbg && tid == 0 && !fixed_mode) atomicAdd((unsigned long long*)(bp.dbg + 40), 1ull);
   if (mg >= 0) {  // block-uniform
     double dsum = tid < n ? fabs(dq_try - dq_ref) * rb->reach[tid] : 0.0;
     if (tid < 64) dsum = wave_sum(dsum);
     if (tid == 0) s_nactive = (rb->reach[0] >= 0.0 && (int)ceil(dsum * scenes[bp.scene_id[b]].rinv) <= mg) ? 1 : 0;
     __syncthreads();
+    if (bp.dbg && tid == 0) atomicAdd((unsigned long long*)(bp.dbg + (s_nactive ? 41 : 42)), 1ull);
     if (s_nactive) {
       double* out = bp.blocks + (((size_t)(1 - slot_cur) * B + b) * T + t0w) * BLK_STRIDE;
       if (tid < BLK_STRIDE) out[tid] = (tid == BLK_SS) ? bp.ss_fixed[4 * b + (t0w < sp.ts ? 2 : 3)] : 0.0;
@@ -699,6 +720,7 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
     }
     __syncthreads();
   }
+  if (sp.dbg_cut == 7) return;
   // sin/cos of every (waypoint, joint), one lane each
   if (tid < ng * F) {
     double a = 0.0, c = 1.0;
@@ -723,13 +745,11 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
   if (tid == 0) s_nactive = 0;
   __syncthreads();
   if (dbg_wg && tid == 0) bp.dbg[16] = clock64();
+  if (sp.dbg_cut == 8) return;
   {
     double* s_X = s_sc + 2 * ng * F;
-    for (int kq = 0; kq < ng; ++kq) {
-      fk_mfma_tree(rb, s_ktab, s_sc + 2 * kq * F, s_X, reinterpret_cast<int*>(s_X + 32 * F + 64), tid, s_vis + kq * L * 12,
-                   s_screw + kq * GTO_MAX_OPT * 6, dbg_wg ? bp.dbg + 20 : nullptr);
-      if (kq + 1 < ng) __syncthreads();  // scratch reuse
-    }
+    fk_mfma_tree(rb, s_ktab, ng, s_sc, s_X, reinterpret_cast<int*>(s_X + ng * 32 * F + 64), tid, s_vis, s_screw,
+                 dbg_wg ? bp.dbg + 20 : nullptr);
   }
   __syncthreads();
   if (dbg_wg && tid == 0) bp.dbg[11] = clock64();
@@ -1869,7 +1889,7 @@ __global__ __launch_bounds__(256) void k_ik_solve(const RobotDev* __restrict__ r
     }
     for (int i = tid; i < 4 * L * 8; i += 256) s_acc[i] = 0.0;
     __syncthreads();
-    fk_mfma_tree(rb, s_tab, s_sc, s_X, reinterpret_cast<int*>(s_X + 32 * F + 64), tid, s_vis, s_screw);
+    fk_mfma_tree(rb, s_tab, 1, s_sc, s_X, reinterpret_cast<int*>(s_X + 32 * F + 64), tid, s_vis, s_screw);
     if (tid < 24) {  // gripper and ee frames from the transposed results X_f = G_f^T (row-major)
       const double* Xg = s_X + (rb->fk_rounds & 1) * 16 * F;
       const int fsel = tid < 12 ? rb->frame_gripper : rb->frame_ee, e = tid % 12;
