@@ -622,7 +622,7 @@ __device__ __forceinline__ void trial_goal_terms_wave(const RobotDev* rb, const 
                                              double* s_gaff, double* s_gscr);
 
 #ifndef GTO_OBS_MIN_WAVES
-#define GTO_OBS_MIN_WAVES 4  // waves per SIMD the register allocator must leave room for
+#define GTO_OBS_MIN_WAVES 3  // waves per SIMD the register allocator must leave room for (LDS allows 3 workgroups per CU at two waypoints each)
 #endif
 __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const RobotDev* __restrict__ rb, const double* __restrict__ px,
                                                        const double* __restrict__ py, const double* __restrict__ pz,
