@@ -118,7 +118,7 @@ static int validate_opts(const gto_solver_opts* o, std::string& why) {
 
 static size_t lm_lds_bytes(int T) {
   size_t m = (size_t)T - 2;
-  size_t dbl = m * 128 + 4 * m * 8 + 8 * (size_t)T + 16 + 16;
+  size_t dbl = m * 64 + 4 * m * 8 + 8 * (size_t)T + 16 + 16;
   return dbl * sizeof(double) + m * 8 * sizeof(int) + 64;
 }
 

@@ -1376,7 +1376,7 @@ __device__ __forceinline__ double matvec8(double Z, double zc) {
   return pr;
 }
 
-// dynamic LDS layout of k_lm_step (doubles): Z [m][64] | y [m][8] | e [m][8] | A [m][64] | bfull [m][8] |
+// dynamic LDS layout of k_lm_step (doubles): Z [m][64] | y [m][8] | e [m][8] | bfull [m][8] |
 // x [m][8] | Q [8][T] | gaff [16] | red [16] ; then int act [m][8] ; then the kinematics scratch of
 // One workgroup of four wavefronts per instance.  Lane (r,c) = (lane>>3, lane&7) of a wave owns entry
 // (r,c) of the 8x8 blocks; the data-parallel phases (assembly, projected step, predicted decrease) are
@@ -1390,8 +1390,7 @@ __global__ __launch_bounds__(256) void k_lm_step(const RobotDev* __restrict__ rb
   double* s_Z = smem;
   double* s_y = s_Z + (size_t)m * 64;
   double* s_e = s_y + m * 8;
-  double* s_A = s_e + m * 8;
-  double* s_b = s_A + (size_t)m * 64;
+  double* s_b = s_e + m * 8;
   double* s_x = s_b + m * 8;
   double* s_Q = s_x + m * 8;
   double* s_gaff = s_Q + 8 * T;
@@ -1562,9 +1561,9 @@ __global__ __launch_bounds__(256) void k_lm_step(const RobotDev* __restrict__ rb
   }
   __syncthreads();
   if (bp.dbg && b == 0 && tid == 0) bp.dbg[29] = clock64();
-  // undamped blocks -> s_A, damped / frozen system -> s_Z; remember which blocks are purely diagonal.
-  // Everything that depends on the lane only is hoisted; the two waypoints that carry goal terms are
-  // patched afterwards by the wave that owns them, so the loop body is a dozen instructions.
+  // undamped entries stay in registers (av[kk], read again by P5: same wave, same waypoints), the damped /
+  // frozen system goes to s_Z; remember which blocks are purely diagonal.  Everything that depends on the
+  // lane only is hoisted; the two waypoints that carry goal terms are patched by the wave that owns them.
   const bool diagl = r == c;
   const double dadd = (inb && diagl) ? 2.0 * alpha : 0.0;  // velocity term of an interior waypoint
   const double idv = diagl ? 1.0 : 0.0, dmul = diagl ? 1.0 + lambda : 1.0;
@@ -1572,31 +1571,23 @@ __global__ __launch_bounds__(256) void k_lm_step(const RobotDev* __restrict__ rb
   constexpr unsigned long long kOffDiag = ~0x8040201008040201ull;  // lanes (r,c) with r != c
   {
     int first = m;  // first dense block seen by this wave
+    const int s_goal = T - 3, s_stand = sp.use_standoff ? sp.ts - 2 : -1;
 #pragma unroll
     for (int kk = 0; kk < KMAX; ++kk) {
       const int s = wave + 4 * kk;
       if (s < m) {  // wave-uniform
-        const double a = fma(sp.w_obstacle, av[kk], dadd);
+        double a = fma(sp.w_obstacle, av[kk], dadd);
+        if (s == s_goal) {  // goal waypoint T-1: goal block; its velocity term is alpha, not 2 alpha
+          a += gA0;
+          if (inb && diagl) a -= alpha;
+        }
+        if (s == s_stand) a += gA1;  // standoff waypoint
         const bool frozen = (s_actm[s] & lane_bits) != 0;
         const double v = frozen ? idv : a * dmul;
-        s_A[(size_t)s * 64 + lane] = a;
+        av[kk] = a;
         s_Z[(size_t)s * 64 + lane] = v;
         if ((__ballot(v != 0.0) & kOffDiag) && s < first) first = s;
       }
-    }
-    // goal waypoints: T-1 (also: its velocity term is alpha, not 2 alpha) and the standoff waypoint
-#pragma unroll
-    for (int which = 0; which < 2; ++which) {
-      const int s = (which == 0 ? T - 1 : sp.ts) - 2;
-      if (which == 1 && !sp.use_standoff) continue;
-      if ((s & 3) != wave || s < 0 || s >= m) continue;  // wave-uniform
-      double a = s_A[(size_t)s * 64 + lane] + (which == 0 ? gA0 : gA1);
-      if (which == 0 && inb && diagl) a -= alpha;
-      const bool frozen = (s_actm[s] & lane_bits) != 0;
-      const double v = frozen ? idv : a * dmul;
-      s_A[(size_t)s * 64 + lane] = a;
-      s_Z[(size_t)s * 64 + lane] = v;
-      if ((__ballot(v != 0.0) & kOffDiag) && s < first) first = s;
     }
     if (lane == 0 && first < m) atomicMin(s_first_dense, first);
   }
@@ -1774,11 +1765,15 @@ __global__ __launch_bounds__(256) void k_lm_step(const RobotDev* __restrict__ rb
   {
     const double c0 = (c == 0) ? 2.0 : 0.0;
     double part = 0.0;
-    for (int s = wave; s < m; s += 4) {
-      const double sr = s_x[s * 8 + r], scv = s_x[s * 8 + c];
-      const double xn = (s < m - 1) ? s_x[(s + 1) * 8 + r] : 0.0;
-      const double lin = c0 * fma(-alpha, xn, s_b[s * 8 + r]);
-      part = fma(sr, fma(s_A[(size_t)s * 64 + lane], scv, lin), part);
+#pragma unroll
+    for (int kk = 0; kk < KMAX; ++kk) {
+      const int s = wave + 4 * kk;
+      if (s < m) {  // wave-uniform
+        const double sr = s_x[s * 8 + r], scv = s_x[s * 8 + c];
+        const double xn = (s < m - 1) ? s_x[(s + 1) * 8 + r] : 0.0;
+        const double lin = c0 * fma(-alpha, xn, s_b[s * 8 + r]);
+        part = fma(sr, fma(av[kk], scv, lin), part);
+      }
     }
     part = wave_sum(part);
     if (lane == 0) s_red[8 + wave] = part;
