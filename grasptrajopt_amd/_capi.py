@@ -141,9 +141,13 @@ def load_library(path: Optional[str] = None):
     lib.gto_eval_obstacle_normal_eq.argtypes = [H, C.c_int32, _pi, _pd, _pd, _pd, _pd, _pd]
     lib.gto_plan_cost.argtypes = [H, C.c_int32, C.c_int32, _pd, _pd, _pd, _pd]
     lib.gto_solve_ik_batch.argtypes = [H, C.c_int32, _pi, _pd, _pd, _pd, C.c_int32, _pd, _pd, _pi, _pi]
+    _pu8 = C.POINTER(C.c_uint8)
+    lib.gto_depth_sdf_cost.argtypes = [C.c_int, _pf, C.c_int32, C.c_int32, _pd, _pd, _pd, _pd, _pu8, C.c_double, _pd, C.c_int64,
+                                       C.c_float, C.c_float, _pf, _pu8, _pf, _pd, _pu8]
     for fn in ("gto_create", "gto_set_opts", "gto_set_scene", "gto_drop_scene", "gto_solve_batch",
                "gto_solve_batch_device", "gto_last_kernel_time", "gto_set_profiling", "gto_set_stream", "gto_eval_fk",
-               "gto_eval_points", "gto_eval_objective", "gto_eval_obstacle_normal_eq", "gto_plan_cost", "gto_solve_ik_batch"):
+               "gto_eval_points", "gto_eval_objective", "gto_eval_obstacle_normal_eq", "gto_plan_cost", "gto_solve_ik_batch",
+               "gto_depth_sdf_cost"):
         getattr(lib, fn).restype = C.c_int
     if path is None:
         _lib = lib
@@ -154,7 +158,7 @@ EXPORTED_SYMBOLS = (
     "gto_default_opts", "gto_version", "gto_create", "gto_destroy", "gto_last_error", "gto_set_opts",
     "gto_set_scene", "gto_drop_scene", "gto_solve_batch", "gto_solve_batch_device",
     "gto_last_kernel_time", "gto_set_profiling", "gto_set_stream", "gto_eval_fk", "gto_eval_points",
-    "gto_eval_objective", "gto_eval_obstacle_normal_eq", "gto_plan_cost", "gto_solve_ik_batch",
+    "gto_eval_objective", "gto_eval_obstacle_normal_eq", "gto_plan_cost", "gto_solve_ik_batch", "gto_depth_sdf_cost",
 )
 
 

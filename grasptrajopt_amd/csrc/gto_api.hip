@@ -1147,4 +1147,79 @@ int gto_plan_cost(gto_handle* h, int32_t scene_id, int32_t n, const double* plan
   return GTO_OK;
 }
 
+
+// ------------------------------------------------------------------ cost field from a depth image (row f-2)
+int gto_depth_sdf_cost(int device, const float* depth, int32_t H, int32_t W, const double* K, const double* Kinv,
+                       const double* cam_pose, const double* cam_inv, const uint8_t* target_mask, double threshold,
+                       const double* query, int64_t nq, float epsilon, float w_inside, float* sdf_out,
+                       uint8_t* inside_out, float* cost_out, double* points_out, uint8_t* valid_out) {
+  if (!depth || !K || !Kinv || !cam_pose || !cam_inv || H < 1 || W < 1 || nq < 0 || (nq > 0 && !query))
+    return fail(nullptr, GTO_ERR_INVALID_ARG, "gto_depth_sdf_cost: null or empty input");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(nullptr, GTO_ERR_NO_DEVICE, "no HIP device");
+  if (device >= 0 && hipSetDevice(device) != hipSuccess) return fail(nullptr, GTO_ERR_NO_DEVICE, "hipSetDevice failed");
+  const size_t N = (size_t)H * W;
+  std::vector<void*> bufs;
+  auto dalloc = [&](size_t bytes) -> void* {
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes ? bytes : 8) != hipSuccess) return nullptr;
+    bufs.push_back(p);
+    return p;
+  };
+  auto cleanup = [&]() {
+    for (void* p : bufs) (void)hipFree(p);
+  };
+#define DCHK(expr)                                                                                     \
+  do {                                                                                                 \
+    hipError_t e_ = (expr);                                                                            \
+    if (e_ != hipSuccess) {                                                                            \
+      cleanup();                                                                                       \
+      return fail(nullptr, GTO_ERR_HIP, std::string("gto_depth_sdf_cost: ") + hipGetErrorString(e_));  \
+    }                                                                                                  \
+  } while (0)
+  float* d_depth = (float*)dalloc(N * sizeof(float));
+  double* d_mats = (double*)dalloc((9 + 9 + 16 + 16) * sizeof(double));
+  uint8_t* d_mask = target_mask ? (uint8_t*)dalloc(N) : nullptr;
+  double* d_p = (double*)dalloc(3 * N * sizeof(double));
+  uint8_t* d_valid = (uint8_t*)dalloc(N);
+  double* d_q = (double*)dalloc((size_t)nq * 3 * sizeof(double));
+  float* d_sdf = (float*)dalloc((size_t)nq * sizeof(float));
+  float* d_cost = (float*)dalloc((size_t)nq * sizeof(float));
+  uint8_t* d_in = (uint8_t*)dalloc((size_t)nq);
+  if (!d_depth || !d_mats || (target_mask && !d_mask) || !d_p || !d_valid || !d_q || !d_sdf || !d_cost || !d_in) {
+    cleanup();
+    return fail(nullptr, GTO_ERR_ALLOC, "gto_depth_sdf_cost: device allocation failed");
+  }
+  double mats[50];
+  std::memcpy(mats, K, 9 * sizeof(double));
+  std::memcpy(mats + 9, Kinv, 9 * sizeof(double));
+  std::memcpy(mats + 18, cam_pose, 16 * sizeof(double));
+  std::memcpy(mats + 34, cam_inv, 16 * sizeof(double));
+  DCHK(hipMemcpy(d_depth, depth, N * sizeof(float), hipMemcpyHostToDevice));
+  DCHK(hipMemcpy(d_mats, mats, sizeof mats, hipMemcpyHostToDevice));
+  if (target_mask) DCHK(hipMemcpy(d_mask, target_mask, N, hipMemcpyHostToDevice));
+  if (nq) DCHK(hipMemcpy(d_q, query, (size_t)nq * 3 * sizeof(double), hipMemcpyHostToDevice));
+  double *d_px = d_p, *d_py = d_p + N, *d_pz = d_p + 2 * N;
+  hipLaunchKernelGGL(k_depth_backproject, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, 0, d_depth, H, W, d_mats + 9,
+                     d_mats + 18, d_mask, threshold, d_px, d_py, d_pz, d_valid);
+  if (nq)
+    hipLaunchKernelGGL(k_depth_sdf, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, 0, d_px, d_py, d_pz, (int)N, d_depth, H, W,
+                       d_mats, d_mats + 34, d_q, (long)nq, epsilon, w_inside, d_sdf, d_in, d_cost);
+  DCHK(hipGetLastError());
+  DCHK(hipDeviceSynchronize());
+  if (sdf_out && nq) DCHK(hipMemcpy(sdf_out, d_sdf, (size_t)nq * sizeof(float), hipMemcpyDeviceToHost));
+  if (cost_out && nq) DCHK(hipMemcpy(cost_out, d_cost, (size_t)nq * sizeof(float), hipMemcpyDeviceToHost));
+  if (inside_out && nq) DCHK(hipMemcpy(inside_out, d_in, (size_t)nq, hipMemcpyDeviceToHost));
+  if (valid_out) DCHK(hipMemcpy(valid_out, d_valid, N, hipMemcpyDeviceToHost));
+  if (points_out) {
+    std::vector<double> soa(3 * N);
+    DCHK(hipMemcpy(soa.data(), d_p, 3 * N * sizeof(double), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < N; ++i)
+      for (int r = 0; r < 3; ++r) points_out[3 * i + r] = soa[(size_t)r * N + i];
+  }
+#undef DCHK
+  cleanup();
+  return GTO_OK;
+}
+
 }  // extern "C"

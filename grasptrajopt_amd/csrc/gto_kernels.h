@@ -2180,3 +2180,92 @@ __global__ __launch_bounds__(256) void k_plan_cost(const RobotDev* __restrict__ 
   __syncthreads();
   if (tid == 0) partial[(size_t)i * T + t] = s_red[0] + s_red[1] + s_red[2] + s_red[3];
 }
+
+// ------------------------------------------------------------------------------------------------
+// Cost field from a depth image (mesh_to_sdf/depth_point_cloud.py:9-141): the producer
+// of the (F,) cost arrays.  Arithmetic follows the reference's order with FMA contraction switched off
+// in these two kernels: the reference values are reproduced bit for bit (tests/golden/depth_cost.npz);
+// where the reference's BLAS products could differ in the last bit on another machine, the CPU
+// restatement (oracle, -ffp-contract=off) is matched exactly.
+// backproject (:32-52) + world transform (:21-23); invalid pixels become points at infinity
+__global__ void k_depth_backproject(const float* __restrict__ depth, int H, int W, const double* __restrict__ Kinv,
+                                    const double* __restrict__ cam, const uint8_t* __restrict__ target_mask,
+                                    double threshold, double* __restrict__ px, double* __restrict__ py,
+                                    double* __restrict__ pz, uint8_t* __restrict__ valid) {
+#pragma clang fp contract(off)  // plain operators below must stay unfused (HIP's __dmul_rn & co. are no barrier)
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= H * W) return;
+  const int y = i / W, x = i - y * W;
+  const float d = depth[i];
+  const bool ok = (d > 0.0f) && ((double)d < threshold) && (!target_mask || target_mask[i] == 0);
+  double X[3], P[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const double t = (Kinv[3 * r] * (double)x + Kinv[3 * r + 1] * (double)y) + Kinv[3 * r + 2];
+    X[r] = (double)d * t;
+  }
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+    P[r] = ((cam[4 * r] * X[0] + cam[4 * r + 1] * X[1]) + cam[4 * r + 2] * X[2]) + cam[4 * r + 3];
+  px[i] = ok ? P[0] : INFINITY;
+  py[i] = ok ? P[1] : INFINITY;
+  pz[i] = ok ? P[2] : INFINITY;
+  valid[i] = ok ? 1 : 0;
+}
+
+// get_sdf (:56-61) + is_outside (:126-141) + cost map (:84-89): one query per thread, the cloud streamed
+// through LDS in tiles; exact nearest neighbour by exhaustive search in FP64 (the KD-tree of the reference
+// returns the same distance), a few ms for 10^5 queries x 3*10^5 points at the FP64 vector rate.
+__global__ __launch_bounds__(256) void k_depth_sdf(const double* __restrict__ px, const double* __restrict__ py,
+                                                   const double* __restrict__ pz, int N, const float* __restrict__ depth,
+                                                   int H, int W, const double* __restrict__ K,
+                                                   const double* __restrict__ cam_inv, const double* __restrict__ query,
+                                                   long nq, float epsilon, float w_inside, float* __restrict__ sdf_out,
+                                                   uint8_t* __restrict__ inside_out, float* __restrict__ cost_out) {
+#pragma clang fp contract(off)  // see k_depth_backproject
+  __shared__ double sx[256], sy[256], sz[256];
+  const long q = (long)blockIdx.x * 256 + threadIdx.x;
+  const bool live = q < nq;
+  const double q0 = live ? query[3 * q] : 0.0, q1 = live ? query[3 * q + 1] : 0.0, q2 = live ? query[3 * q + 2] : 0.0;
+  double best = INFINITY;
+  for (int base = 0; base < N; base += 256) {
+    const int j = base + threadIdx.x;
+    sx[threadIdx.x] = j < N ? px[j] : INFINITY;
+    sy[threadIdx.x] = j < N ? py[j] : INFINITY;
+    sz[threadIdx.x] = j < N ? pz[j] : INFINITY;
+    __syncthreads();
+#pragma unroll 8
+    for (int k = 0; k < 256; ++k) {
+      const double dx = q0 - sx[k], dy = q1 - sy[k], dz = q2 - sz[k];
+      const double d2 = (dx * dx + dy * dy) + dz * dz;
+      best = fmin(best, d2);  // NaN (inf - inf never occurs: queries are finite) is ignored by fmin
+    }
+    __syncthreads();
+  }
+  if (!live) return;
+  float dist = (float)sqrt(best);
+  double pc[3], u[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+    pc[r] = ((cam_inv[4 * r] * q0 + cam_inv[4 * r + 1] * q1) + cam_inv[4 * r + 2] * q2) + cam_inv[4 * r + 3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+    u[r] = (K[3 * r] * pc[0] + K[3 * r + 1] * pc[1]) + K[3 * r + 2] * pc[2];
+  const double ux = u[0] / u[2], uy = u[1] / u[2];
+  // .astype(int): truncation toward zero; non-finite / out-of-range values become INT64_MIN in NumPy
+  const bool fx = fabs(ux) < 9.0e18, fy = fabs(uy) < 9.0e18;
+  const long ix = fx ? (long)ux : LONG_MIN, iy = fy ? (long)uy : LONG_MIN;
+  bool outside = true;
+  if (ix >= 0 && iy >= 0 && ix < W && iy < H) outside = pc[2] < (double)depth[iy * W + ix];
+  if (!outside) dist = -dist;
+  float c = 0.0f;
+  if (!outside) {
+    c = w_inside * (-dist + epsilon / 2.0f);
+  } else if (dist > 0.0f && dist < epsilon) {
+    const float e = dist - epsilon;
+    c = (e * e) / (2.0f * epsilon);
+  }
+  if (sdf_out) sdf_out[q] = dist;
+  if (inside_out) inside_out[q] = outside ? 0 : 1;
+  if (cost_out) cost_out[q] = c;
+}

@@ -239,6 +239,24 @@ int gto_eval_obstacle_normal_eq(gto_handle* h, int32_t B, const int32_t* scene_i
 int gto_plan_cost(gto_handle* h, int32_t scene_id, int32_t n, const double* plans,
                   const double* base_pos /*[3]*/, double* cost_out /*[n]*/, double* dist_out /*[n]*/);
 
+/*
+ * Cost field from a depth image: what the reference's DepthPointCloud does with a KD-tree on
+ * the CPU (mesh_to_sdf/depth_point_cloud.py:9-141) to produce sdf_cost_all / sdf_cost_obstacle.  Stand-alone
+ * (no handle): uses HIP device `device`.
+ *   depth [height*width] float32, row-major; K, Kinv 3x3 row-major (the reference inverts with np.linalg.inv;
+ *   pass the same inverse for bit parity); cam_pose, cam_inv 4x4 row-major (camera in the world / its inverse);
+ *   target_mask [height*width] or NULL (pixels != 0 are dropped, :41-44); threshold: depth cut-off (:13)
+ *   query [nq][3] world points (the voxel centres `workspace_points`, gto/gto_models.py:155-171)
+ * Outputs (host; each may be NULL): sdf_out [nq] signed distance to the nearest back-projected point (:56-61),
+ * inside_out [nq] = !is_outside (:126-141), cost_out [nq] = get_sdf_cost(query, epsilon, w_inside) (:64-91),
+ * points_out [height*width][3] + valid_out [height*width]: the back-projected world points in pixel order.
+ * Bit-identical to the reference on tests/golden/depth_cost.npz.
+ */
+int gto_depth_sdf_cost(int device, const float* depth, int32_t height, int32_t width, const double* K, const double* Kinv,
+                       const double* cam_pose, const double* cam_inv, const uint8_t* target_mask, double threshold,
+                       const double* query, int64_t nq, float epsilon, float w_inside, float* sdf_out,
+                       uint8_t* inside_out, float* cost_out, double* points_out, uint8_t* valid_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -19,6 +19,7 @@
  */
 #include "../include/gto_solver.h"
 
+#include <limits.h>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -284,6 +285,71 @@ void orc_sdf_cost_map(int n, const float* signed_dist, const unsigned char* insi
       c = (e * e) / (2.0f * epsilon);
     }
     cost[i] = c;
+  }
+}
+
+/* ------------------------------------------------------------------ cost field from a depth image
+ * mesh_to_sdf/depth_point_cloud.py:9-141 DepthPointCloud: the producer of the (F,) cost arrays.
+ *   backproject (:32-52): X = depth * (Kinv @ [x, y, 1]) for pixels with 0 < depth < threshold (and
+ *   target_mask == 0), row-major pixel order; points = R_cam X + t_cam (:21-23).
+ *   get_sdf (:56-61): distance to the nearest cloud point (sklearn KDTree, float64 -> float32), negated
+ *   where the query is not "outside".
+ *   is_outside (:126-141): project the query into the camera; inside the viewport it is outside iff its
+ *   camera depth is smaller than the depth image at the pixel (int() truncation); outside the viewport: outside.
+ * Kinv and cam_inv are passed in (the reference gets them from np.linalg.inv; a caller that wants bit
+ * parity passes the same). Arithmetic follows the reference's order, without FMA contraction (-ffp-contract=off). */
+/* points_out [H*W][3] in pixel order with valid_out flags; returns the number of valid points */
+int orc_depth_backproject(const float* depth, int H, int W, const double* Kinv, const double* cam,
+                          const unsigned char* target_mask, double threshold, double* points_out,
+                          unsigned char* valid_out) {
+  int n = 0;
+  for (int y = 0; y < H; ++y)
+    for (int x = 0; x < W; ++x) {
+      const int i = y * W + x;
+      const float d = depth[i];
+      const int ok = (d > 0.0f) && ((double)d < threshold) && (!target_mask || target_mask[i] == 0);
+      valid_out[i] = (unsigned char)ok;
+      /* R = Kinv @ [x, y, 1] (float64), X = depth (f32 -> f64) * R */
+      double X[3];
+      for (int r = 0; r < 3; ++r) X[r] = (double)d * (Kinv[3 * r] * (double)x + Kinv[3 * r + 1] * (double)y + Kinv[3 * r + 2] * 1.0);
+      for (int r = 0; r < 3; ++r)
+        points_out[3 * (size_t)i + r] = (cam[4 * r] * X[0] + cam[4 * r + 1] * X[1] + cam[4 * r + 2] * X[2]) + cam[4 * r + 3];
+      n += ok;
+    }
+  return n;
+}
+
+/* signed distance (float32) and inside flag of nq query points against the valid cloud points (brute force) */
+void orc_depth_sdf(const double* points, const unsigned char* valid, int H, int W, const float* depth, const double* K,
+                   const double* cam_inv, const double* query, long nq, float* sdf_out, unsigned char* inside_out) {
+  const long N = (long)H * W;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
+  for (long q = 0; q < nq; ++q) {
+    const double* p = query + 3 * q;
+    double best = INFINITY;
+    for (long i = 0; i < N; ++i) {
+      if (!valid[i]) continue;
+      const double dx = p[0] - points[3 * i], dy = p[1] - points[3 * i + 1], dz = p[2] - points[3 * i + 2];
+      const double d2 = (dx * dx + dy * dy) + dz * dz;
+      if (d2 < best) best = d2;
+    }
+    float dist = (float)sqrt(best);
+    /* is_outside */
+    double pc[3];
+    for (int r = 0; r < 3; ++r) pc[r] = (cam_inv[4 * r] * p[0] + cam_inv[4 * r + 1] * p[1] + cam_inv[4 * r + 2] * p[2]) + cam_inv[4 * r + 3];
+    double u[3];
+    for (int r = 0; r < 3; ++r) u[r] = K[3 * r] * pc[0] + K[3 * r + 1] * pc[1] + K[3 * r + 2] * pc[2];
+    const double ux = u[0] / u[2], uy = u[1] / u[2];
+    /* .astype(int): truncation toward zero; non-finite or out-of-range values become INT64_MIN in NumPy */
+    long px = (ux == ux && fabs(ux) < 9.0e18) ? (long)ux : LONG_MIN;
+    long py = (uy == uy && fabs(uy) < 9.0e18) ? (long)uy : LONG_MIN;
+    int outside = 1;
+    if (px >= 0 && py >= 0 && px < W && py < H) outside = pc[2] < (double)depth[py * W + px];
+    if (!outside) dist = -dist;
+    if (sdf_out) sdf_out[q] = dist;
+    if (inside_out) inside_out[q] = (unsigned char)!outside;
   }
 }
 

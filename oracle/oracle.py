@@ -124,6 +124,37 @@ def sdf_cost_map(signed_dist, inside, epsilon=0.02, w_inside=1.0):
     return out
 
 
+def depth_sdf_cost(depth, K, cam, target_mask, threshold, query, epsilon=0.02, w_inside=1.0):
+    """DepthPointCloud(depth, K, cam, target_mask, threshold) -> points, then get_sdf / is_outside /
+    get_sdf_cost at `query` (mesh_to_sdf/depth_point_cloud.py:9-141).  Returns (points (N,3) in pixel
+    order, sdf f32 (nq,), inside bool (nq,), cost f32 (nq,))."""
+    depth = np.ascontiguousarray(depth, dtype=np.float32)
+    H, W = depth.shape
+    K = _f64(K).reshape(3, 3)
+    cam = _f64(cam).reshape(4, 4)
+    Kinv, cam_inv = _f64(np.linalg.inv(K)), _f64(np.linalg.inv(cam))
+    tm = None if target_mask is None else np.ascontiguousarray(target_mask, dtype=np.uint8).reshape(H, W)
+    pts = np.empty((H * W, 3))
+    valid = np.empty(H * W, dtype=np.uint8)
+    pu8 = C.POINTER(C.c_uint8)
+    f = lib().orc_depth_backproject
+    f.argtypes = [_pf, C.c_int, C.c_int, _pd, _pd, pu8, C.c_double, _pd, pu8]
+    f.restype = C.c_int
+    f(_p(depth, _pf), H, W, _p(Kinv, _pd), _p(cam, _pd), None if tm is None else tm.ctypes.data_as(pu8), float(threshold),
+      _p(pts, _pd), valid.ctypes.data_as(pu8))
+    query = _f64(query).reshape(-1, 3)
+    nq = query.shape[0]
+    sdf = np.empty(nq, dtype=np.float32)
+    inside = np.empty(nq, dtype=np.uint8)
+    g = lib().orc_depth_sdf
+    g.argtypes = [_pd, pu8, C.c_int, C.c_int, _pf, _pd, _pd, _pd, C.c_long, _pf, pu8]
+    g.restype = None
+    g(_p(pts, _pd), valid.ctypes.data_as(pu8), H, W, _p(depth, _pf), _p(K, _pd), _p(cam_inv, _pd), _p(query, _pd), nq,
+      _p(sdf, _pf), inside.ctypes.data_as(pu8))
+    cost = sdf_cost_map(sdf, inside, epsilon, w_inside)
+    return pts[valid.astype(bool)], sdf, inside.astype(bool), cost
+
+
 def interpolate_waypoints(waypoints, n, m):
     w = _f64(waypoints).reshape(2, m)
     out = np.empty((n, m))

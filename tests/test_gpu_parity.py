@@ -340,3 +340,39 @@ def test_ik_matches_oracle(capi, oracle_mod, robot, collide, grad_mode):
     with pytest.raises(capi.GTOError, match="scene"):
         h.solve_ik_batch(7, q0, prob.goals[:, 0], prob.base)
     h.close()
+
+
+def test_depth_cost_field_matches_reference_golden_and_oracle(capi, oracle_mod):
+    """gto_depth_sdf_cost through the DepthPointCloud surface: bit-identical to the reference-generated
+    fixture, and to the CPU restatement on a larger random scene (ragged sizes, masked and invalid
+    pixels, queries outside the viewport and behind the camera)."""
+    import grasptrajopt_amd as g_
+    g = golden("depth_cost.npz")
+    for tag, tm in (("all", None), ("obs", g["mask"])):
+        dpc = g_.DepthPointCloud(g["depth"], g["K"], g["cam"], target_mask=tm, threshold=1.5)
+        q = g[f"{tag}_query"]
+        np.testing.assert_array_equal(dpc.points, g[f"{tag}_points"])
+        np.testing.assert_array_equal(dpc.get_sdf(q), g[f"{tag}_sdf"])
+        np.testing.assert_array_equal(~dpc.is_outside(q), g[f"{tag}_inside"])
+        np.testing.assert_array_equal(dpc.get_sdf_cost(q, epsilon=0.02, w_inside=1), g[f"{tag}_cost"])
+    rng = np.random.default_rng(3)
+    H, W = 117, 203
+    K = np.array([[180.0, 0.3, 101.2], [0, 178.5, 58.7], [0, 0, 1.0]])
+    depth = (0.6 + 0.5 * rng.random((H, W))).astype(np.float32)
+    depth[rng.random((H, W)) < 0.1] = 0.0  # invalid
+    depth[5:9, 7:40] = 2.0                 # beyond the threshold
+    mask = (rng.random((H, W)) < 0.05).astype(np.uint8)
+    a = 0.3
+    cam = np.eye(4)
+    cam[:3, :3] = np.array([[0, -np.sin(a), np.cos(a)], [-1.0, 0, 0], [0, -np.cos(a), -np.sin(a)]])
+    cam[:3, 3] = [-0.3, 0.1, 0.8]
+    q = rng.uniform([-1.0, -1.0, -0.5], [1.5, 1.0, 1.5], size=(1237, 3))
+    dpc = g_.DepthPointCloud(depth, K, cam, target_mask=mask, threshold=1.5)
+    pts, sdf, inside, cost = oracle_mod.depth_sdf_cost(depth, K, cam, mask, 1.5, q, epsilon=0.03, w_inside=2.0)
+    np.testing.assert_array_equal(dpc.points, pts)
+    np.testing.assert_array_equal(dpc.get_sdf(q), sdf)
+    np.testing.assert_array_equal(~dpc.is_outside(q), inside)
+    np.testing.assert_array_equal(dpc.get_sdf_cost(q, epsilon=0.03, w_inside=2.0), cost)
+    assert inside.any() and (~inside).any() and (cost > 0).any()
+    np.testing.assert_array_equal(dpc.get_sdf_in_batches(q, batch_size=500), sdf)
+    assert dpc.get_sdf(np.zeros((0, 3))).shape == (0,)

@@ -143,3 +143,17 @@ def test_ik_oracle_recovers_reachable_poses(oracle_mod):
     np.testing.assert_allclose(qz, q, atol=1e-4)  # the constant shift moves the relative-decrease stop a little
     _, _, val, _ = oz.eval_points(0, qz, prob.base, use_obs=True)
     np.testing.assert_allclose(fz, 10.0 * val.sum(axis=1), rtol=1e-6, atol=1e-7)
+
+
+def test_depth_cost_field_against_reference_golden(oracle_mod):
+    """Row f-2, pinned: back-projection, KD-tree distance, is_outside and the cost map of the reference's
+    DepthPointCloud (mesh_to_sdf/depth_point_cloud.py), generated by running the reference itself
+    (tests/golden/make_golden.py); the restatement reproduces every value bit for bit."""
+    g = golden("depth_cost.npz")
+    for tag, tm in (("all", None), ("obs", g["mask"])):
+        pts, sdf, inside, cost = oracle_mod.depth_sdf_cost(g["depth"], g["K"], g["cam"], tm, 1.5, g[f"{tag}_query"])
+        np.testing.assert_array_equal(pts, g[f"{tag}_points"])
+        np.testing.assert_array_equal(sdf, g[f"{tag}_sdf"])
+        np.testing.assert_array_equal(inside, g[f"{tag}_inside"])
+        np.testing.assert_array_equal(cost, g[f"{tag}_cost"])
+    assert g["all_inside"].any() and (~g["all_inside"]).any()
