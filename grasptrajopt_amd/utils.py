@@ -43,3 +43,21 @@ def interpolate_waypoints(waypoints, n: int, m: int, mode: str = "cubic") -> np.
              else interpolate.CubicSpline(x, w[:, i], bc_type="clamped"))
         data[:, i] = f(t[1:-1])
     return data
+
+
+def plan_in_collision(robot, depth_pc, plan, base_position=(0.0, 0.0, 0.0), max_points: int = 5, is_mobile: bool = False):
+    """The collision statistic of the reference's offline evaluator (examples/pybullet_evaluate_plans.py:
+    219-233): a plan collides if at some waypoint more than ``max_points`` robot surface points have a
+    negative signed distance to the observed scene.  All waypoints go to the GPU in two calls (FK of the
+    surface points, then DepthPointCloud.get_sdf) instead of a Python loop with a KD-tree query per waypoint.
+    Returns (in_collision, first_colliding_waypoint or -1, points_in_collision (T,))."""
+    plan = np.asarray(plan, dtype=np.float64)
+    T = plan.shape[1]
+    h = robot._util_handle()
+    xyz, _, _, _ = h.eval_points(0, plan.T, [0, 0, 0], want_field=False)  # (T, P, 3), robot-base frame
+    if not is_mobile:
+        xyz = xyz + np.asarray(base_position, dtype=np.float64).reshape(1, 1, 3)
+    sdf = depth_pc.get_sdf(xyz.reshape(-1, 3)).reshape(T, -1)
+    count = (sdf < 0).sum(axis=1)
+    hit = np.nonzero(count > max_points)[0]
+    return bool(hit.size), int(hit[0]) if hit.size else -1, count

@@ -155,3 +155,32 @@ def test_ik_solver_surface_matches_oracle(oracle_mod):
     q2, ep2, er2, c2 = ik2.solve_ik(qc, RT[1])
     assert c2 == 0.0 and q2.shape == (robot.ndof,)
     robot.close()
+
+
+def test_evaluator_collision_statistic_composes(oracle_mod):
+    """examples/pybullet_evaluate_plans.py:219-233 through the drop-in classes: FK surface points of every
+    waypoint + DepthPointCloud.get_sdf, batched (utils.plan_in_collision) and as the reference's loop."""
+    from grasptrajopt_amd.utils import plan_in_collision
+    rng = np.random.default_rng(9)
+    cfg, robot, planner, orc, c_all, c_obs, RT, qsol = _setup("panda", oracle_mod, 2, rng)
+    # a synthetic depth camera looking at the workspace from above: a table plane at z = 0 with a box on it
+    H, W = 60, 80
+    K = np.array([[70.0, 0, 40.0], [0, 70.0, 30.0], [0, 0, 1.0]])
+    cam = np.eye(4)
+    cam[:3, :3] = np.array([[0, -1.0, 0], [-1.0, 0, 0], [0, 0, -1.0]])  # optical axis straight down
+    cam[:3, 3] = [0.5, 0.0, 1.2]
+    depth = np.full((H, W), 1.2, dtype=np.float32)
+    depth[20:40, 30:50] = 0.9  # a box 30 cm high
+    dpc = g.DepthPointCloud(depth, K, cam)
+    qc = np.array(cfg["default_pose"])
+    plan = np.tile(qc[:, None], (1, 50))
+    # swing joint 2 so that the arm dips into the table in the second half
+    plan[1] = np.linspace(qc[1], 1.6, 50)
+    hit, first, count = plan_in_collision(robot, dpc, plan, [0, 0, 0])
+    ref_count = []
+    for i in range(50):
+        pts, _ = robot.compute_fk_surface_points(plan[:, i])
+        ref_count.append(int(np.sum(dpc.get_sdf(pts) < 0)))
+    np.testing.assert_array_equal(count, ref_count)
+    assert hit and first == int(np.nonzero(np.array(ref_count) > 5)[0][0]) and count[0] <= 5
+    robot.close()
