@@ -91,11 +91,14 @@ def main():
     # D pipeline lanes: each one solver handle bound to ONE stream of its own, with its own copy of the
     # batch in HBM and its own outputs (grasptrajopt_amd.parallel.BatchPipeline runs them concurrently)
     class Lane:
-        def __init__(self):
+        def __init__(self, first=None):
             self.stream = torch.cuda.Stream(dev)
             self.h = _capi.SolverHandle(desc, cfg["link_ee"], cfg["link_gripper"], opts, device=local_rank, n_gripper_points=100)
             self.h.set_stream(self.stream.cuda_stream)
-            self.h.set_scene(0, sc.c_all, sc.c_obs, sc.shape, sc.origin, sc.res)
+            if first is None:
+                self.h.set_scene(0, sc.c_all, sc.c_obs, sc.shape, sc.origin, sc.res)
+            else:
+                self.h.share_scene(0, first.h)  # one copy of the scene in HBM for all lanes
 
         def upload(self, qc, RT, S, base, Q0):
             t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(dt).to(dev)
@@ -111,7 +114,8 @@ def main():
         def step(self):
             self.h.solve_batch_device(B, 1, *self.ptrs, self.stream.cuda_stream)
 
-    lanes = [Lane() for _ in range(D)]
+    lanes = [Lane()]
+    lanes += [Lane(lanes[0]) for _ in range(D - 1)]
     h = lanes[0].h
     # goal grasps: collision-free configurations w.r.t. the obstacle field (target object removed);
     # links that no optimised joint moves (the base) are ignored
@@ -282,7 +286,7 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
         print(json.dumps(out))
-    for ln in lanes:
+    for ln in reversed(lanes):  # the owner of the shared scene goes last
         ln.h.close()
     if world > 1:
         dist.destroy_process_group()

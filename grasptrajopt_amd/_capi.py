@@ -135,6 +135,7 @@ def load_library(path: Optional[str] = None):
     lib.gto_last_kernel_time.argtypes = [H, _pd, _pi]
     lib.gto_set_profiling.argtypes = [H, C.c_int32]
     lib.gto_set_stream.argtypes = [H, C.c_void_p]
+    lib.gto_share_scene.argtypes = [H, C.c_int32, H, C.c_int32]
     lib.gto_eval_fk.argtypes = [H, C.c_int32, _pd, _pd]
     lib.gto_eval_points.argtypes = [H, C.c_int32, C.c_int32, _pd, _pd, C.c_int32, _pd, _pi, _pd, _pd]
     lib.gto_eval_objective.argtypes = [H, C.c_int32, C.c_int32, _pi, _pd, _pi, _pd, _pd, _pd, _pd, _pd, _pd, _pi]
@@ -145,7 +146,7 @@ def load_library(path: Optional[str] = None):
     lib.gto_depth_sdf_cost.argtypes = [C.c_int, _pf, C.c_int32, C.c_int32, _pd, _pd, _pd, _pd, _pu8, C.c_double, _pd, C.c_int64,
                                        C.c_float, C.c_float, _pf, _pu8, _pf, _pd, _pu8]
     for fn in ("gto_create", "gto_set_opts", "gto_set_scene", "gto_drop_scene", "gto_solve_batch",
-               "gto_solve_batch_device", "gto_last_kernel_time", "gto_set_profiling", "gto_set_stream", "gto_eval_fk",
+               "gto_solve_batch_device", "gto_last_kernel_time", "gto_set_profiling", "gto_set_stream", "gto_share_scene", "gto_eval_fk",
                "gto_eval_points", "gto_eval_objective", "gto_eval_obstacle_normal_eq", "gto_plan_cost", "gto_solve_ik_batch",
                "gto_depth_sdf_cost"):
         getattr(lib, fn).restype = C.c_int
@@ -157,7 +158,7 @@ def load_library(path: Optional[str] = None):
 EXPORTED_SYMBOLS = (
     "gto_default_opts", "gto_version", "gto_create", "gto_destroy", "gto_last_error", "gto_set_opts",
     "gto_set_scene", "gto_drop_scene", "gto_solve_batch", "gto_solve_batch_device",
-    "gto_last_kernel_time", "gto_set_profiling", "gto_set_stream", "gto_eval_fk", "gto_eval_points",
+    "gto_last_kernel_time", "gto_set_profiling", "gto_set_stream", "gto_share_scene", "gto_eval_fk", "gto_eval_points",
     "gto_eval_objective", "gto_eval_obstacle_normal_eq", "gto_plan_cost", "gto_solve_ik_batch", "gto_depth_sdf_cost",
 )
 
@@ -268,6 +269,11 @@ class SolverHandle:
                                              vp(standoff), vp(base_pos), vp(Q0), vp(Q_out), vp(dQ_out),
                                              vp(cost_out), vp(iters_out), vp(status_out), vp(stream))
         self._check(rc, "gto_solve_batch_device")
+
+    def share_scene(self, scene_id, src: "SolverHandle", src_scene_id=None):
+        """Use a scene that lives in another handle on the same GPU without a second copy."""
+        self._check(self.lib.gto_share_scene(self._h, int(scene_id), src._h, int(scene_id if src_scene_id is None else src_scene_id)),
+                    "gto_share_scene")
 
     def set_stream(self, stream):
         """Bind every launch/copy of this handle to the caller's HIP stream (an int such as

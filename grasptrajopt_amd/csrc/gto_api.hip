@@ -407,7 +407,7 @@ void gto_destroy(gto_handle* h) {
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (auto& s : h->scenes) {
-    if (s.valid) {
+    if (s.valid == 1) {
       if (s.c_obs != s.c_all) (void)hipFree((void*)s.c_obs);
       (void)hipFree((void*)s.c_all);
       if (s.r_obs != s.r_all) (void)hipFree((void*)s.r_obs);
@@ -463,6 +463,40 @@ static int sync_scene_table(gto_handle* h) {
   return GTO_OK;
 }
 
+// valid: 0 empty, 1 owned by this handle, 2 borrowed from another handle (gto_share_scene)
+static int free_scene(gto_handle* h, SceneDev& s) {
+  if (s.valid == 1) {
+    if (s.c_obs != s.c_all) HIPCHK(h, hipFree((void*)s.c_obs));
+    HIPCHK(h, hipFree((void*)s.c_all));
+    if (s.r_obs != s.r_all) HIPCHK(h, hipFree((void*)s.r_obs));
+    HIPCHK(h, hipFree((void*)s.r_all));
+    if (s.d_obs != s.d_all) HIPCHK(h, hipFree((void*)s.d_obs));
+    HIPCHK(h, hipFree((void*)s.d_all));
+  }
+  s.valid = 0;
+  return GTO_OK;
+}
+
+int gto_share_scene(gto_handle* dst, int32_t dst_id, gto_handle* src, int32_t src_id) {
+  if (!dst || !src) return GTO_ERR_INVALID_ARG;
+  if (dst_id < 0 || dst_id >= 65536) return fail(dst, GTO_ERR_INVALID_ARG, "scene_id out of range [0,65536)");
+  if (src_id < 0 || (size_t)src_id >= src->scenes.size() || !src->scenes[src_id].valid)
+    return fail(dst, GTO_ERR_NO_SCENE, "gto_share_scene: the source scene was never set");
+  if (dst->device != src->device) return fail(dst, GTO_ERR_INVALID_ARG, "gto_share_scene: handles live on different devices");
+  HIPCHK(dst, hipSetDevice(dst->device));
+  HIPCHK(dst, hipStreamSynchronize(dst->stream));
+  if ((size_t)dst_id >= dst->scenes.size()) {
+    SceneDev z;
+    memset(&z, 0, sizeof z);
+    dst->scenes.resize(dst_id + 1, z);
+  }
+  int rcf = free_scene(dst, dst->scenes[dst_id]);
+  if (rcf) return rcf;
+  dst->scenes[dst_id] = src->scenes[src_id];
+  dst->scenes[dst_id].valid = 2;
+  return sync_scene_table(dst);
+}
+
 int gto_set_scene(gto_handle* h, int32_t id, const float* c_all, const float* c_obs, const int32_t shape[3],
                   const double origin[3], double res) {
   if (!h) return GTO_ERR_INVALID_ARG;
@@ -479,15 +513,8 @@ int gto_set_scene(gto_handle* h, int32_t id, const float* c_all, const float* c_
     h->scenes.resize(id + 1, z);
   }
   SceneDev& s = h->scenes[id];
-  if (s.valid) {
-    if (s.c_obs != s.c_all) HIPCHK(h, hipFree((void*)s.c_obs));
-    HIPCHK(h, hipFree((void*)s.c_all));
-    if (s.r_obs != s.r_all) HIPCHK(h, hipFree((void*)s.r_obs));
-    HIPCHK(h, hipFree((void*)s.r_all));
-    if (s.d_obs != s.d_all) HIPCHK(h, hipFree((void*)s.d_obs));
-    HIPCHK(h, hipFree((void*)s.d_all));
-    s.valid = 0;
-  }
+  int rcf = free_scene(h, s);
+  if (rcf) return rcf;
   float *da = nullptr, *dob = nullptr;
   HIPCHK(h, hipMalloc((void**)&da, nvox * sizeof(float)));
   HIPCHK(h, hipMemcpy(da, c_all, nvox * sizeof(float), hipMemcpyHostToDevice));
@@ -558,12 +585,8 @@ int gto_drop_scene(gto_handle* h, int32_t id) {
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   SceneDev& s = h->scenes[id];
-  if (s.c_obs != s.c_all) HIPCHK(h, hipFree((void*)s.c_obs));
-  HIPCHK(h, hipFree((void*)s.c_all));
-  if (s.r_obs != s.r_all) HIPCHK(h, hipFree((void*)s.r_obs));
-  HIPCHK(h, hipFree((void*)s.r_all));
-  if (s.d_obs != s.d_all) HIPCHK(h, hipFree((void*)s.d_obs));
-  HIPCHK(h, hipFree((void*)s.d_all));
+  int rcf = free_scene(h, s);
+  if (rcf) return rcf;
   memset(&s, 0, sizeof s);
   return sync_scene_table(h);
 }

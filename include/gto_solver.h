@@ -168,6 +168,14 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
                            int32_t* status_out, void* stream);
 
 /*
+ * Let `dst` use scene `src_id` of `src` under the id `dst_id` without a second copy in HBM (fields, voxel
+ * records, distance fields: 148 MB for a 128^3 scene).  For handles that work on the same scene side by side
+ * (grasptrajopt_amd.parallel.BatchPipeline).  `src` keeps ownership: it must outlive `dst`'s use of the
+ * scene, and replacing or dropping the scene in `src` invalidates the borrowed entry.
+ */
+int gto_share_scene(gto_handle* dst, int32_t dst_id, gto_handle* src, int32_t src_id);
+
+/*
  * Inverse kinematics for B goal poses of link_ee: the pre-step that produces the
  * q_solutions of plan_goalset.  T = 1 problem of gto/ik_solver.py:30-110:
  *   min_q sum_k ||T_g(q) p_k - RT G p_k||^2 + w_obstacle * sum_pts c_obs[off(x(q))],  lo <= q <= hi,

@@ -278,8 +278,9 @@ def test_pipelined_batches_equal_serial_solves(capi, oracle_mod):
         hs.append(h)
     for i, p in enumerate(probs):
         p.finish(hs[0].eval_fk)
-        for h in hs:
-            h.set_scene(i, p.scene.c_all, p.scene.c_obs, p.scene.shape, p.scene.origin, p.scene.res)
+        hs[0].set_scene(i, p.scene.c_all, p.scene.c_obs, p.scene.shape, p.scene.origin, p.scene.res)
+        hs[1].share_scene(i, hs[0])  # borrowed: no second copy in HBM
+        hs[2].set_scene(i, p.scene.c_all, p.scene.c_obs, p.scene.shape, p.scene.origin, p.scene.res)
     batches = [(np.full(p.B, i, np.int32), p.qc, p.goals, 1, p.S, p.base, p.Q0) for i, p in enumerate(probs)]
     serial = [hs[0].solve_batch(*b) for b in batches]
     with BatchPipeline(hs) as pipe:
@@ -293,7 +294,12 @@ def test_pipelined_batches_equal_serial_solves(capi, oracle_mod):
     hs[1].set_stream(None)
     again = hs[1].solve_batch(*batches[0])
     np.testing.assert_array_equal(again[0], serial[0][0])
-    for h in hs:
+    # a borrowed scene can be dropped without touching the owner's copy; sharing an unknown scene fails
+    hs[1].drop_scene(0)
+    np.testing.assert_array_equal(hs[0].solve_batch(*batches[0])[0], serial[0][0])
+    with pytest.raises(capi.GTOError, match="scene"):
+        hs[1].share_scene(0, hs[0], 77)
+    for h in (hs[1], hs[2], hs[0]):  # the owner of the shared scenes goes last
         h.close()
 
 
