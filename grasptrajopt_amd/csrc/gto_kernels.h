@@ -60,17 +60,6 @@ struct BatchPtrs {
 };
 
 // ------------------------------------------------------------------------------------------------
-__device__ inline double wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
-__device__ inline double wave_max(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
-  return v;
-}
-
 // floor((x - o) / res) clipped to [0, n-1], bit-identical to the reference's index
 // (gto/gto_models.py:174-187): the true quotient is only formed when the fast product lands within
 // 1e-9 of a voxel face (the two can differ by an ulp there and nowhere else).
@@ -132,6 +121,40 @@ __device__ inline double row_sum16(double v) {
 // afterwards row 0 holds sum(a), row 1 sum(c), row 2 sum(b), row 3 sum(d) in all of its lanes.
 __device__ inline double wave_sum4(double a, double b, double c, double d) {
   return row_sum16(swap16_add(swap32_add(a, b), swap32_add(c, d)));
+}
+
+// Sum / maximum over the 64 lanes of a wave, result in every lane: two lane-swap steps (halves, then
+// odd/even rows) and four DPP steps inside the 16-lane rows; 18 instructions, no LDS crossbar
+// (the __shfl_xor butterfly costs 40+ and goes through ds_bpermute).
+__device__ inline double wave_sum(double v) {
+  const double h = swap32_add(v, v);
+  return row_sum16(swap16_add(h, h));
+}
+template <int CTRL>
+__device__ inline double dpp_max(double v) {
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  const int lo2 = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
+  const int hi2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+  return fmax(v, __hiloint2double(hi2, lo2));
+}
+__device__ inline double wave_max(double v) {
+  {
+    const unsigned lo = __double2loint(v), hi = __double2hiint(v);
+    const gto_uint2 l = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const gto_uint2 h = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    v = fmax(__hiloint2double(h.x, l.x), __hiloint2double(h.y, l.y));
+  }
+  {
+    const unsigned lo = __double2loint(v), hi = __double2hiint(v);
+    const gto_uint2 l = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const gto_uint2 h = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    v = fmax(__hiloint2double(h.x, l.x), __hiloint2double(h.y, l.y));
+  }
+  v = dpp_max<0xB1>(v);
+  v = dpp_max<0x4E>(v);
+  v = dpp_max<0x141>(v);
+  v = dpp_max<0x140>(v);
+  return v;
 }
 
 __device__ inline void wave_sync_lds() {
@@ -886,11 +909,13 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
       atomicOr(&s_touched[fk_], 1u << fl_);                                                  \
     }                                                                                        \
     gacc = 0.0;                                                                              \
-    {                                                                                        \
-      const double sw_ = wave_sum(ss);                                                       \
-      if (lane == 0) s_ssw[wave][fk_] += sw_;                                                \
-      ss = 0.0;                                                                              \
-    }                                                                                        \
+  } while (0)
+  // the sum of c^2 belongs to the waypoint, not to the link: it is only reduced when the waypoint changes
+#define GTO_FLUSH_SS(kq_)                                                                    \
+  do {                                                                                       \
+    const double sw_ = wave_sum(ss);                                                         \
+    if (lane == 0) s_ssw[wave][kq_] += sw_;                                                  \
+    ss = 0.0;                                                                                \
   } while (0)
 
   // software prefetch: the next chunk's point coordinates are requested before the current chunk is
@@ -923,7 +948,10 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
       }
     }
     if (ch.key != cur_key) {
-      if (cur_key >= 0) GTO_FLUSH(cur_key);
+      if (cur_key >= 0) {
+        GTO_FLUSH(cur_key);
+        if ((cur_key >> 16) != (ch.key >> 16)) GTO_FLUSH_SS(cur_key >> 16);
+      }
       cur_key = ch.key;
     }
     {
@@ -978,7 +1006,11 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
     x1 = n1;
     x2 = n2;
   }
-  if (cur_key >= 0) GTO_FLUSH(cur_key);
+  if (cur_key >= 0) {
+    GTO_FLUSH(cur_key);
+    GTO_FLUSH_SS(cur_key >> 16);
+  }
+#undef GTO_FLUSH_SS
 #undef GTO_FLUSH
 #undef GTO_DRAIN
   if (dbg_wg && tid == 0) bp.dbg[13] = clock64();
