@@ -1402,9 +1402,9 @@ __device__ __forceinline__ int gj_invert8(double& S, int lane, int r, int c) {
 // y[r] = sum_c Z[r][c] z[c] for lane (r,c); every lane of row r ends up with y[r]
 __device__ __forceinline__ double matvec8(double Z, double zc) {
   double pr = Z * zc;
-  pr += __shfl_xor(pr, 1, 64);
-  pr += __shfl_xor(pr, 2, 64);
-  pr += __shfl_xor(pr, 4, 64);
+  pr = dpp_add<0xB1>(pr);   // quad_perm [1,0,3,2]: lane ^ 1
+  pr = dpp_add<0x4E>(pr);   // quad_perm [2,3,0,1]: lane ^ 2
+  pr = dpp_add<0x141>(pr);  // row_half_mirror: the other quad of the 8-lane row
   return pr;
 }
 
