@@ -157,6 +157,23 @@ __device__ inline double wave_max(double v) {
   return v;
 }
 
+template <int CTRL>
+__device__ inline int dpp_min_i32(int v) {
+  return min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, CTRL, 0xf, 0xf, false));
+}
+// minimum over the 64 lanes of a wave, result in every lane
+__device__ inline int wave_min_i32(int v) {
+  const gto_uint2 a = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
+  v = min((int)a.x, (int)a.y);
+  const gto_uint2 b = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
+  v = min((int)b.x, (int)b.y);
+  v = dpp_min_i32<0xB1>(v);
+  v = dpp_min_i32<0x4E>(v);
+  v = dpp_min_i32<0x141>(v);
+  v = dpp_min_i32<0x140>(v);
+  return v;
+}
+
 __device__ inline void wave_sync_lds() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -841,9 +858,7 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
   const int NA = s_nactive;
   if (TG == 1 && !fixed_mode) {
     // remember how much room this waypoint had (only if the whole waypoint was culled)
-    int ms = my_slack;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) ms = min(ms, __shfl_xor(ms, o, 64));
+    const int ms = wave_min_i32(my_slack);
     if (lane == 0) s_wcount[wave] = ms;
     __syncthreads();
     if (tid < n) bp.qref[((size_t)b * T + t0w) * GTO_MAX_OPT + tid] = dq_try;
