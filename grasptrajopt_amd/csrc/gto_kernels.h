@@ -933,65 +933,97 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
     ss = 0.0;                                                                                \
   } while (0)
 
-  // software prefetch: the next chunk's point coordinates are requested before the current chunk is
-  // processed, so two memory round trips (points, voxel records) overlap
+  // Two-stage software pipeline over the wave's chunks.  Stage A of chunk c+1 (transform, voxel index,
+  // ISSUE of the 32-B record gather) runs before stage B of chunk c (consume the record, append wrenches),
+  // and the point coordinates of chunk c+2 are requested before that: three memory round trips (points,
+  // records, points) are in flight at once instead of one after the other.
   struct ChunkLite {
     int key, start, count;
   };
-  ChunkLite ch = {0, 0, 0};
-  double x0 = 0.0, x1 = 0.0, x2 = 0.0;
-  if (c0 < c1) {
-    const int4 d4 = s_active[c0];
+  struct Staged {  // what stage B needs of a chunk
+    int key, count;
+    double y0, y1, y2;
+    double4 rec;   // voxel record (gradient mode)
+    float fval;    // field value (value-only mode)
+  };
+  auto load_chunk = [&](int c, ChunkLite& ch, double& x0, double& x1, double& x2) {
+    const int4 d4 = s_active[c];
     ch = {d4.x, d4.y, d4.z};
+    x0 = x1 = x2 = 0.0;
     if (lane < ch.count) {
       x0 = px[ch.start + lane];
       x1 = py[ch.start + lane];
       x2 = pz[ch.start + lane];
     }
+  };
+  auto stage_a = [&](const ChunkLite& ch, double x0, double x1, double x2, Staged& st_) {
+    const int kq = ch.key >> 16, link = ch.key & 0xffff;
+    const bool pre = use_all(kq);  // gto/gto_planner.py:117-131: c_all before the standoff waypoint
+    const double* V = s_vis + (kq * L + link) * 12;
+    // point in the robot-base frame (gto/gto_planner.py:114-116); the field frame adds base_position;
+    // lanes past the end of the chunk carry x = 0 and have their cost and gradient zeroed in stage B
+    const double y0 = V[0] * x0 + V[1] * x1 + V[2] * x2 + V[3];
+    const double y1 = V[4] * x0 + V[5] * x1 + V[6] * x2 + V[7];
+    const double y2 = V[8] * x0 + V[9] * x1 + V[10] * x2 + V[11];
+    // voxel index (voxel_axis_fast for the three axes with ONE shared exact-fallback branch: if any axis
+    // lands within 1e-9 of a voxel face, all three are redone in the reference's own order)
+    const double u0 = fma(y0, sc.rinv, cx), u1 = fma(y1, sc.rinv, cy), u2 = fma(y2, sc.rinv, cz);
+    double k0 = floor(u0), k1 = floor(u1), k2 = floor(u2);
+    const double edge = fmax(fmax(fabs((u0 - k0) - 0.5), fabs((u1 - k1) - 0.5)), fabs((u2 - k2) - 0.5));
+    if (edge > 0.5 - 1e-9) {
+      k0 = floor(((y0 + bx) - sc.ox) / sc.res);
+      k1 = floor(((y1 + by) - sc.oy) / sc.res);
+      k2 = floor(((y2 + bz) - sc.oz) / sc.res);
+    }
+    const int ix = min(max((int)k0, 0), sc.nx - 1);  // v_cvt_i32_f64 saturates, NaN -> 0
+    const int iy = min(max((int)k1, 0), sc.ny - 1);
+    const int iz = min(max((int)k2, 0), sc.nz - 1);
+    const int off = iz + nz * (iy + sc.ny * ix);
+    st_.key = ch.key;
+    st_.count = ch.count;
+    st_.y0 = y0, st_.y1 = y1, st_.y2 = y2;
+    st_.fval = 0.f;
+    st_.rec = make_double4(0.0, 0.0, 0.0, 0.0);
+    if (!need_grad) {
+      st_.fval = (pre ? sc.c_all : sc.c_obs)[off];
+    } else {
+      // one 32-B voxel record: cost + central differences (gto/sdf_callback.py:90-114); the divisor
+      // stays 2*res also at clipped borders.  Two 16-B loads, one cache line.
+      st_.rec = *reinterpret_cast<const double4*>(&(pre ? sc.r_all : sc.r_obs)[off]);
+    }
+  };
+  ChunkLite nch = {0, 0, 0};
+  double n0 = 0.0, n1 = 0.0, n2 = 0.0;
+  Staged cur = {};
+  if (c0 < c1) {
+    ChunkLite ch;
+    double x0, x1, x2;
+    load_chunk(c0, ch, x0, x1, x2);
+    if (c0 + 1 < c1) load_chunk(c0 + 1, nch, n0, n1, n2);
+    stage_a(ch, x0, x1, x2, cur);
   }
 #pragma unroll 1
   for (int c = c0; c < c1; ++c) {
-    ChunkLite nch = {0, 0, 0};
-    double n0 = 0.0, n1 = 0.0, n2 = 0.0;
+    Staged nxt = {};
     if (c + 1 < c1) {
-      const int4 d4 = s_active[c + 1];
-      nch = {d4.x, d4.y, d4.z};
-      if (lane < nch.count) {
-        n0 = px[nch.start + lane];
-        n1 = py[nch.start + lane];
-        n2 = pz[nch.start + lane];
-      }
+      stage_a(nch, n0, n1, n2, nxt);  // gather of chunk c+1 goes out now
+      if (c + 2 < c1) load_chunk(c + 2, nch, n0, n1, n2);
     }
-    if (ch.key != cur_key) {
+    if (cur.key != cur_key) {
       if (cur_key >= 0) {
         GTO_FLUSH(cur_key);
-        if ((cur_key >> 16) != (ch.key >> 16)) GTO_FLUSH_SS(cur_key >> 16);
+        if ((cur_key >> 16) != (cur.key >> 16)) GTO_FLUSH_SS(cur_key >> 16);
       }
-      cur_key = ch.key;
+      cur_key = cur.key;
     }
     {
-      // lanes past the end of the chunk carry x = 0 and have their cost and gradient zeroed
-      const bool valid = lane < ch.count;
-      const int kq = ch.key >> 16, link = ch.key & 0xffff;
-      const bool pre = use_all(kq);  // gto/gto_planner.py:117-131: c_all before the standoff waypoint
-      const double* V = s_vis + (kq * L + link) * 12;
-      // point in the robot-base frame (gto/gto_planner.py:114-116); the field frame adds base_position
-      const double y0 = V[0] * x0 + V[1] * x1 + V[2] * x2 + V[3];
-      const double y1 = V[4] * x0 + V[5] * x1 + V[6] * x2 + V[7];
-      const double y2 = V[8] * x0 + V[9] * x1 + V[10] * x2 + V[11];
-      const int ix = voxel_axis_fast(y0, cx, bx, sc.ox, sc.res, sc.rinv, sc.nx);
-      const int iy = voxel_axis_fast(y1, cy, by, sc.oy, sc.res, sc.rinv, sc.ny);
-      const int iz = voxel_axis_fast(y2, cz, bz, sc.oz, sc.res, sc.rinv, sc.nz);
-      const int off = iz + nz * (iy + sc.ny * ix);
+      const bool valid = lane < cur.count;
       if (!need_grad) {
-        const float* __restrict__ field = pre ? sc.c_all : sc.c_obs;
-        const double cval = valid ? (double)field[off] : 0.0;
+        const double cval = valid ? (double)cur.fval : 0.0;
         ss = fma(cval, cval, ss);
       } else {
-        // one 32-B voxel record: cost + central differences (gto/sdf_callback.py:90-114); the divisor
-        // stays 2*res also at clipped borders
-        const VoxelRec* __restrict__ rec = pre ? sc.r_all : sc.r_obs;
-        const double4 lo4 = *reinterpret_cast<const double4*>(&rec[off]);  // two 16-B loads, one line
+        const double4 lo4 = cur.rec;
+        const double y0 = cur.y0, y1 = cur.y1, y2 = cur.y2;
         const double cval = valid ? (double)__builtin_bit_cast(float, (unsigned)__double2loint(lo4.w)) : 0.0;
         ss = fma(cval, cval, ss);
         const double w0 = lo4.x * sc.inv2r;
@@ -1001,25 +1033,20 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
         const unsigned long long am = __ballot(act);
         if (am) {  // wave-uniform
           if (act) {
-            // wrench of the gradient about the base-frame origin: (y x w, w), then the cost value
-            double* e = lst + (cnt + __popcll(am & ((1ull << lane) - 1ull))) * 8;
-            e[0] = y1 * w2 - y2 * w1;
-            e[1] = y2 * w0 - y0 * w2;
-            e[2] = y0 * w1 - y1 * w0;
-            e[3] = w0;
-            e[4] = w1;
-            e[5] = w2;
-            e[6] = cval;
+            // wrench of the gradient about the base-frame origin: (y x w, w), then the cost value;
+            // one 64-B list entry: three 16-B stores and one 8-B store
+            double2* e = reinterpret_cast<double2*>(lst + (cnt + __popcll(am & ((1ull << lane) - 1ull))) * 8);
+            e[0] = make_double2(y1 * w2 - y2 * w1, y2 * w0 - y0 * w2);
+            e[1] = make_double2(y0 * w1 - y1 * w0, w0);
+            e[2] = make_double2(w1, w2);
+            reinterpret_cast<double*>(e)[6] = cval;
           }
           cnt += __popcll(am);
           if (cnt > GTO_LIST_CAP - 64) GTO_DRAIN();
         }
       }
     }
-    ch = nch;
-    x0 = n0;
-    x1 = n1;
-    x2 = n2;
+    cur = nxt;
   }
   if (cur_key >= 0) {
     GTO_FLUSH(cur_key);
