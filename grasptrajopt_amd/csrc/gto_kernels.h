@@ -873,42 +873,35 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
   if (sp.dbg_cut == 2) return;
 
   // Sparse Gram accumulation.  Most surface points are in free space (zero gradient): a lane whose
-  // point has a non-zero gradient appends its wrench (y x w, w) and cost c to a small per-wave LDS
-  // list; the list is folded into the per-link 6x6 Gram by the wave with ONE accumulator per lane
-  // (lane k < 28 owns Gram entry k for even list slots, lane 28+k for odd slots), so the hot loop
-  // carries no 28-wide per-lane accumulator, needs no cross-lane reduction and its cost follows the
-  // number of points that actually touch the obstacle band.
+  // point has a non-zero gradient appends x = (y x w, w, c) to a small per-wave LDS list, and the list is
+  // folded into the per-link Gram X^T X (6x6 wrench Gram, c * wrench, c^2: the upper triangle of a 7x7) on
+  // the FP64 matrix core: v_mfma_f64_16x16x4_f64 takes four list entries per instruction, with the same
+  // register as A (A[i][k] = x_k[i], lane l: i = l & 15, k = l >> 4) and as B (B[k][j] = x_k[j]); the
+  // accumulator D[row = (l >> 4) + 4 reg][col = l & 15] stays in registers until the (waypoint, link) key
+  // changes.  The hot loop carries no per-lane accumulators, needs no cross-lane reduction, its cost
+  // follows the number of points that actually touch the obstacle band, and the fold leaves the vector
+  // ALU to the other waves of the CU.
+  typedef double gto_v4f64 __attribute__((ext_vector_type(4)));
   double* lst = s_list + wave * (GTO_LIST_CAP * 8);
   double* gram_w = s_gram + (size_t)wave * ng * L * GTO_GRAM;  // this wave's private Gram copy
-  const int grp = lane < 28 ? 0 : (lane < 56 ? 1 : -1);
-  const int kk = lane - 28 * (grp > 0 ? 1 : 0);  // Gram entry owned by this lane (valid when grp >= 0)
-  int oi = 0, oj = 0;                            // list-entry components multiplied by this lane
-  if (grp >= 0) {
-    if (kk < 21) {
-      int q = 0;
-      for (int i = 0; i < 6; ++i)
-        for (int j = i; j < 6; ++j) {
-          if (q == kk) {
-            oi = i;
-            oj = j;
-          }
-          ++q;
-        }
-    } else {
-      oi = 6;  // cost value c
-      oj = kk - 21;
-    }
-  }
-  double gacc = 0.0;  // this lane's Gram entry of the current (waypoint, link)
-  double ss = 0.0;    // sum of c^2 over this lane's points of the current waypoint
+  const int mcol = lane & 15, mrow = lane >> 4;                // D column; D rows mrow (reg 0) and mrow + 4 (reg 1)
+  // packed Gram index of D entry (row, col), row <= col < 7: 21 wrench-Gram entries, then c * wrench (6), then c^2
+  auto gram_index = [](int row, int col) { return col < 6 ? sym6(row, col) : (row < 6 ? 21 + row : 27); };
+  const int gk0 = (mrow <= mcol && mcol < 7) ? gram_index(mrow, mcol) : -1;
+  const int gk1 = (mrow + 4 <= mcol && mcol < 7) ? gram_index(mrow + 4, mcol) : -1;
+  gto_v4f64 gD = {0.0, 0.0, 0.0, 0.0};
+  double ss = 0.0;  // sum of c^2 over this lane's points of the current waypoint
   int cnt = 0, cur_key = -1;
 
 #define GTO_DRAIN()                                                                          \
   do {                                                                                       \
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                                   \
     __builtin_amdgcn_wave_barrier();                                                         \
-    if (grp >= 0 && kk < 27)                                                                 \
-      for (int e_ = grp; e_ < cnt; e_ += 2) gacc = fma(lst[e_ * 8 + oi], lst[e_ * 8 + oj], gacc); \
+    for (int e_ = 0; e_ < cnt; e_ += 4) {                                                    \
+      const int ei_ = e_ + mrow;                                                             \
+      const double xv_ = (ei_ < cnt && mcol < 7) ? lst[ei_ * 8 + mcol] : 0.0;                \
+      gD = __builtin_amdgcn_mfma_f64_16x16x4f64(xv_, xv_, gD, 0, 0, 0);                      \
+    }                                                                                        \
     __builtin_amdgcn_wave_barrier();                                                         \
     cnt = 0;                                                                                 \
   } while (0)
@@ -917,13 +910,12 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
   do {                                                                                       \
     if (cnt) GTO_DRAIN();                                                                    \
     const int fk_ = (key) >> 16, fl_ = (key)&0xffff;                                         \
-    /* even-slot + odd-slot partial sums meet in the lower lane; one writer per address */   \
-    const double gsum_ = gacc + __shfl(gacc, (lane + 28) & 63, 64);                          \
-    if (grp == 0 && kk < 27 && gsum_ != 0.0) {                                               \
-      gram_w[(fk_ * L + fl_) * GTO_GRAM + kk] += gsum_;                                      \
-      atomicOr(&s_touched[fk_], 1u << fl_);                                                  \
-    }                                                                                        \
-    gacc = 0.0;                                                                              \
+    double* gdst_ = gram_w + (fk_ * L + fl_) * GTO_GRAM;                                     \
+    const bool w0_ = gk0 >= 0 && gD[0] != 0.0, w1_ = gk1 >= 0 && gD[1] != 0.0;              \
+    if (w0_) gdst_[gk0] += gD[0];                                                            \
+    if (w1_) gdst_[gk1] += gD[1];                                                            \
+    if (__ballot(w0_ || w1_) && lane == 0) atomicOr(&s_touched[fk_], 1u << fl_);             \
+    gD = gto_v4f64{0.0, 0.0, 0.0, 0.0};                                                      \
   } while (0)
   // the sum of c^2 belongs to the waypoint, not to the link: it is only reduced when the waypoint changes
 #define GTO_FLUSH_SS(kq_)                                                                    \
