@@ -21,7 +21,7 @@
 #define GTO_MAX_TG 8         // waypoints per workgroup of the obstacle kernel
 #define GTO_MAX_T 96         // waypoints the step kernel's register-resident phases are unrolled for (and its LDS holds)
 #ifndef GTO_LIST_CAP
-#define GTO_LIST_CAP 80      // wrench-list entries (8 doubles) per wave: a full chunk (64) fits after a drain
+#define GTO_LIST_CAP 64      // wrench-list entries (8 doubles) per wave: a full chunk (64) fits after a drain
 #endif
 
 struct InstState {
@@ -645,7 +645,7 @@ struct ObsLds {  // dynamic LDS layout (offsets in doubles), computed identicall
     int o = 0;
     vis = o;    o += TG * L * 12;
     screw = o;  o += TG * GTO_MAX_OPT * 6;
-    gram = o;   o += 4 * TG * L * GTO_GRAM;  // one private copy per wave, summed in wave order (deterministic)
+    gram = o;   o += TG * L * GTO_GRAM;  // every (waypoint, link) is folded by exactly one wave
     out = o;    o += TG * BLK_STRIDE;
     // also, in the prologue: operand table, sin/cos [TG][F][2] and scratch of fk_mfma_tree; in the epilogue
     // s_u; in the goal workgroups their scratch
@@ -662,7 +662,7 @@ __device__ __forceinline__ void trial_goal_terms_wave(const RobotDev* rb, const 
                                              double* s_gaff, double* s_gscr);
 
 #ifndef GTO_OBS_MIN_WAVES
-#define GTO_OBS_MIN_WAVES 3  // waves per SIMD the register allocator must leave room for (LDS allows 3 workgroups per CU at two waypoints each)
+#define GTO_OBS_MIN_WAVES 4  // waves per SIMD the register allocator must leave room for: four workgroups per CU (28 KB of LDS each)
 #endif
 __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const RobotDev* __restrict__ rb, const double* __restrict__ px,
                                                        const double* __restrict__ py, const double* __restrict__ pz,
@@ -778,7 +778,7 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
     s_sc[2 * idx] = a;
     s_sc[2 * idx + 1] = c;
   }
-  for (int i = tid; i < 4 * ng * L * GTO_GRAM; i += 256) s_gram[i] = 0.0;
+  for (int i = tid; i < ng * L * GTO_GRAM; i += 256) s_gram[i] = 0.0;
   if (tid < 4 * GTO_MAX_TG) (&s_ssw[0][0])[tid] = 0.0;
   for (int i = tid; i < ng * BLK_STRIDE; i += 256) s_out[i] = 0.0;
   if (tid < GTO_MAX_TG) s_touched[tid] = 0u;
@@ -867,8 +867,16 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
       bp.margin[(size_t)b * T + t0w] = (NA == 0 && mall >= 2) ? mall - 2 : -1;
     }
   }
-  // contiguous range of surviving chunks per wave
-  const int c0 = (int)(((long)NA * wave) / 4), c1 = (int)(((long)NA * (wave + 1)) / 4);
+  // Contiguous range of surviving chunks per wave, cut at key changes only: a (waypoint, link) key is then
+  // folded by exactly ONE wave, so a single Gram copy needs neither atomics nor per-wave copies, the result
+  // is bit-reproducible, and the 15 KB of LDS saved buy a fourth workgroup per CU.  (A link has a handful
+  // of chunks, so the ranges stay balanced.)
+  auto cut_at_key = [&](int p) {
+    if (p <= 0) return 0;
+    while (p < NA && s_active[p].x == s_active[p - 1].x) ++p;
+    return p < NA ? p : NA;
+  };
+  const int c0 = cut_at_key((int)(((long)NA * wave) / 4)), c1 = wave == 3 ? NA : cut_at_key((int)(((long)NA * (wave + 1)) / 4));
   if (dbg_wg && tid == 0) bp.dbg[12] = clock64();
   if (sp.dbg_cut == 2) return;
 
@@ -883,7 +891,7 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
   // ALU to the other waves of the CU.
   typedef double gto_v4f64 __attribute__((ext_vector_type(4)));
   double* lst = s_list + wave * (GTO_LIST_CAP * 8);
-  double* gram_w = s_gram + (size_t)wave * ng * L * GTO_GRAM;  // this wave's private Gram copy
+  double* gram_w = s_gram;
   const int mcol = lane & 15, mrow = lane >> 4;                // D column; D rows mrow (reg 0) and mrow + 4 (reg 1)
   // packed Gram index of D entry (row, col), row <= col < 7: 21 wrench-Gram entries, then c * wrench (6), then c^2
   auto gram_index = [](int row, int col) { return col < 6 ? sym6(row, col) : (row < 6 ? 21 + row : 27); };
@@ -1052,8 +1060,6 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
   __syncthreads();
   // fold the four per-wave copies in wave order: the result does not depend on which wave ran first
   {
-    const int ne = ng * L * GTO_GRAM;
-    for (int i = tid; i < ne; i += 256) s_gram[i] = ((s_gram[i] + s_gram[ne + i]) + s_gram[2 * ne + i]) + s_gram[3 * ne + i];
     if (tid < ng) s_out[tid * BLK_STRIDE + BLK_SS] = ((s_ssw[0][tid] + s_ssw[1][tid]) + s_ssw[2][tid]) + s_ssw[3][tid];
   }
   __syncthreads();
