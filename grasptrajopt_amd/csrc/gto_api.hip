@@ -56,6 +56,7 @@ struct gto_handle {
   double last_ms = 0.0;
   int last_launches = 0;
   size_t lm_lds = 0;
+  int base_lds_set = 0;
   bool ik_attr_set = false;
 };
 
@@ -936,6 +937,50 @@ int gto_solve_ik_batch(gto_handle* h, int32_t B, const int32_t* scene_id, const 
                      B, (double*)d_q, (double*)d_cost, (int32_t*)d_it, (int32_t*)d_stat);
   HIPCHK(h, hipGetLastError());
   if ((rc = fetch_out(h, 0, q_out, B * ndof * sizeof(double)))) return rc;
+  if ((rc = fetch_out(h, 2, cost_out, B * sizeof(double)))) return rc;
+  if ((rc = fetch_out(h, 3, iters_out, B * sizeof(int32_t)))) return rc;
+  if ((rc = fetch_out(h, 4, status_out, B * sizeof(int32_t)))) return rc;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return GTO_OK;
+}
+
+int gto_solve_base_batch(gto_handle* h, int32_t B, int32_t n_max, const int32_t* n_goals, const double* qc,
+                         const double* goals, double effort_weight, int32_t max_iter, double* y_out, double* q_out,
+                         double* cost_out, int32_t* iters_out, int32_t* status_out) {
+  if (!h) return GTO_ERR_INVALID_ARG;
+  if (B < 0 || max_iter < 0) return fail(h, GTO_ERR_INVALID_ARG, "B and max_iter must be >= 0");
+  if (n_max < 1 || n_max > GTO_MAX_BASE_GOALS) return fail(h, GTO_ERR_UNSUPPORTED, "n_max must be in [1, 32]");
+  if (B == 0) return GTO_OK;
+  if (!n_goals || !qc || !goals || !y_out || !q_out) return fail(h, GTO_ERR_INVALID_ARG, "null input array");
+  for (int b = 0; b < B; ++b)
+    if (n_goals[b] < 1 || n_goals[b] > n_max) return fail(h, GTO_ERR_INVALID_ARG, "n_goals[b] must be in [1, n_max]");
+  HIPCHK(h, hipSetDevice(h->device));
+  const size_t ndof = h->rb.ndof;
+  int rc;
+  const void *d_qc, *d_goals, *d_ng;
+  void *d_q, *d_y, *d_cost, *d_it, *d_stat;
+  if ((rc = stage_in(h, 1, qc, B * ndof * sizeof(double), &d_qc))) return rc;
+  if ((rc = stage_in(h, 2, goals, (size_t)B * n_max * 16 * sizeof(double), &d_goals))) return rc;
+  if ((rc = stage_in(h, 3, n_goals, B * sizeof(int32_t), &d_ng))) return rc;
+  if ((rc = stage_out(h, 0, q_out, (size_t)B * n_max * ndof * sizeof(double), &d_q))) return rc;
+  if ((rc = stage_out(h, 1, y_out, (size_t)B * 3 * sizeof(double), &d_y))) return rc;
+  if ((rc = stage_out(h, 2, cost_out, B * sizeof(double), &d_cost))) return rc;
+  if ((rc = stage_out(h, 3, iters_out, B * sizeof(int32_t), &d_it))) return rc;
+  if ((rc = stage_out(h, 4, status_out, B * sizeof(int32_t), &d_stat))) return rc;
+  SolveParams sp = make_params(h, 1, false);
+  sp.max_iter = max_iter;
+  const size_t lds = (size_t)base_lds_doubles(n_max) * sizeof(double);
+  if (lds > 160 * 1024) return fail(h, GTO_ERR_UNSUPPORTED, "goal set too large for the base kernel's LDS");
+  if ((int)lds > h->base_lds_set) {
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_base_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    h->base_lds_set = (int)lds;
+  }
+  hipLaunchKernelGGL(k_base_solve, dim3(B), dim3(256), lds, h->stream, h->d_rb, (const double*)d_qc, (const double*)d_goals,
+                     (const int32_t*)d_ng, sp, effort_weight, n_max, (double*)d_y, (double*)d_q, (double*)d_cost,
+                     (int32_t*)d_it, (int32_t*)d_stat);
+  HIPCHK(h, hipGetLastError());
+  if ((rc = fetch_out(h, 0, q_out, (size_t)B * n_max * ndof * sizeof(double)))) return rc;
+  if ((rc = fetch_out(h, 1, y_out, (size_t)B * 3 * sizeof(double)))) return rc;
   if ((rc = fetch_out(h, 2, cost_out, B * sizeof(double)))) return rc;
   if ((rc = fetch_out(h, 3, iters_out, B * sizeof(int32_t)))) return rc;
   if ((rc = fetch_out(h, 4, status_out, B * sizeof(int32_t)))) return rc;

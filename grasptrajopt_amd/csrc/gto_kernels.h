@@ -2131,6 +2131,429 @@ __global__ __launch_bounds__(256) void k_ik_solve(const RobotDev* __restrict__ r
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Base placement of a mobile manipulator (gto/base_planner.py:35-134):
+//   min  w |(x,y,theta)|^2 + sum_i sum_k | A(q_i) p_k - B(x,y,theta) RT_i G p_k |^2 ,
+//   lo <= q_i <= hi,  -pi <= theta <= pi,   unknowns: the base pose and one arm configuration per goal.
+// One workgroup per goal set runs the whole projected Levenberg-Marquardt loop (oracle:
+// solve_base_instance).  Residuals r_k = x_k - tau_k with x_k = A(q_i) p_k (moved by the joint screws s_j)
+// and tau_k = B RT_i G p_k (moved by the base pose through the screws sigma = (0;e_x), (0;e_y), (z; -z x t)),
+// so with X_p = [-[p]_x | I] the Gauss-Newton blocks of goal i are
+//   D = S^T (sum X_x^T X_x) S,  C = -S^T (sum X_x^T X_tau) Sigma,  S_b = Sigma^T (sum X_tau^T X_tau) Sigma,
+// all closed forms in the moments of the gripper cloud (goal_gram_moments twice, goal_cross_moments).
+// The normal equations are an arrow: one 8x8 block D_i per goal, coupled only through the 3x3 base
+// block; each wave eliminates its goals' blocks by Gauss-Jordan, thread 0 solves the 3x3 Schur
+// complement, and sums over goals run in goal order (bit-reproducible).
+#define GTO_MAX_BASE_GOALS 32
+#define GTO_BASE_SYS 112  // per goal: D 8x8 | C 8x3 | S 3x3 | g 3+8 | f
+__host__ __device__ inline int base_lds_doubles(int n_max) {
+  return GTO_MAX_DOF + 8 * GTO_MAX_DOF + 8 * GTO_MAX_FRAMES * 12 + 8 * 24 + 8 * GTO_MAX_OPT * 6 + 2 * n_max * GTO_BASE_SYS +
+         3 * (8 + 8 * n_max) + n_max * (24 + 8 + 16) + 32;
+}
+
+// sum_k X_x^T X_tau (6x6, row-major) for x = A p, tau = Y p:
+//   [[ tr(T) I - T , [sum x]_x ], [ -[sum tau]_x , K I ]],  T = sum tau x^T = R_Y M R_A^T + (R_Y mu) t_A^T + t_Y (R_A mu)^T + K t_Y t_A^T
+__device__ __forceinline__ void goal_cross_moments(const RobotDev* rb, const double* A, const double* Y, double* Wc) {
+  const double K = rb->grip_count;
+  double Amu[3], Ymu[3], YM[9], TX[9];
+  for (int r = 0; r < 3; ++r) {
+    Amu[r] = A[4 * r] * rb->grip_mu[0] + A[4 * r + 1] * rb->grip_mu[1] + A[4 * r + 2] * rb->grip_mu[2];
+    Ymu[r] = Y[4 * r] * rb->grip_mu[0] + Y[4 * r + 1] * rb->grip_mu[1] + Y[4 * r + 2] * rb->grip_mu[2];
+    for (int c = 0; c < 3; ++c)
+      YM[3 * r + c] = Y[4 * r] * rb->grip_M[c] + Y[4 * r + 1] * rb->grip_M[3 + c] + Y[4 * r + 2] * rb->grip_M[6 + c];
+  }
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c)
+      TX[3 * r + c] = YM[3 * r] * A[4 * c] + YM[3 * r + 1] * A[4 * c + 1] + YM[3 * r + 2] * A[4 * c + 2] + Ymu[r] * A[4 * c + 3] +
+                      Y[4 * r + 3] * Amu[c] + K * Y[4 * r + 3] * A[4 * c + 3];
+  const double tr = TX[0] + TX[4] + TX[8];
+  const double sx[3] = {Amu[0] + K * A[3], Amu[1] + K * A[7], Amu[2] + K * A[11]};
+  const double st[3] = {Ymu[0] + K * Y[3], Ymu[1] + K * Y[7], Ymu[2] + K * Y[11]};
+  for (int i = 0; i < 36; ++i) Wc[i] = 0.0;
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) Wc[6 * r + c] = ((r == c) ? tr : 0.0) - TX[3 * r + c];
+  Wc[6 * 0 + 4] = -sx[2], Wc[6 * 0 + 5] = sx[1], Wc[6 * 1 + 3] = sx[2], Wc[6 * 1 + 5] = -sx[0], Wc[6 * 2 + 3] = -sx[1], Wc[6 * 2 + 4] = sx[0];
+  Wc[6 * 3 + 1] = st[2], Wc[6 * 3 + 2] = -st[1], Wc[6 * 4 + 0] = -st[2], Wc[6 * 4 + 2] = st[0], Wc[6 * 5 + 0] = st[1], Wc[6 * 5 + 1] = -st[0];
+  Wc[6 * 3 + 3] = Wc[6 * 4 + 4] = Wc[6 * 5 + 5] = K;
+}
+
+// screw of variable a of one goal's block: a < 3 the base pose acting on the target points, a >= 3 joint a - 3
+__device__ __forceinline__ void base_screw(int a, const double* scr, double tx, double ty, double* s) {
+  if (a < 3) {
+    s[0] = s[1] = 0.0, s[2] = a == 2 ? 1.0 : 0.0;
+    s[3] = a == 0 ? 1.0 : (a == 2 ? ty : 0.0);
+    s[4] = a == 1 ? 1.0 : (a == 2 ? -tx : 0.0);
+    s[5] = 0.0;
+  } else {
+#pragma unroll
+    for (int q = 0; q < 6; ++q) s[q] = scr[6 * (a - 3) + q];
+  }
+}
+
+__global__ __launch_bounds__(256) void k_base_solve(const RobotDev* __restrict__ rb, const double* __restrict__ qc,
+                                                    const double* __restrict__ goals, const int32_t* __restrict__ n_goals,
+                                                    SolveParams sp, double w_effort, int n_max, double* __restrict__ y_out,
+                                                    double* __restrict__ q_out, double* __restrict__ cost_out,
+                                                    int32_t* __restrict__ iters_out, int32_t* __restrict__ status_out) {
+  extern __shared__ __attribute__((aligned(16))) double smem_base[];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int F = rb->n_frames, n = rb->n_opt, ndof = rb->ndof, ng = n_goals[b], NV = 8 + 8 * n_max;
+  double* s_qc = smem_base;
+  double* s_q = s_qc + GTO_MAX_DOF;             // [8][GTO_MAX_DOF]
+  double* s_fr = s_q + 8 * GTO_MAX_DOF;         // [8][GTO_MAX_FRAMES*12]
+  double* s_gaff = s_fr + 8 * GTO_MAX_FRAMES * 12;  // [8][24] gripper and ee affines
+  double* s_scr = s_gaff + 8 * 24;              // [8][GTO_MAX_OPT*6] joint screws
+  double* s_sys = s_scr + 8 * GTO_MAX_OPT * 6;  // [2][n_max][GTO_BASE_SYS]
+  double* s_x = s_sys + 2 * n_max * GTO_BASE_SYS;  // [8 + 8 n_max]: base pose in 0..2, goal i's joints at 8 + 8 i
+  double* s_xt = s_x + NV;
+  double* s_st = s_xt + NV;                     // projected step
+  double* s_E = s_st + NV;                      // [n_max][24] D^-1 C
+  double* s_u = s_E + n_max * 24;               // [n_max][8]  D^-1 rhs
+  double* s_part = s_u + n_max * 8;             // [n_max][16] C^T E (9), C^T u (3), quadratic part, max step
+  double* s_red = s_part + n_max * 16;          // [32]
+  const double PI_ = 3.141592653589793;
+  if (tid < ndof) s_qc[tid] = qc[(size_t)b * ndof + tid];
+  for (int i = tid; i < NV; i += 256) {
+    double v = 0.0;
+    if (i >= 8) {
+      const int j = i & 7;
+      if (j < n) v = fmin(fmax(qc[(size_t)b * ndof + rb->opt_index[j]], rb->lower[j]), rb->upper[j]);
+    }
+    s_x[i] = v;
+    s_xt[i] = v;
+    s_st[i] = 0.0;
+  }
+  const int half = lane >> 5, l = lane & 31, slot8 = wave * 2 + half;
+  const int r = lane >> 3, c = lane & 7;
+  const uint32_t ancg = rb->frame_anc[rb->frame_gripper];
+  double f = INFINITY, lambda = sp.lambda0, nu = 2.0, pred = 0.0;
+  int first = 1, k = 0, status = GTO_STATUS_MAX_ITER, slot = 0;
+  __syncthreads();
+  for (;; ++k) {
+    // ---- evaluate the trial point: eight goals per pass, two per wavefront
+    const int ts_ = first ? slot : 1 - slot;
+    const double th = s_xt[2], bxp = s_xt[0], byp = s_xt[1];
+    double sn, cs;
+    sincos(th, &sn, &cs);
+    for (int pass = 0; pass * 8 < ng; ++pass) {
+      const int gi = pass * 8 + slot8;
+      const bool valid = gi < ng;
+      if (l < ndof) s_q[slot8 * GTO_MAX_DOF + l] = s_qc[l];
+      wave_sync();
+      if (l < n && valid) s_q[slot8 * GTO_MAX_DOF + rb->opt_index[l]] = s_xt[8 + 8 * gi + l];
+      wave_sync();
+      fk_pair_wave(rb, s_q + wave * 2 * GTO_MAX_DOF, s_fr + wave * 2 * GTO_MAX_FRAMES * 12, lane);
+      const double* fr = s_fr + slot8 * GTO_MAX_FRAMES * 12;
+      if (l < 12) {
+        s_gaff[24 * slot8 + l] = fr[12 * rb->frame_gripper + l];
+        s_gaff[24 * slot8 + 12 + l] = fr[12 * rb->frame_ee + l];
+      }
+      if (l >= 12 && l < 12 + n) {
+        const int j = l - 12;
+        for (int i = 0; i < F; ++i)
+          if (rb->opt_of_frame[i] == j) screw_of_frame(rb, i, fr + 12 * i, s_scr + slot8 * GTO_MAX_OPT * 6 + 6 * j);
+      }
+      wave_sync();
+      if (valid) {
+        const double* ga = s_gaff + 24 * slot8;
+        const double* scr = s_scr + slot8 * GTO_MAX_OPT * 6;
+        double Y0[12], Y[12];
+        goal_target(ga, goals + ((size_t)b * n_max + gi) * 16, nullptr, Y0);
+        // target pose seen from the current base: B RT G, B = rt2tr(rotz(theta), [x, y, 0])
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+          Y[cc] = cs * Y0[cc] - sn * Y0[4 + cc] + (cc == 3 ? bxp : 0.0);
+          Y[4 + cc] = sn * Y0[cc] + cs * Y0[4 + cc] + (cc == 3 ? byp : 0.0);
+          Y[8 + cc] = Y0[8 + cc];
+        }
+        const double fi = goal_cost_moments(rb, ga, Y);
+        double* sys = s_sys + ((size_t)ts_ * n_max + gi) * GTO_BASE_SYS;
+        // entry e of the block: D (0..63), C (64..87), S_b (88..96), gradient half (97..107)
+        auto entry_vars = [&](int e, int& a, int& bb) {
+          bb = -1;
+          if (e < 64) a = 3 + (e >> 3), bb = 3 + (e & 7);
+          else if (e < 88) a = 3 + (e - 64) / 3, bb = (e - 64) % 3;
+          else if (e < 97) a = (e - 88) / 3, bb = (e - 88) % 3;
+          else a = e - 97;
+        };
+        auto live = [&](int a) { return a < 3 || (a - 3 < n && ((ancg >> (a - 3)) & 1u)); };
+        {  // joint-joint block and joint gradient: moments of the points x
+          double W21[21], v6[6];
+          goal_gram_moments(rb, ga, Y, W21, v6);
+          for (int e = l; e < 108; e += 32) {
+            int a, bb;
+            entry_vars(e, a, bb);
+            if (!(e < 64 || e >= 100)) continue;
+            double v = 0.0;
+            if (live(a) && (bb < 0 || live(bb))) {
+              double sa[6], sb[6];
+              base_screw(a, scr, bxp, byp, sa);
+              if (bb < 0) {
+#pragma unroll
+                for (int q = 0; q < 6; ++q) v += sa[q] * v6[q];
+              } else {
+                base_screw(bb, scr, bxp, byp, sb);
+#pragma unroll
+                for (int p = 0; p < 6; ++p) {
+                  double u = 0.0;
+#pragma unroll
+                  for (int q = 0; q < 6; ++q) u += W21[sym6(p, q)] * sb[q];
+                  v += sa[p] * u;
+                }
+              }
+            }
+            sys[e] = v;
+          }
+        }
+        {  // base-base block and base gradient: moments of the target points tau; v6 = sum X_tau^T (tau - x)
+          double W21[21], v6[6];
+          goal_gram_moments(rb, Y, ga, W21, v6);
+          for (int e = l; e < 108; e += 32) {
+            int a, bb;
+            entry_vars(e, a, bb);
+            if (!(e >= 88 && e < 100)) continue;
+            double v = 0.0, sa[6], sb[6];
+            base_screw(a, scr, bxp, byp, sa);
+            if (bb < 0) {
+#pragma unroll
+              for (int q = 0; q < 6; ++q) v += sa[q] * v6[q];
+            } else {
+              base_screw(bb, scr, bxp, byp, sb);
+#pragma unroll
+              for (int p = 0; p < 6; ++p) {
+                double u = 0.0;
+#pragma unroll
+                for (int q = 0; q < 6; ++q) u += W21[sym6(p, q)] * sb[q];
+                v += sa[p] * u;
+              }
+            }
+            sys[e] = v;
+          }
+        }
+        if (l < 24) {  // coupling block: C[j][a] = -s_j^T (sum X_x^T X_tau) sigma_a
+          double Wc[36];
+          goal_cross_moments(rb, ga, Y, Wc);
+          const int e = 64 + l;
+          int a, bb;
+          entry_vars(e, a, bb);
+          double v = 0.0;
+          if (live(a)) {
+            double sa[6], sb[6];
+            base_screw(a, scr, bxp, byp, sa);
+            base_screw(bb, scr, bxp, byp, sb);
+#pragma unroll
+            for (int p = 0; p < 6; ++p) {
+              double u = 0.0;
+#pragma unroll
+              for (int q = 0; q < 6; ++q) u += Wc[6 * p + q] * sb[q];
+              v -= sa[p] * u;
+            }
+          }
+          sys[e] = v;
+        }
+        if (l == 0) sys[108] = fi;
+      }
+      wave_sync();
+    }
+    __syncthreads();
+    if (tid == 0) {
+      double ft = w_effort * (bxp * bxp + byp * byp + th * th);
+      for (int i = 0; i < ng; ++i) ft += s_sys[((size_t)ts_ * n_max + i) * GTO_BASE_SYS + 108];
+      s_red[0] = ft;
+    }
+    __syncthreads();
+    const double f_try = s_red[0];
+    // ---- accept / reject (block-uniform)
+    int done = 0, take = 0;
+    if (first) {
+      first = 0;
+      take = 1;
+      f = f_try;
+    } else if (f_try < f && pred > 0.0) {
+      const double df = f - f_try, rho = df / pred;
+      f = f_try;
+      slot = 1 - slot;
+      take = 1;
+      const double sg = 2.0 * rho - 1.0;
+      double fac = 1.0 - sg * sg * sg;
+      fac = fmax(fac, 1.0 / 3.0);
+      lambda = fmax(lambda * fac, 1e-12);
+      nu = 2.0;
+      if (df <= sp.tol_rel_f * (1.0 + f)) {
+        status = GTO_STATUS_CONVERGED;
+        done = 1;
+      }
+    } else {
+      lambda *= nu;
+      nu *= 2.0;
+      if (lambda > 1e15) {
+        status = GTO_STATUS_CONVERGED;
+        done = 1;
+      }
+    }
+    if (take)
+      for (int i = tid; i < NV; i += 256) s_x[i] = s_xt[i];
+    if (done) break;
+    if (k >= sp.max_iter) {
+      status = GTO_STATUS_MAX_ITER;
+      break;
+    }
+    __syncthreads();
+    // ---- step at the current iterate.  (1) base gradient half and base active set
+    const double* sysc = s_sys + (size_t)slot * n_max * GTO_BASE_SYS;
+    if (tid < 3) {
+      double g = w_effort * s_x[tid];
+      for (int i = 0; i < ng; ++i) g += sysc[(size_t)i * GTO_BASE_SYS + 97 + tid];
+      const double lo = tid == 2 ? -PI_ : -INFINITY, hi = tid == 2 ? PI_ : INFINITY;
+      s_red[4 + tid] = g;
+      s_red[8 + tid] = ((s_x[tid] <= lo && g > 0.0) || (s_x[tid] >= hi && g < 0.0)) ? 1.0 : 0.0;
+    }
+    if (tid == 3) s_red[1] = 0.0;  // failure flag
+    __syncthreads();
+    const bool acty0 = s_red[8] != 0.0, acty1 = s_red[9] != 0.0, acty2 = s_red[10] != 0.0;
+    // (2) eliminate the goal blocks: E_i = D_i^-1 C_i, u_i = D_i^-1 rhs_i, and their Schur contributions
+    for (int i = wave; i < ng; i += 4) {
+      const double* sys = sysc + (size_t)i * GTO_BASE_SYS;
+      const double* xi = s_x + 8 + 8 * i;
+      const double xr = xi[r], xc = xi[c], br = sys[100 + r], bc = sys[100 + c];
+      const int rr = r < n ? r : 0, cc = c < n ? c : 0;
+      const bool ar = r >= n || (xr <= rb->lower[rr] && br > 0.0) || (xr >= rb->upper[rr] && br < 0.0);
+      const bool ac = c >= n || (xc <= rb->lower[cc] && bc > 0.0) || (xc >= rb->upper[cc] && bc < 0.0);
+      double S = sys[lane];
+      if (ar || ac) S = (r == c) ? 1.0 : 0.0;
+      else if (r == c) S *= (1.0 + lambda);
+      const int bad = gj_invert8(S, lane, r, c);
+      const double C0 = (ac || acty0) ? 0.0 : sys[64 + 3 * c], C1 = (ac || acty1) ? 0.0 : sys[64 + 3 * c + 1],
+                   C2 = (ac || acty2) ? 0.0 : sys[64 + 3 * c + 2];
+      const double e0 = matvec8(S, C0), e1 = matvec8(S, C1), e2 = matvec8(S, C2), u = matvec8(S, ac ? 0.0 : -bc);
+      if (c == 0) {
+        s_E[i * 24 + 3 * r] = e0, s_E[i * 24 + 3 * r + 1] = e1, s_E[i * 24 + 3 * r + 2] = e2;
+        s_u[i * 8 + r] = u;
+      }
+      if (__any(bad) && lane == 0) s_red[1] = 1.0;
+      wave_sync();
+      if (lane < 12) {
+        const int a = lane < 9 ? lane / 3 : lane - 9, a2 = lane < 9 ? lane % 3 : -1;
+        const bool acta = a == 0 ? acty0 : (a == 1 ? acty1 : acty2);
+        double v = 0.0;
+        for (int j = 0; j < n; ++j) {
+          const double xj = xi[j], bj = sys[100 + j];
+          const bool aj = (xj <= rb->lower[j] && bj > 0.0) || (xj >= rb->upper[j] && bj < 0.0);
+          const double cj = (aj || acta) ? 0.0 : sys[64 + 3 * j + a];
+          v += cj * (a2 >= 0 ? s_E[i * 24 + 3 * j + a2] : s_u[i * 8 + j]);
+        }
+        s_part[i * 16 + lane] = v;
+      }
+    }
+    __syncthreads();
+    // (3) 3x3 Schur complement in goal order, Cholesky, base step
+    if (tid == 0) {
+      double M[9], rh[3];
+      const bool act[3] = {acty0, acty1, acty2};
+      for (int a = 0; a < 3; ++a) {
+        for (int a2 = 0; a2 < 3; ++a2) {
+          double v = (a == a2) ? w_effort : 0.0;
+          for (int i = 0; i < ng; ++i) v += sysc[(size_t)i * GTO_BASE_SYS + 88 + 3 * a + a2];
+          if (act[a] || act[a2]) v = (a == a2) ? 1.0 : 0.0;
+          else if (a == a2) v *= (1.0 + lambda);
+          M[3 * a + a2] = v;
+        }
+        rh[a] = act[a] ? 0.0 : -s_red[4 + a];
+      }
+      for (int i = 0; i < ng; ++i) {
+        for (int e = 0; e < 9; ++e) M[e] -= s_part[i * 16 + e];
+        for (int a = 0; a < 3; ++a) rh[a] -= s_part[i * 16 + 9 + a];
+      }
+      // Cholesky M = L L^T
+      int bad = 0;
+      double L00 = M[0], L10, L20, L11, L21, L22;
+      if (!(L00 > 0.0)) bad = 1;
+      L00 = sqrt(L00);
+      L10 = M[3] / L00, L20 = M[6] / L00;
+      L11 = M[4] - L10 * L10;
+      if (!(L11 > 0.0)) bad = 1;
+      L11 = sqrt(L11);
+      L21 = (M[7] - L20 * L10) / L11;
+      L22 = M[8] - L20 * L20 - L21 * L21;
+      if (!(L22 > 0.0)) bad = 1;
+      L22 = sqrt(L22);
+      const double z0 = rh[0] / L00, z1 = (rh[1] - L10 * z0) / L11, z2 = (rh[2] - L20 * z0 - L21 * z1) / L22;
+      const double d2 = z2 / L22, d1 = (z1 - L21 * d2) / L11, d0 = (z0 - L10 * d1 - L20 * d2) / L00;
+      s_red[12] = d0, s_red[13] = d1, s_red[14] = d2;
+      if (bad) s_red[1] = 1.0;
+    }
+    __syncthreads();
+    if (s_red[1] != 0.0) {
+      status = GTO_STATUS_NUMERICAL;
+      break;
+    }
+    // (4) back-substitute, project, and the terms of the predicted reduction
+    const double dy0 = s_red[12], dy1 = s_red[13], dy2 = s_red[14];
+    const double sy0 = dy0, sy1 = dy1, sy2 = fmin(fmax(s_x[2] + dy2, -PI_), PI_) - s_x[2];
+    if (tid == 0) {
+      s_xt[0] = s_x[0] + dy0, s_xt[1] = s_x[1] + dy1, s_xt[2] = fmin(fmax(s_x[2] + dy2, -PI_), PI_);
+    }
+    for (int i = wave; i < ng; i += 4) {
+      const double* sys = sysc + (size_t)i * GTO_BASE_SYS;
+      const double* xi = s_x + 8 + 8 * i;
+      const int rr = r < n ? r : 0;
+      const double dq = s_u[i * 8 + r] - (s_E[i * 24 + 3 * r] * dy0 + s_E[i * 24 + 3 * r + 1] * dy1 + s_E[i * 24 + 3 * r + 2] * dy2);
+      double v = fmin(fmax(xi[r] + dq, rb->lower[rr]), rb->upper[rr]);
+      if (r >= n) v = 0.0;
+      const double sr = v - xi[r];
+      const double sc_ = __shfl(sr, c << 3, 64);
+      if (c == 0) s_xt[8 + 8 * i + r] = v;
+      double part = sys[lane] * sr * sc_;  // s_i^T D_i s_i
+      if (c < 3) {
+        const double syc = c == 0 ? sy0 : (c == 1 ? sy1 : sy2);
+        part += 2.0 * sys[64 + 3 * r + c] * sr * syc;  // 2 s_i^T C_i s_y
+      }
+      if (c == 3) part += 2.0 * sys[100 + r] * sr;  // 2 g_q . s_i
+      if (lane < 9) {
+        const int a = lane / 3, a2 = lane % 3;
+        const double sa = a == 0 ? sy0 : (a == 1 ? sy1 : sy2), sb = a2 == 0 ? sy0 : (a2 == 1 ? sy1 : sy2);
+        part += sys[88 + lane] * sa * sb;  // s_y^T S_i s_y
+      }
+      if (lane >= 9 && lane < 12) part += 2.0 * sys[97 + lane - 9] * (lane == 9 ? sy0 : (lane == 10 ? sy1 : sy2));
+      part = wave_sum(part);
+      double ms = (c == 0 && r < n) ? fabs(sr) : 0.0;
+      ms = wave_max(ms);
+      if (lane == 0) {
+        s_part[i * 16 + 12] = part;
+        s_part[i * 16 + 13] = ms;
+      }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      double q = w_effort * (sy0 * sy0 + sy1 * sy1 + sy2 * sy2) + 2.0 * w_effort * (s_x[0] * sy0 + s_x[1] * sy1 + s_x[2] * sy2);
+      double ms = fmax(fabs(sy0), fmax(fabs(sy1), fabs(sy2)));
+      for (int i = 0; i < ng; ++i) {
+        q += s_part[i * 16 + 12];
+        ms = fmax(ms, s_part[i * 16 + 13]);
+      }
+      s_red[2] = -q;
+      s_red[3] = ms;
+    }
+    __syncthreads();
+    if (s_red[3] < sp.tol_step) {
+      status = GTO_STATUS_CONVERGED;
+      break;
+    }
+    pred = s_red[2];
+  }
+  __syncthreads();
+  if (tid < 3) y_out[(size_t)b * 3 + tid] = s_x[tid];
+  for (int idx = tid; idx < n_max * ndof; idx += 256) {
+    const int i = idx / ndof, dq = idx % ndof, j = rb->opt_of_dof[dq];
+    q_out[((size_t)b * n_max + i) * ndof + dq] = (j >= 0 && i < ng) ? s_x[8 + 8 * i + j] : s_qc[dq];
+  }
+  if (tid == 0) {
+    if (cost_out) cost_out[b] = f;
+    if (iters_out) iters_out[b] = k;
+    if (status_out) status_out[b] = status;
+  }
+}
+
 __global__ __launch_bounds__(64) void k_lm_finalize(const RobotDev* __restrict__ rb, BatchPtrs bp, SolveParams sp, int B,
                                                     double* Q_out, double* dQ_out, double* cost_out,
                                                     int32_t* iters_out, int32_t* status_out) {

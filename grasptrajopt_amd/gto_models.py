@@ -186,6 +186,43 @@ class GTORobotModel:
         off = idx[:, 2] + self.field_shape[2] * (idx[:, 1] + self.field_shape[1] * idx[:, 0])
         return np.clip(off, 0, self.field_size - 1).astype(np.int32)
 
+    # ------------------------------------------------------------------ x-y occupancy grid (mobile base)
+    def setup_occupancy_grid(self, points, epsilon=0.02):
+        """gto/gto_models.py:218-244: grid nodes of the x-y plane that have an observed point (z > 0.01)
+        within `epsilon`.  The reference asks a KD-tree for every node's nearest point; equivalently every
+        point marks the nodes within `epsilon` of it (one scatter pass, no tree)."""
+        points = np.asarray(points, dtype=np.float64)
+        xys = points[points[:, 2] > 0.01, :2]
+        m, r = self.field_margin, self.grid_resolution
+        self.xlim_2d = [0, np.max(xys[:, 0])]
+        self.ylim_2d = [np.min(xys[:, 1]), np.max(xys[:, 1])]
+        self.occupancy_grid_origin = np.array([self.xlim_2d[0] - m, self.ylim_2d[0] - m]).reshape((1, 2))
+        self.xgrid = np.arange(self.xlim_2d[0] - m, self.xlim_2d[1] + m, r)
+        self.ygrid = np.arange(self.ylim_2d[0] - m, self.ylim_2d[1] + m, r)
+        nx, ny = len(self.xgrid), len(self.ygrid)
+        self.occupancy_grid_shape = (nx, ny)
+        self.occupancy_grid_size = nx * ny
+        grid = np.zeros((nx, ny))
+        ix0 = np.rint((xys[:, 0] - self.xgrid[0]) / r).astype(np.int64)
+        iy0 = np.rint((xys[:, 1] - self.ygrid[0]) / r).astype(np.int64)
+        k = int(np.ceil(epsilon / r))
+        for di in range(-k, k + 1):
+            for dj in range(-k, k + 1):
+                ix, iy = ix0 + di, iy0 + dj
+                ok = (ix >= 0) & (ix < nx) & (iy >= 0) & (iy < ny)
+                ix, iy, p = ix[ok], iy[ok], xys[ok]
+                near = np.sqrt((p[:, 0] - self.xgrid[ix]) ** 2 + (p[:, 1] - self.ygrid[iy]) ** 2) < epsilon
+                grid[ix[near], iy[near]] = 1.0
+        self.occupancy_grid = grid.reshape(-1, 1)  # (size, 1), as the reference's KD-tree distances are
+
+    def points_to_offsets_occupancy_numpy(self, points):
+        """gto/gto_models.py:262-273."""
+        xys = np.asarray(points, dtype=np.float64)[:, :2]
+        idx = np.floor((xys - self.occupancy_grid_origin) / self.grid_resolution)
+        for a in range(2):
+            idx[:, a] = np.clip(idx[:, a], 0, self.occupancy_grid_shape[a] - 1).astype(np.int32)
+        return (idx[:, 1] + self.occupancy_grid_shape[1] * idx[:, 0]).astype(np.int32)
+
     def compute_plan_cost(self, plan, sdf_cost_obstacle, base_position, handle=None):
         """gto/gto_models.py:204-215 for one plan (ndof, T) -> (cost, dist), evaluated on the GPU."""
         h = handle or self._util_handle()

@@ -137,3 +137,32 @@ def make_seed(qc: np.ndarray, q_goal: np.ndarray, T: int, param_index) -> np.nda
     data = interpolate_waypoints(np.stack([qc, q_goal]), T, qc.shape[0])
     data[:, param_index] = np.asarray(qc)[param_index]
     return data.T.copy()
+
+
+def base_pose_matrix(y) -> np.ndarray:
+    """rt2tr(rotz(theta), [x, y, 0]) of a planar base pose y = (x, y, theta) (gto/base_planner.py:49-51)."""
+    c, s = np.cos(y[2]), np.sin(y[2])
+    M = np.eye(4)
+    M[:2, :2] = [[c, -s], [s, c]]
+    M[0, 3], M[1, 3] = y[0], y[1]
+    return M
+
+
+def make_base_goal_sets(desc, fk: Callable[[np.ndarray], np.ndarray], link_ee: str, qc, B: int, n: int, seed: int,
+                        spread: float = 0.5, shift: float = 0.4, turn: float = 0.6):
+    """Goal sets for the base-placement problem: every set is reachable from ONE displaced base pose y*
+    (|x|,|y| <= shift, |theta| <= turn): arm configurations within `spread` of qc, goal_i = B(y*)^-1 FK_ee(q_i),
+    i.e. poses of link_ee seen from the current base.  Returns (goals (B,n,4,4), y* (B,3))."""
+    rng = np.random.default_rng(7000 + seed)
+    qc = np.asarray(qc, dtype=np.float64)
+    oi = np.asarray(desc.opt_index)
+    lo, hi = np.asarray(desc.lower)[oi], np.asarray(desc.upper)[oi]
+    fe = desc.frame_index(link_ee)
+    goals, ystar = np.zeros((B, n, 4, 4)), np.zeros((B, 3))
+    for b in range(B):
+        ystar[b] = [rng.uniform(-shift, shift), rng.uniform(-shift, shift), rng.uniform(-turn, turn)]
+        Binv = np.linalg.inv(base_pose_matrix(ystar[b]))
+        q = np.tile(qc, (n, 1))
+        q[:, oi] = np.clip(qc[oi] + rng.uniform(-spread, spread, size=(n, len(oi))), lo, hi)
+        goals[b] = Binv @ np.asarray(fk(q))[:, fe]
+    return goals, ystar

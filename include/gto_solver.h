@@ -196,6 +196,30 @@ int gto_solve_ik_batch(gto_handle* h, int32_t B, const int32_t* scene_id, const 
                        int32_t* status_out);
 
 /*
+ * Base placement of a mobile manipulator for B goal sets: where to park the base so that
+ * every goal of the set is reachable.  Problem of gto/base_planner.py:35-94 with T = goal_size:
+ *   min  effort_weight * |(x,y,theta)|^2 + sum_i sum_k | T_g(q_i) p_k - B(x,y,theta) RT_i G p_k |^2 ,
+ *   lo <= q_i <= hi (:92),  -pi <= theta <= pi (:55),  B = rt2tr(rotz(theta), [x,y,0]) (:49-51),
+ * unknowns: the base pose and ONE arm configuration per goal (:58-60); seeded at the zero pose and at qc
+ * for every goal (:104-105).  Same projected Levenberg-Marquardt as the trajectory problem, the whole
+ * iteration on the GPU, one workgroup per goal set; the arrow-shaped normal equations are eliminated
+ * goal block by goal block onto the 3x3 base block.
+ *   n_max     row stride of goals / q_out, 1 <= n_goals[b] <= n_max <= 32
+ *   n_goals   [B]
+ *   qc        [B][ndof]          current configuration (:96)
+ *   goals     [B][n_max][16]     RT_i of link_ee in the CURRENT base frame, row-major 4x4 (:98-101)
+ *   max_iter  iteration cap (reference IPOPT cap: 100, :95)
+ * Outputs (host): y_out [B][3] = (x, y, theta), the old base in the new base frame (:52);
+ * q_out [B][n_max][ndof] arm configuration per goal (rows >= n_goals[b]: qc); cost_out, iters_out,
+ * status_out as in gto_solve_batch (may be NULL).  err_pos / err_rot (:127-143) follow from gto_eval_fk,
+ * the occupancy statistic (:146-158) from gto_eval_points' transformed points.
+ * Replaces: BasePlanner.setup_optimization + the solve inside plan_goalset (gto/base_planner.py:35-123).
+ */
+int gto_solve_base_batch(gto_handle* h, int32_t B, int32_t n_max, const int32_t* n_goals, const double* qc,
+                         const double* goals, double effort_weight, int32_t max_iter, double* y_out, double* q_out,
+                         double* cost_out, int32_t* iters_out, int32_t* status_out);
+
+/*
  * Bind the handle to the caller's HIP stream (e.g. torch.cuda.current_stream().cuda_stream): every
  * launch and copy of every entry point then goes to that stream and the handle creates none of its
  * own.  NULL gives the handle a private non-blocking stream again (the state after gto_create).

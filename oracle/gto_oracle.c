@@ -1201,6 +1201,216 @@ int orc_solve_ik_batch(const gto_robot_desc* d, const gto_solver_opts* o, const 
   return GTO_OK;
 }
 
+/* ------------------------------------------------------------------ base placement
+ * gto/base_planner.py:35-94.  Unknowns z = [x, y, theta ; q_1 .. q_n] (one arm configuration per goal):
+ *   f = w |(x,y,theta)|^2 + sum_i sum_k | A(q_i) p_k - (B(x,y,theta) RT_i G(q_i)) p_k |^2 ,
+ * B = rt2tr(rotz(theta), [x,y,0]) (:49-51), A = gripper-link transform (:66-68), joint limits on every
+ * q_i (:92) and -pi <= theta <= pi (:55).  The reference also carries n-1 unused copies of the task
+ * state (T = goal_size, only column 0 enters the cost, :44-46); they stay at their zero seed and are
+ * not represented here.  Same projected Levenberg-Marquardt rules as solve_ik_instance; the normal
+ * equations are assembled point by point and solved by one dense Cholesky factorisation. */
+static void base_evaluate(const gto_robot_desc* d, int ng, const double* z, const double* qc, const double* goals,
+                          double w_effort, int want_deriv, double* f_out, double* A, double* b) {
+  const int n = d->n_opt, N = 3 + n * ng;
+  orc_kin* k = (orc_kin*)malloc(sizeof(orc_kin));
+  if (want_deriv) {
+    memset(A, 0, sizeof(double) * (size_t)N * N);
+    memset(b, 0, sizeof(double) * (size_t)N);
+  }
+  const double th = z[2], cs = cos(th), sn = sin(th);
+  const double Bm[12] = {cs, -sn, 0, z[0], sn, cs, 0, z[1], 0, 0, 1, 0};
+  double f = w_effort * (z[0] * z[0] + z[1] * z[1] + z[2] * z[2]);
+  if (want_deriv)
+    for (int a = 0; a < 3; ++a) {
+      A[a * N + a] += w_effort;
+      b[a] += w_effort * z[a];
+    }
+  double q[GTO_MAX_DOF];
+  for (int i = 0; i < ng; ++i) {
+    for (int c = 0; c < d->ndof; ++c) q[c] = qc[c];
+    for (int j = 0; j < n; ++j) q[d->opt_index[j]] = z[3 + i * n + j];
+    kin_compute(d, q, k);
+    const double* Ag = k->frames + 12 * d->frame_gripper;
+    const unsigned ancg = k->anc[d->frame_gripper];
+    double Y0[12];
+    goal_target(k, d, goals + 16 * (size_t)i, NULL, Y0);
+    for (int p = 0; p < d->n_gripper_points; ++p) {
+      double xa[3], g[3], tau[3], r[3];
+      aff_apply(Ag, d->gripper_points + 3 * p, xa);
+      aff_apply(Y0, d->gripper_points + 3 * p, g);
+      aff_apply(Bm, g, tau);
+      for (int c = 0; c < 3; ++c) {
+        r[c] = xa[c] - tau[c];
+        f += r[c] * r[c];
+      }
+      if (!want_deriv) continue;
+      /* residual Jacobian columns: base x, y, theta, then this goal's joints */
+      double J[3][3 + NMAX];
+      J[0][0] = -1.0, J[1][0] = 0.0, J[2][0] = 0.0;
+      J[0][1] = 0.0, J[1][1] = -1.0, J[2][1] = 0.0;
+      J[0][2] = tau[1] - z[1], J[1][2] = -(tau[0] - z[0]), J[2][2] = 0.0;
+      for (int j = 0; j < n; ++j) {
+        double col[3] = {0, 0, 0};
+        if (ancg >> j & 1u) point_jac_col(k, j, xa, col);
+        J[0][3 + j] = col[0], J[1][3 + j] = col[1], J[2][3 + j] = col[2];
+      }
+      for (int a = 0; a < 3 + n; ++a) {
+        const int ia = a < 3 ? a : 3 + i * n + (a - 3);
+        b[ia] += J[0][a] * r[0] + J[1][a] * r[1] + J[2][a] * r[2];
+        for (int c = 0; c < 3 + n; ++c) {
+          const int ic = c < 3 ? c : 3 + i * n + (c - 3);
+          A[ia * N + ic] += J[0][a] * J[0][c] + J[1][a] * J[1][c] + J[2][a] * J[2][c];
+        }
+      }
+    }
+  }
+  *f_out = f;
+  free(k);
+}
+
+static void solve_base_instance(const gto_robot_desc* d, const gto_solver_opts* o, int ng, int n_max, const double* qc,
+                                const double* goals, double w_effort, int max_iter, double* y_out, double* q_out,
+                                double* cost_out, int32_t* iters_out, int32_t* status_out) {
+  const int n = d->n_opt, N = 3 + n * ng;
+  double* x = (double*)malloc(sizeof(double) * N * 8);
+  double *xtry = x + N, *lo = x + 2 * N, *hi = x + 3 * N, *bcur = x + 4 * N, *btry = x + 5 * N, *rhs = x + 6 * N,
+         *dx = x + 7 * N;
+  double* Abuf = (double*)malloc(sizeof(double) * (size_t)N * N * 3);
+  double *Acur = Abuf, *Atry = Abuf + (size_t)N * N, *M = Abuf + 2 * (size_t)N * N;
+  int* act = (int*)malloc(sizeof(int) * N);
+  lo[0] = lo[1] = -INFINITY, hi[0] = hi[1] = INFINITY;
+  lo[2] = -3.141592653589793, hi[2] = 3.141592653589793; /* np.pi, gto/base_planner.py:55 */
+  xtry[0] = xtry[1] = xtry[2] = 0.0; /* gto/base_planner.py:105 */
+  for (int i = 0; i < ng; ++i)
+    for (int j = 0; j < n; ++j) {
+      double v = qc[d->opt_index[j]]; /* every goal starts from the current configuration (:104) */
+      lo[3 + i * n + j] = d->lower[j], hi[3 + i * n + j] = d->upper[j];
+      if (v < d->lower[j]) v = d->lower[j];
+      if (v > d->upper[j]) v = d->upper[j];
+      xtry[3 + i * n + j] = v;
+    }
+  double lambda = o->lambda0, nu = 2.0, f = INFINITY, pred = 0.0;
+  int status = GTO_STATUS_MAX_ITER, first = 1, k = 0;
+  for (;; ++k) {
+    double f_try;
+    base_evaluate(d, ng, xtry, qc, goals, w_effort, 1, &f_try, Atry, btry);
+    int done = 0, take = 0;
+    if (first) {
+      first = 0;
+      take = 1;
+    } else if (f_try < f && pred > 0.0) {
+      double df = f - f_try, rho = df / pred;
+      take = 1;
+      double s = 2.0 * rho - 1.0, fac = 1.0 - s * s * s;
+      if (fac < 1.0 / 3.0) fac = 1.0 / 3.0;
+      lambda *= fac;
+      if (lambda < 1e-12) lambda = 1e-12;
+      nu = 2.0;
+      if (df <= o->tol_rel_f * (1.0 + f_try)) {
+        status = GTO_STATUS_CONVERGED;
+        done = 1;
+      }
+    } else {
+      lambda *= nu;
+      nu *= 2.0;
+      if (lambda > 1e15) {
+        status = GTO_STATUS_CONVERGED;
+        done = 1;
+      }
+    }
+    if (take) {
+      memcpy(x, xtry, sizeof(double) * N);
+      memcpy(bcur, btry, sizeof(double) * N);
+      double* t = Acur;
+      Acur = Atry;
+      Atry = t;
+      f = f_try;
+    }
+    if (done) break;
+    if (k >= max_iter) {
+      status = GTO_STATUS_MAX_ITER;
+      break;
+    }
+    for (int i = 0; i < N; ++i) act[i] = (x[i] <= lo[i] && bcur[i] > 0.0) || (x[i] >= hi[i] && bcur[i] < 0.0);
+    for (int i = 0; i < N; ++i) {
+      for (int j = 0; j < N; ++j) {
+        double v = Acur[(size_t)i * N + j];
+        if (act[i] || act[j]) v = (i == j) ? 1.0 : 0.0;
+        else if (i == j) v *= (1.0 + lambda);
+        M[(size_t)i * N + j] = v;
+      }
+      rhs[i] = act[i] ? 0.0 : -bcur[i];
+    }
+    if (!chol(M, N)) {
+      status = GTO_STATUS_NUMERICAL;
+      break;
+    }
+    for (int i = 0; i < N; ++i) {
+      double s = rhs[i];
+      for (int c = 0; c < i; ++c) s -= M[(size_t)i * N + c] * dx[c];
+      dx[i] = s / M[(size_t)i * N + i];
+    }
+    for (int i = N - 1; i >= 0; --i) {
+      double s = dx[i];
+      for (int c = i + 1; c < N; ++c) s -= M[(size_t)c * N + i] * dx[c];
+      dx[i] = s / M[(size_t)i * N + i];
+    }
+    double maxstep = 0.0;
+    for (int i = 0; i < N; ++i) {
+      double v = x[i] + dx[i];
+      if (v < lo[i]) v = lo[i];
+      if (v > hi[i]) v = hi[i];
+      xtry[i] = v;
+      dx[i] = v - x[i];
+      if (fabs(dx[i]) > maxstep) maxstep = fabs(dx[i]);
+    }
+    if (maxstep < o->tol_step) {
+      status = GTO_STATUS_CONVERGED;
+      break;
+    }
+    double bts = 0.0, sAs = 0.0;
+    for (int i = 0; i < N; ++i) {
+      bts += bcur[i] * dx[i];
+      double r = 0.0;
+      for (int j = 0; j < N; ++j) r += Acur[(size_t)i * N + j] * dx[j];
+      sAs += dx[i] * r;
+    }
+    pred = -(2.0 * bts + sAs);
+  }
+  for (int a = 0; a < 3; ++a) y_out[a] = x[a];
+  for (int i = 0; i < n_max; ++i) { /* parameter joints as given (optas/solver.py:139-157); unused rows = qc */
+    for (int c = 0; c < d->ndof; ++c) q_out[(size_t)i * d->ndof + c] = qc[c];
+    if (i < ng)
+      for (int j = 0; j < n; ++j) q_out[(size_t)i * d->ndof + d->opt_index[j]] = x[3 + i * n + j];
+  }
+  if (cost_out) *cost_out = f;
+  if (iters_out) *iters_out = k;
+  if (status_out) *status_out = status;
+  free(act);
+  free(Abuf);
+  free(x);
+}
+
+/* Same contract as gto_solve_base_batch. */
+int orc_solve_base_batch(const gto_robot_desc* d, const gto_solver_opts* o, int32_t B, int32_t n_max,
+                         const int32_t* n_goals, const double* qc, const double* goals, double w_effort,
+                         int32_t max_iter, double* y_out, double* q_out, double* cost_out, int32_t* iters_out,
+                         int32_t* status_out, int32_t n_threads) {
+  if (d->n_opt > NMAX || d->n_frames > GTO_MAX_FRAMES || d->n_links > GTO_MAX_LINKS || d->ndof > GTO_MAX_DOF)
+    return GTO_ERR_UNSUPPORTED;
+  for (int b = 0; b < B; ++b)
+    if (n_goals[b] < 1 || n_goals[b] > n_max) return GTO_ERR_INVALID_ARG;
+#ifdef _OPENMP
+  if (n_threads > 0) omp_set_num_threads(n_threads);
+#pragma omp parallel for schedule(dynamic, 1)
+#endif
+  for (int b = 0; b < B; ++b)
+    solve_base_instance(d, o, n_goals[b], n_max, qc + (size_t)b * d->ndof, goals + (size_t)b * n_max * 16, w_effort, max_iter,
+                        y_out + 3 * (size_t)b, q_out + (size_t)b * n_max * d->ndof, cost_out ? cost_out + b : NULL,
+                        iters_out ? iters_out + b : NULL, status_out ? status_out + b : NULL);
+  return GTO_OK;
+}
+
 /* Objective terms at given trajectories (same contract as gto_eval_objective). */
 int orc_eval_objective(const gto_robot_desc* d, const gto_solver_opts* o, const orc_scene* scenes,
                        int32_t B, int32_t n_max, const int32_t* scene_id, const double* goals,

@@ -307,6 +307,28 @@ class Oracle:
             raise RuntimeError(f"orc_solve_ik_batch failed ({rc})")
         return q, cost, iters, status
 
+    def solve_base_batch(self, qc, goals, n_goals=None, effort_weight=0.01, max_iter=100, n_threads=0):
+        """Base placement for B goal sets (gto/base_planner.py:35-134): qc (B,ndof), goals (B,n_max,4,4).
+        Returns (y (B,3) = x, y, theta, q (B,n_max,ndof), cost (B,), iters (B,), status (B,))."""
+        d = self.desc
+        qc = _f64(qc).reshape(-1, d.ndof)
+        B = qc.shape[0]
+        goals = _f64(goals).reshape(B, -1, 16)
+        n_max = goals.shape[1]
+        ng = _i32(np.broadcast_to(np.asarray(n_max if n_goals is None else n_goals), (B,)))
+        y, q, cost = np.empty((B, 3)), np.zeros((B, n_max, d.ndof)), np.empty(B)
+        iters, status = np.empty(B, dtype=np.int32), np.empty(B, dtype=np.int32)
+        f = self.lib.orc_solve_base_batch
+        f.argtypes = [C.POINTER(CRobotDesc), C.POINTER(CSolverOpts), C.c_int32, C.c_int32, _pi, _pd, _pd, C.c_double,
+                      C.c_int32, _pd, _pd, _pd, _pi, _pi, C.c_int32]
+        f.restype = C.c_int
+        rc = f(C.byref(self._cdesc), C.byref(self.opts), B, n_max, _p(ng, _pi), _p(qc, _pd), _p(goals, _pd),
+               float(effort_weight), int(max_iter), _p(y, _pd), _p(q, _pd), _p(cost, _pd), _p(iters, _pi),
+               _p(status, _pi), n_threads)
+        if rc != 0:
+            raise RuntimeError(f"orc_solve_base_batch failed ({rc})")
+        return y, q, cost, iters, status
+
     def eval_objective(self, scene_id, goals, n_goals, standoff, base_pos, Q):
         d, T = self.desc, self.T
         Q = _f64(Q).reshape(-1, d.ndof, T)

@@ -12,6 +12,7 @@ What executes from the reference:
   gto/sdf_callback.py                      SDFCallback / JacFun / HesFun .eval
   gto/utils.py                             interpolate_waypoints (scipy CubicSpline)
   mesh_to_sdf/depth_point_cloud.py         DepthPointCloud.get_sdf / get_sdf_cost (sklearn KDTree)
+  gto/gto_models.py                        setup_occupancy_grid, points_to_offsets_occupancy_numpy (mobile base)
 Third-party modules that are absent (casadi, urdf_parser_py, ...) are replaced by the numpy
 stand-ins in _reference_stubs.py; no reference source is copied into the fixtures.
 """
@@ -33,7 +34,7 @@ import _reference_stubs as stubs  # noqa: E402
 REF = stubs.REF
 
 
-def extract_functions(path, names):
+def extract_functions(path, names, extra_ns=None):
     """Compile selected function definitions out of a reference file without importing it."""
     src = open(path).read()
     tree = ast.parse(src)
@@ -42,6 +43,7 @@ def extract_functions(path, names):
         if isinstance(node, ast.FunctionDef) and node.name in names:
             code = textwrap.dedent(ast.get_source_segment(src, node))
             ns = {"np": np}
+            ns.update(extra_ns or {})
             exec(compile(code, path, "exec"), ns)
             out[node.name] = ns[node.name]
     return out
@@ -131,6 +133,28 @@ def golden_grid(rng):
     return out
 
 
+def golden_occupancy(rng):
+    """x-y occupancy grid of the mobile pipeline (gto/gto_models.py:218-270; sklearn KDTree as there)."""
+    from sklearn.neighbors import KDTree
+    import io
+    import contextlib
+    fns = extract_functions(f"{REF}/gto/gto_models.py", {"setup_occupancy_grid", "points_to_offsets_occupancy_numpy"},
+                            {"KDTree": KDTree})
+    # a table-like slab of points in front of the robot plus floor points (z <= 0.01 are ignored by the reference)
+    n = 6000
+    cloud = np.concatenate([
+        np.c_[rng.uniform(0.6, 1.4, n), rng.uniform(-0.7, 0.5, n), rng.uniform(0.02, 0.8, n)],
+        np.c_[rng.uniform(0.0, 2.0, 500), rng.uniform(-1.0, 1.0, 500), rng.uniform(-0.01, 0.01, 500)],
+        np.c_[rng.uniform(1.7, 1.75, 40), rng.uniform(0.9, 0.95, 40), rng.uniform(0.3, 0.4, 40)]])
+    obj = types.SimpleNamespace(field_margin=0.4, grid_resolution=0.05)
+    with contextlib.redirect_stdout(io.StringIO()):
+        fns["setup_occupancy_grid"](obj, cloud)
+    q = np.c_[rng.uniform(-0.8, 2.6, 3000), rng.uniform(-1.6, 1.8, 3000), rng.uniform(0, 1, 3000)]
+    return dict(cloud=cloud, origin=obj.occupancy_grid_origin, shape=np.array(obj.occupancy_grid_shape),
+                size=obj.occupancy_grid_size, grid=obj.occupancy_grid, query=q,
+                offsets=fns["points_to_offsets_occupancy_numpy"](obj, q.copy()))
+
+
 def golden_depth(ref, rng):
     H, W = 48, 64
     K = np.array([[60.0, 0, 32.0], [0, 60.0, 24.0], [0, 0, 1.0]])
@@ -195,6 +219,9 @@ def golden_plans():
 
 
 def main():
+    if "--only-occupancy" in sys.argv:  # added later; its own generator so the other fixtures stay byte-identical
+        np.savez_compressed(f"{HERE}/occupancy.npz", **golden_occupancy(np.random.default_rng(20240207)))
+        return
     ref = stubs.install()
     rng = np.random.default_rng(20240206)
     fk_panda = golden_fk(ref, "panda", rng)
@@ -215,6 +242,7 @@ def main():
                            [0.7883297, 0.6071185, 0.09971584, -0.15167381],
                            [0.06673018, 0.07674521, -0.99481508, 0.22877409], [0, 0, 0, 1.0]]))
     np.savez_compressed(f"{HERE}/known_answers.npz", **known)
+    np.savez_compressed(f"{HERE}/occupancy.npz", **golden_occupancy(np.random.default_rng(20240207)))
     for f in sorted(glob.glob(f"{HERE}/*.npz")):
         print(os.path.basename(f), os.path.getsize(f))
 

@@ -348,6 +348,48 @@ def test_ik_matches_oracle(capi, oracle_mod, robot, collide, grad_mode):
     h.close()
 
 
+@pytest.mark.parametrize("robot,n", [("fetch", 10), ("panda", 32), ("fetch", 1)])
+def test_base_placement_matches_oracle(capi, oracle_mod, robot, n):
+    """gto_solve_base_batch (one workgroup per goal set, arrow system eliminated on the GPU) against the CPU
+    restatement of gto/base_planner.py: same iteration counts and status; base pose and joint angles within
+    1e-6 (m, rad) where the problem is well conditioned (no effort term, or a bounded number of iterations
+    with it); with the tiny effort weight run to the cap the minimiser sits in a nearly flat valley (the arm
+    can absorb base motion), so there the objective is compared (1e-6 relative) and the point only coarsely.
+    Ragged goal sets and the padding rows of q_out are covered as well."""
+    from grasptrajopt_amd import load_builtin, synthetic as syn
+    cfg, desc = cfg_of(robot), load_builtin(robot)
+    opts = oracle_mod.reference_opts()
+    h = capi.SolverHandle(desc, cfg["link_ee"], cfg["link_gripper"], opts, device=0, n_gripper_points=100)
+    o = oracle_mod.Oracle(desc, cfg["link_ee"], cfg["link_gripper"], opts, n_gripper_points=100)
+    qc = np.array(cfg["default_pose"], dtype=np.float64)
+    B = 9
+    goals, _ = syn.make_base_goal_sets(desc, h.eval_fk, cfg["link_ee"], qc, B, n, seed=3)
+    QC = np.tile(qc, (B, 1))
+    rng = np.random.default_rng(2)
+    QC[1:, desc.opt_index] += rng.uniform(-0.1, 0.1, size=(B - 1, len(desc.opt_index)))  # per-set current configuration
+    ng = rng.integers(1, n + 1, size=B).astype(np.int32)
+    ng[0] = n
+    for w, cap, tol in ((0.0, 100, 1e-6), (0.01, 25, 1e-6), (0.01, 100, None)):
+        yg, qg, fg, ig, sg = h.solve_base_batch(QC, goals, ng, effort_weight=w, max_iter=cap)
+        yo, qo, fo, io, so = o.solve_base_batch(QC, goals, ng, effort_weight=w, max_iter=cap)
+        np.testing.assert_array_equal(ig, io)
+        np.testing.assert_array_equal(sg, so)
+        np.testing.assert_allclose(fg, fo, rtol=1e-6, atol=1e-14)
+        if tol is not None:
+            np.testing.assert_allclose(yg, yo, atol=tol)
+            np.testing.assert_allclose(qg, qo, atol=tol)
+        else:
+            np.testing.assert_allclose(yg, yo, atol=5e-3)
+        for b in range(B):  # padding rows carry the current configuration
+            np.testing.assert_array_equal(qg[b, ng[b]:], np.broadcast_to(QC[b], (n - ng[b], desc.ndof)))
+    # argument checks fail loudly
+    with pytest.raises(capi.GTOError):
+        h.solve_base_batch(QC, goals, np.zeros(B, dtype=np.int32))
+    with pytest.raises(capi.GTOError):
+        h.solve_base_batch(QC[:1], np.tile(np.eye(4), (1, 33, 1, 1)))
+    h.close()
+
+
 def test_depth_cost_field_matches_reference_golden_and_oracle(capi, oracle_mod):
     """gto_depth_sdf_cost through the DepthPointCloud surface: bit-identical to the reference-generated
     fixture, and to the CPU restatement on a larger random scene (ragged sizes, masked and invalid

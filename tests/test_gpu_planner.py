@@ -157,6 +157,44 @@ def test_ik_solver_surface_matches_oracle(oracle_mod):
     robot.close()
 
 
+def test_base_planner_surface_matches_oracle(oracle_mod):
+    """BasePlanner called the way examples/pybullet_gto_planning_mobile.py:127,183-199 calls the reference:
+    setup_occupancy_grid(points); setup_optimization(n, weight); plan_goalset(q0 (ndof,1), RTs) ->
+    (plan (ndof,n), y, err_pos, err_rot, cost); the base pose then moves the robot and the goals."""
+    cfg = cfg_of("fetch")
+    robot = g.GTORobotModel(desc=g.load_builtin("fetch"), time_derivs=[0, 1], param_joints=cfg["param_joints"],
+                            collision_link_names=cfg["collision_link_names"], device=0)
+    orc = oracle_mod.Oracle(robot.desc, cfg["link_ee"], cfg["link_gripper"], oracle_mod.reference_opts())
+    qc = np.array(cfg["default_pose"], dtype=np.float64)
+    n = 6
+    goals, ystar = syn.make_base_goal_sets(robot.desc, orc.eval_fk, cfg["link_ee"], qc, 2, n, seed=4)
+    # observed scene: a table far in front of the robot -> the robot's footprint is free before and after the move
+    rng = np.random.default_rng(0)
+    cloud = np.c_[rng.uniform(1.6, 2.2, 4000), rng.uniform(-0.6, 0.6, 4000), rng.uniform(0.02, 0.75, 4000)]
+    robot.setup_occupancy_grid(cloud)
+    bp = g.BasePlanner(robot, cfg["link_ee"], cfg["link_gripper"])
+    bp.setup_optimization(n, 0.0)
+    plan, y, err_pos, err_rot, cost = bp.plan_goalset(qc.reshape(-1, 1), goals[0])
+    assert plan.shape == (robot.ndof, n) and y.shape == (3,) and err_pos.shape == (n,) and err_rot.shape == (n,)
+    yo, qo, fo, _, _ = orc.solve_base_batch(qc[None], goals[:1], effort_weight=0.0)
+    np.testing.assert_allclose(y, yo[0], atol=1e-6)
+    np.testing.assert_allclose(plan, qo[0].T, atol=1e-6)
+    assert (err_pos < 1e-3).all() and (err_rot < 0.1).all()  # reachable by construction
+    assert cost == 0.0
+    # an obstacle exactly where the robot stands after the move is counted by the occupancy statistic
+    RT_inv = np.linalg.inv(syn.base_pose_matrix(y))
+    foot, _ = robot.compute_fk_surface_points(qc, tf_base=RT_inv)
+    robot.setup_occupancy_grid(np.r_[cloud, foot[foot[:, 2] > 0.05][::7]])
+    assert bp.base_collision_cost(qc, y) > 0
+    # both goal sets in one call, and with the effort term the base moves less
+    Q2, y2, ep2, er2, it2, st2 = bp.plan_goalset_batch(qc, goals)
+    np.testing.assert_allclose(y2[0], y, atol=1e-9)
+    bp.setup_optimization(n, 0.01)
+    _, yw, _, _, _ = bp.plan_goalset(qc, goals[0])
+    assert np.linalg.norm(yw) < np.linalg.norm(y)
+    robot.close()
+
+
 def test_evaluator_collision_statistic_composes(oracle_mod):
     """examples/pybullet_evaluate_plans.py:219-233 through the drop-in classes: FK surface points of every
     waypoint + DepthPointCloud.get_sdf, batched (utils.plan_in_collision) and as the reference's loop."""

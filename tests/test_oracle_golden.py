@@ -157,3 +157,55 @@ def test_depth_cost_field_against_reference_golden(oracle_mod):
         np.testing.assert_array_equal(inside, g[f"{tag}_inside"])
         np.testing.assert_array_equal(cost, g[f"{tag}_cost"])
     assert g["all_inside"].any() and (~g["all_inside"]).any()
+
+
+def test_base_placement_oracle_recovers_reachable_goal_sets(oracle_mod):
+    """Base-placement restatement (gto/base_planner.py:35-94): goal sets generated as reachable from a
+    displaced base are matched to zero residual without the effort term (Gauss-Newton converges in a few
+    iterations, which pins the Jacobian of every block); with the effort term the optimum trades a small
+    residual for a smaller base motion; a single goal needs no base motion at all."""
+    from helpers import cfg_of
+    from grasptrajopt_amd import load_builtin, synthetic as syn
+    cfg, desc = cfg_of("fetch"), load_builtin("fetch")
+    o = oracle_mod.Oracle(desc, cfg["link_ee"], cfg["link_gripper"], oracle_mod.reference_opts(), n_gripper_points=100)
+    qc = np.array(cfg["default_pose"], dtype=np.float64)
+    B, n = 4, 6
+    goals, ystar = syn.make_base_goal_sets(desc, o.eval_fk, cfg["link_ee"], qc, B, n, seed=1)
+    QC = np.tile(qc, (B, 1))
+    y, q, f, it, st = o.solve_base_batch(QC, goals, effort_weight=0.0, n_threads=1)
+    assert (f < 1e-8).all() and (st == 0).all() and (it <= 60).all()  # relative-decrease stop: tol_rel_f = 1e-8
+    fe, fg = desc.frame_index(cfg["link_ee"]), desc.frame_index(cfg["link_gripper"])
+    fr = o.eval_fk(q.reshape(B * n, -1)).reshape(B, n, -1, 4, 4)
+    for b in range(B):  # tf_base @ RT_i == FK_ee(q_i): the base pose and the arm postures are consistent
+        np.testing.assert_allclose(syn.base_pose_matrix(y[b]) @ goals[b], fr[b, :, fe], atol=1e-4)
+    oi, pi = desc.opt_index, desc.param_index
+    assert (q[..., oi] >= desc.lower[oi] - 1e-12).all() and (q[..., oi] <= desc.upper[oi] + 1e-12).all()
+    np.testing.assert_array_equal(q[..., pi], np.broadcast_to(qc[pi], q[..., pi].shape))
+    assert (np.abs(y[:, 2]) <= np.pi).all()
+    # effort term: smaller base motion, small positive residual; objective below the zero-effort point's value
+    yw, qw, fw, _, _ = o.solve_base_batch(QC, goals, effort_weight=0.01, n_threads=1)
+    assert (np.linalg.norm(yw, axis=1) < np.linalg.norm(y, axis=1)).all()
+    assert (fw <= 0.01 * (y ** 2).sum(axis=1) + 1e-9).all()
+    # ragged goal sets: a set's solution does not depend on the padding rows
+    ng = np.array([n, 3, 1, 2], dtype=np.int32)
+    yr, qr, fr_, itr, _ = o.solve_base_batch(QC, goals, n_goals=ng, effort_weight=0.0, n_threads=1)
+    np.testing.assert_array_equal(yr[0], y[0])
+    y1, q1, f1, _, _ = o.solve_base_batch(QC[1:2], goals[1:2, :3], effort_weight=0.0, n_threads=1)
+    np.testing.assert_array_equal(yr[1], y1[0])
+    np.testing.assert_array_equal(qr[1, :3], q1[0])
+    np.testing.assert_array_equal(qr[1, 3:], np.broadcast_to(qc, (n - 3, len(qc))))
+
+
+def test_occupancy_grid_against_reference_golden():
+    """x-y occupancy grid of the mobile pipeline (gto/gto_models.py:218-273), pinned on a fixture produced
+    by the reference's own setup_occupancy_grid / points_to_offsets_occupancy_numpy (sklearn KD-tree)."""
+    import types
+    from grasptrajopt_amd.gto_models import GTORobotModel
+    d = golden("occupancy.npz")
+    o = types.SimpleNamespace(field_margin=0.4, grid_resolution=0.05)
+    GTORobotModel.setup_occupancy_grid(o, d["cloud"])
+    np.testing.assert_array_equal(o.occupancy_grid_origin, d["origin"])
+    assert tuple(o.occupancy_grid_shape) == tuple(d["shape"]) and o.occupancy_grid_size == int(d["size"])
+    np.testing.assert_array_equal(o.occupancy_grid, d["grid"])
+    assert 0 < o.occupancy_grid.sum() < o.occupancy_grid_size
+    np.testing.assert_array_equal(GTORobotModel.points_to_offsets_occupancy_numpy(o, d["query"]), d["offsets"])

@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""base_rate.py — base placement (gto_solve_base_batch) against the oracle and its rate.
+Usage: python tools/base_rate.py [--robot fetch] [--sets 64] [--goals 10]"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--robot", default="fetch")
+    ap.add_argument("--sets", type=int, default=64)
+    ap.add_argument("--goals", type=int, default=10)
+    ap.add_argument("--effort", type=float, default=0.01)
+    args = ap.parse_args()
+    from grasptrajopt_amd import _capi, synthetic as syn
+    from grasptrajopt_amd.robot_desc import load_builtin
+    from oracle import oracle
+
+    desc = load_builtin("panda_5k" if args.robot == "panda" else args.robot)
+    cfg = json.load(open(os.path.join(ROOT, "grasptrajopt_amd", "data", f"{args.robot}_cfg.json")))
+    opts = _capi.default_opts()
+    h = _capi.SolverHandle(desc, cfg["link_ee"], cfg["link_gripper"], opts, device=0, n_gripper_points=100)
+    orc = oracle.Oracle(desc, cfg["link_ee"], cfg["link_gripper"], opts, n_gripper_points=100)
+    qc = np.array(cfg["default_pose"], dtype=np.float64)
+    goals, ystar = syn.make_base_goal_sets(desc, h.eval_fk, cfg["link_ee"], qc, args.sets, args.goals, 0)
+    QC = np.tile(qc, (args.sets, 1))
+    for w in (0.0, args.effort):
+        yg, qg, cg, ig, sg = h.solve_base_batch(QC, goals, effort_weight=w)
+        t0 = time.perf_counter()
+        yg, qg, cg, ig, sg = h.solve_base_batch(QC, goals, effort_weight=w)
+        tg = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        yo, qo, co, io, so = orc.solve_base_batch(QC, goals, effort_weight=w)
+        to = time.perf_counter() - t0
+        print(f"effort {w}: GPU {args.sets / tg:9.1f} sets/s  oracle {args.sets / to:8.1f} sets/s ({oracle.Oracle.num_threads()} threads)")
+        print(f"  max|dy| {np.abs(yg - yo).max():.3e}  max|dq| {np.abs(qg - qo).max():.3e}  max|dcost| {np.abs(cg - co).max():.3e}"
+              f"  iters equal {np.array_equal(ig, io)} (mean {ig.mean():.1f}, max {ig.max()})  status equal {np.array_equal(sg, so)}")
+        print("  y[0] gpu", yg[0], "oracle", yo[0], "planted", ystar[0], "cost", cg[0])
+
+
+if __name__ == "__main__":
+    main()
