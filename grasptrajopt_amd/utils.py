@@ -61,3 +61,24 @@ def plan_in_collision(robot, depth_pc, plan, base_position=(0.0, 0.0, 0.0), max_
     count = (sdf < 0).sum(axis=1)
     hit = np.nonzero(count > max_points)[0]
     return bool(hit.size), int(hit[0]) if hit.size else -1, count
+
+
+def grasp_collision_ratio(gripper_model, depth_pc, RT_grasps, q_gripper, RT_offset=None):
+    """The grasp collision filter of the planning driver (examples/pybullet_gto_planning.py:203-219,
+    examples/pybullet_gto_planning_mobile.py:307-322): for every candidate grasp pose the open gripper's
+    surface points are placed at ``RT_grasp @ RT_offset`` and the fraction with a negative signed distance to
+    the observed obstacles is returned (the driver rejects ratios above 0.01).  The gripper's points are
+    computed once and all n x P placed points go to the GPU in ONE DepthPointCloud.get_sdf call instead of
+    one FK + one KD-tree query per grasp.  Returns ratio (n,) float64."""
+    RT = np.asarray(RT_grasps, dtype=np.float64).reshape(-1, 4, 4)
+    if RT_offset is not None:
+        RT = RT @ np.asarray(RT_offset, dtype=np.float64)
+    pts, _ = gripper_model.compute_fk_surface_points(q_gripper)  # gripper frame, (P, 3)
+    world = np.einsum("nij,pj->npi", RT[:, :3, :3], pts) + RT[:, None, :3, 3]
+    sdf = np.asarray(depth_pc.get_sdf(world.reshape(-1, 3))).reshape(RT.shape[0], -1)
+    return (sdf < 0).sum(axis=1) / sdf.shape[1]
+
+
+def filter_grasps(gripper_model, depth_pc, RT_grasps, q_gripper, RT_offset=None, threshold: float = 0.01):
+    """in_collision (n,) int32 exactly as the driver builds it: ratio > threshold."""
+    return (grasp_collision_ratio(gripper_model, depth_pc, RT_grasps, q_gripper, RT_offset) > threshold).astype(np.int32)

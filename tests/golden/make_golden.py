@@ -218,7 +218,46 @@ def golden_plans():
     return out
 
 
+def golden_results():
+    """Evaluator totals of the stored result files (examples/pybullet_evaluate_plans.py:162-181,262-290),
+    counted here with plain loops, and a one-scene excerpt of one file as a wire-format sample."""
+    def count(data):
+        n = succ = 0
+        tsum = {"checking_time": 0.0, "ik_time": 0.0, "planning_time": 0.0}
+        tcnt = {"checking_time": 0, "ik_time": 0, "planning_time": 0}
+        per_obj = {}
+        for scene in data.values():
+            for order in scene.values():
+                for name, obj in order.items():
+                    if not (isinstance(obj, dict) and "reward" in obj):
+                        continue
+                    n += 1
+                    succ += obj["reward"]
+                    c = per_obj.setdefault(name, [0, 0])
+                    c[0] += 1
+                    c[1] += obj["reward"]
+                    for k in tsum:
+                        if obj.get(k) is not None:
+                            tsum[k] += obj[k]
+                            tcnt[k] += 1
+        return dict(trials=n, success=succ, per_object=per_obj,
+                    mean_time={k: (tsum[k] / tcnt[k] if tcnt[k] else None) for k in tsum})
+
+    totals = {}
+    for fn in sorted(glob.glob(f"{REF}/examples/results_iros2024/GTO_*.json")):
+        totals[os.path.basename(fn)] = count(json.load(open(fn)))
+    fn = sorted(glob.glob(f"{REF}/examples/results_iros2024/GTO_scenereplica_mobile_fetch_tabletop_*.json"))[0]
+    data = json.load(open(fn))
+    first = next(iter(data))
+    totals["excerpt"] = count({first: data[first]})
+    return totals, {first: data[first]}, os.path.basename(fn)
+
+
 def main():
+    if "--only-results" in sys.argv:
+        totals, excerpt, name = golden_results()
+        json.dump(dict(totals=totals, excerpt=excerpt, excerpt_of=name), open(f"{HERE}/results.json", "w"))
+        return
     if "--only-occupancy" in sys.argv:  # added later; its own generator so the other fixtures stay byte-identical
         np.savez_compressed(f"{HERE}/occupancy.npz", **golden_occupancy(np.random.default_rng(20240207)))
         return
@@ -243,6 +282,8 @@ def main():
                            [0.06673018, 0.07674521, -0.99481508, 0.22877409], [0, 0, 0, 1.0]]))
     np.savez_compressed(f"{HERE}/known_answers.npz", **known)
     np.savez_compressed(f"{HERE}/occupancy.npz", **golden_occupancy(np.random.default_rng(20240207)))
+    totals, excerpt, name = golden_results()
+    json.dump(dict(totals=totals, excerpt=excerpt, excerpt_of=name), open(f"{HERE}/results.json", "w"))
     for f in sorted(glob.glob(f"{HERE}/*.npz")):
         print(os.path.basename(f), os.path.getsize(f))
 

@@ -103,3 +103,43 @@ def test_urdf_and_mesh_front_end(tmp_path):
     # same seed -> same points (the reference's draw is unseeded; ours is reproducible)
     r2 = g.GTORobotModel(str(tmp_path), urdf_filename=str(tmp_path / "r.urdf"), param_joints=["j3"], points_per_link=50)
     np.testing.assert_array_equal(r2.desc.points, d.points)
+
+
+def test_result_files_wire_format_and_evaluator_totals(tmp_path):
+    """Row f-4: the result tree of examples/pybullet_gto_planning.py:321-338 (and the mobile driver's
+    RT_base_new entry) read back from an excerpt of one of the reference's stored files, the evaluator's
+    totals (examples/pybullet_evaluate_plans.py:162-181,262-290) against counts made with plain loops when the
+    fixture was generated, and a write/read round trip under the reference's file name pattern."""
+    import datetime
+    import json
+    from conftest import GOLDEN
+    from grasptrajopt_amd import results as R
+    g = json.load(open(os.path.join(GOLDEN, "results.json")))
+    tree, want = g["excerpt"], g["totals"]["excerpt"]
+    trials = list(R.iter_trials(tree))
+    assert len(trials) == want["trials"] and all(name != "RT_base_new" for _, _, name, _ in trials)
+    s = R.summarize(tree)
+    assert s["total_trial"] == want["trials"] and s["total_success"] == want["success"] and s["total_collision"] == 0
+    assert {k: [v["total"], v["success"]] for k, v in s["per_object"].items()} == want["per_object"]
+    for k in R.TIME_KEYS:
+        assert s["mean_time"][k] == pytest.approx(want["mean_time"][k], rel=1e-12)
+    assert s["total_time"] == pytest.approx(sum(want["mean_time"].values()), rel=1e-12)
+    plans = [R.plan_array(e) for _, _, _, e in trials if e["plan"] is not None]
+    assert plans and all(p.shape == (15, 50) for p in plans)  # Fetch: ndof 15, T = 50
+    # collision callback is asked once per stored plan
+    seen = []
+    s2 = R.summarize(tree, in_collision=lambda sc, od, ob, plan: (seen.append(ob), plan.shape == (15, 50))[1])
+    assert len(seen) == len(plans) and s2["total_collision"] == len(plans)
+    # writer: same tree shape, reference file name pattern, failures carry plan None
+    out = {"7": {"random": {"003_cracker_box": R.object_result(1, plans[0], 0.5, 1.25, 0.01),
+                            "024_bowl": R.object_result(0, None, 0.4, None, None)}}}
+    now = datetime.datetime(2024, 2, 6, 18, 7, 50)
+    path = R.write_results(out, str(tmp_path), "panda", "tabletop", now=now)
+    assert path.endswith("GTO_scenereplica_panda_tabletop_24-02-06_T180750.json")
+    assert R.result_filename("fetch", "shelf", mobile=True, now=now) == "GTO_scenereplica_mobile_fetch_shelf_24-02-06_T180750.json"
+    back = R.read_results(path)
+    assert back == json.loads(json.dumps(out))
+    sb = R.summarize(back)
+    assert sb["total_trial"] == 2 and sb["total_success"] == 1
+    assert sb["mean_time"] == {"checking_time": pytest.approx(0.45), "ik_time": 1.25, "planning_time": 0.01}
+    np.testing.assert_array_equal(R.plan_array(back["7"]["random"]["003_cracker_box"]), plans[0])

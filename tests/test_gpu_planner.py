@@ -222,3 +222,40 @@ def test_evaluator_collision_statistic_composes(oracle_mod):
     np.testing.assert_array_equal(count, ref_count)
     assert hit and first == int(np.nonzero(np.array(ref_count) > 5)[0][0]) and count[0] <= 5
     robot.close()
+
+
+def test_grasp_collision_filter_matches_reference_loop(oracle_mod):
+    """Row f-3: the driver's grasp filter (examples/pybullet_gto_planning.py:203-219) batched
+    (utils.grasp_collision_ratio: one get_sdf call for all grasps) against the reference's own loop of
+    compute_fk_surface_points(q, tf_base=RT @ standoff) + get_sdf per grasp, through the drop-in classes."""
+    from grasptrajopt_amd.utils import grasp_collision_ratio, filter_grasps
+    cfg = cfg_of("panda")
+    # any GTORobotModel serves as the gripper model; here the arm's own point set at a fixed configuration
+    gripper = g.GTORobotModel(desc=g.load_builtin("panda"), time_derivs=[0, 1], param_joints=cfg["param_joints"],
+                              collision_link_names=cfg["collision_link_names"], device=0)
+    H, W = 60, 80
+    K = np.array([[70.0, 0, 40.0], [0, 70.0, 30.0], [0, 0, 1.0]])
+    cam = np.eye(4)
+    cam[:3, :3] = np.array([[0, -1.0, 0], [-1.0, 0, 0], [0, 0, -1.0]])
+    cam[:3, 3] = [0.5, 0.0, 1.5]
+    depth = np.full((H, W), 1.5, dtype=np.float32)
+    depth[15:45, 25:55] = 1.0  # a 0.5 m block on the floor
+    dpc = g.DepthPointCloud(depth, K, cam)
+    rng = np.random.default_rng(1)
+    n = 24
+    RT = np.tile(np.eye(4), (n, 1, 1))
+    RT[:, :3, 3] = np.c_[rng.uniform(0.0, 1.0, n), rng.uniform(-0.6, 0.6, n), rng.uniform(-0.3, 0.9, n)]
+    ang = rng.uniform(-np.pi, np.pi, n)
+    RT[:, 0, 0], RT[:, 0, 1], RT[:, 1, 0], RT[:, 1, 1] = np.cos(ang), -np.sin(ang), np.sin(ang), np.cos(ang)
+    off = syn.standoff_pose(-0.1, "z")
+    q = np.array(cfg["default_pose"])
+    ratio = grasp_collision_ratio(gripper, dpc, RT, q, off)
+    ref = np.empty(n)
+    for i in range(n):
+        pts, _ = gripper.compute_fk_surface_points(q, tf_base=RT[i] @ off)
+        sdf = dpc.get_sdf(pts)
+        ref[i] = np.sum(sdf < 0) / len(sdf)
+    np.testing.assert_allclose(ratio, ref, atol=2.0 / gripper.desc.n_points)  # points exactly on the zero level may flip
+    assert (ratio > 0.01).any() and (ratio <= 0.01).any()
+    np.testing.assert_array_equal(filter_grasps(gripper, dpc, RT, q, off), (ratio > 0.01).astype(np.int32))
+    gripper.close()
