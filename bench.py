@@ -32,14 +32,18 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s sp
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--steps", type=int, default=96)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="goal grasps (instances) per GPU per step")
-    ap.add_argument("--pipeline", type=int, default=4, help="batches (steps) in flight per GPU: solver handles/streams")
+    ap.add_argument("--pipeline", type=int, default=4, help="lanes per GPU: solver handles, each with its stream and host thread")
+    ap.add_argument("--merge", type=int, default=4, help="steps (batches) a lane folds into one launch; steps in flight = pipeline x merge")
     ap.add_argument("--max-iter", type=int, default=100, help="iteration cap (reference IPOPT cap: 100)")
     ap.add_argument("--robot", default="panda_5k")
     ap.add_argument("--grid", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--merged-launches-only", action="store_true",
+                    help="skip the one-batch-per-launch passes (serial latency, host API): every launch of the run then has the "
+                         "timed region's size, which is what the per-launch PMC averages of tools/pmc_pass.sh need")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the CPU-baseline sample")
     ap.add_argument("--traffic", type=float, default=None,
                     help="HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes (see profiles/)")
@@ -78,7 +82,7 @@ def main():
     opts = _capi.default_opts()
     opts.max_iter = args.max_iter
     T, ndof, B = opts.T, desc.ndof, args.batch
-    D = max(1, args.pipeline)
+    D, M = max(1, args.pipeline), max(1, args.merge)
 
     # this rank's shard of the global problem list: scene = global rank id, 64 grasps each
     lo, hi = shard_range(world * B, rank, world)
@@ -88,8 +92,9 @@ def main():
     sc = syn.make_scene(scene_seed, n=args.grid, res=res, origin=(-0.3, -1.12, 0.0) if fetch else (-0.4, -1.12, -0.4),
                         table_z=0.45 if fetch else -0.03)
 
-    # D pipeline lanes: each one solver handle bound to ONE stream of its own, with its own copy of the
-    # batch in HBM and its own outputs (grasptrajopt_amd.parallel.BatchPipeline runs them concurrently)
+    # D pipeline lanes: each one solver handle bound to ONE stream of its own, with its own copy of M batches
+    # (M consecutive steps, distinct goal sets) in HBM and its own outputs; a launch solves m <= M of them at
+    # once (grasptrajopt_amd.parallel.BatchPipeline runs the lanes concurrently)
     class Lane:
         def __init__(self, first=None):
             self.stream = torch.cuda.Stream(dev)
@@ -101,18 +106,21 @@ def main():
                 self.h.share_scene(0, first.h)  # one copy of the scene in HBM for all lanes
 
         def upload(self, qc, RT, S, base, Q0):
+            n = qc.shape[0]  # M * B instances, batch m in rows [m B, (m+1) B)
             t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(dt).to(dev)
-            self.inp = [torch.zeros(B, dtype=torch.int32, device=dev), t(qc, torch.float64), t(RT.reshape(B, 1, 16), torch.float64),
-                        torch.ones(B, dtype=torch.int32, device=dev), t(S, torch.float64), t(base, torch.float64), t(Q0, torch.float64)]
-            self.d_Q = torch.empty((B, ndof, T), dtype=torch.float64, device=dev)
-            self.d_dQ = torch.empty((B, ndof, T - 1), dtype=torch.float64, device=dev)
-            self.d_cost = torch.empty(B, dtype=torch.float64, device=dev)
-            self.d_it = torch.empty(B, dtype=torch.int32, device=dev)
-            self.d_st = torch.empty(B, dtype=torch.int32, device=dev)
-            self.ptrs = [x.data_ptr() for x in self.inp + [self.d_Q, self.d_dQ, self.d_cost, self.d_it, self.d_st]]
+            self.inp = [torch.zeros(n, dtype=torch.int32, device=dev), t(qc, torch.float64), t(RT.reshape(n, 1, 16), torch.float64),
+                        torch.ones(n, dtype=torch.int32, device=dev), t(S, torch.float64), t(base, torch.float64), t(Q0, torch.float64)]
+            self.d_Q = torch.empty((n, ndof, T), dtype=torch.float64, device=dev)
+            self.d_dQ = torch.empty((n, ndof, T - 1), dtype=torch.float64, device=dev)
+            self.d_cost = torch.empty(n, dtype=torch.float64, device=dev)
+            self.d_it = torch.empty(n, dtype=torch.int32, device=dev)
+            self.d_st = torch.empty(n, dtype=torch.int32, device=dev)
+            self.bufs = self.inp + [self.d_Q, self.d_dQ, self.d_cost, self.d_it, self.d_st]
 
-        def step(self):
-            self.h.solve_batch_device(B, 1, *self.ptrs, self.stream.cuda_stream)
+        def step(self, m=1, first=0):
+            """One launch over batches first .. first+m-1 of this lane."""
+            ptrs = [x.data_ptr() + first * B * x.stride(0) * x.element_size() for x in self.bufs]
+            self.h.solve_batch_device(m * B, 1, *ptrs, self.stream.cuda_stream)
 
     lanes = [Lane()]
     lanes += [Lane(lanes[0]) for _ in range(D - 1)]
@@ -125,12 +133,15 @@ def main():
         _, _, val, _ = h.eval_points(0, q, [0.0, 0.0, 0.0], use_obs=True)
         return (val * moving[None, :]).sum(axis=1)
 
-    RT, qg = syn.make_goals(desc, h.eval_fk, cfg["link_ee"], B, seed=scene_seed, collision_cost=goal_collision_cost,
-                            zlim=(0.55, 1.2) if fetch else (0.08, 0.7))
-    qc = np.tile(np.array(cfg["default_pose"]), (B, 1))
-    Q0 = np.stack([syn.make_seed(qc[b], qg[b], T, desc.param_index) for b in range(B)])
-    S = np.tile(syn.standoff_pose(-0.1, cfg["axis_standoff"]).reshape(1, 16), (B, 1))
-    base = np.zeros((B, 3))
+    zlim = (0.55, 1.2) if fetch else (0.08, 0.7)
+    sets = [syn.make_goals(desc, h.eval_fk, cfg["link_ee"], B, seed=scene_seed + 1009 * m, collision_cost=goal_collision_cost, zlim=zlim)
+            for m in range(M)]  # M different grasp sets in the same scene: the batches of M consecutive steps
+    RT, qg = np.concatenate([x[0] for x in sets]), np.concatenate([x[1] for x in sets])
+    NB = M * B
+    qc = np.tile(np.array(cfg["default_pose"]), (NB, 1))
+    Q0 = np.stack([syn.make_seed(qc[b], qg[b], T, desc.param_index) for b in range(NB)])
+    S = np.tile(syn.standoff_pose(-0.1, cfg["axis_standoff"]).reshape(1, 16), (NB, 1))
+    base = np.zeros((NB, 3))
     for ln in lanes:
         ln.upload(qc, RT, S, base, Q0)
     torch.cuda.synchronize(dev)
@@ -140,51 +151,71 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    def launch_plan(n):
+        """Split n steps (batches) into launches of at most M batches, a multiple of D launches when n allows,
+        sizes within one of each other: every lane gets the same amount of work."""
+        L = max(-(-n // M), min(n, D))
+        if L % D and n >= D * (L // D + 1):
+            L = D * (L // D + 1)
+        return [n // L + (1 if i < n % L else 0) for i in range(L)]
+
     def run_steps(pipe, n):
-        futs = [pipe.submit("step") for _ in range(n)]
+        futs = [pipe.submit("step", m) for m in launch_plan(n)]
         for f in futs:
             f.result()
 
     pipe = BatchPipeline(lanes)
-    run_steps(pipe, args.warmup * D)  # every lane sees >= W warmup steps
+    run_steps(pipe, args.warmup * D * M)  # every lane sees >= W warmup launches
     barrier()
-    # ---- timed region: exactly K steps (batches), up to D of them in flight
+    # ---- timed region: exactly K steps (batches), up to D x M of them in flight
     t0 = time.perf_counter()
     run_steps(pipe, args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
     pipe.close()
+    merged_Q, merged_it = lanes[0].d_Q.clone(), lanes[0].d_it.clone()
+    same = all(bool(torch.equal(l.d_Q, merged_Q)) and bool(torch.equal(l.d_it, merged_it)) for l in lanes[1:])
 
-    # ---- the same K steps strictly one after the other on one lane: per-batch latency, then once more
-    # with HIP events around every launch of the dominant kernel (on its launch stream) for the roofline;
-    # alone on the GPU, so a launch's duration is the kernel's own and matches the rocprofv3 summary
+    # ---- the same K steps strictly one after the other, one batch per launch, on one lane: per-batch
+    # latency (and a check that a batch solved alone equals the batch solved inside a merged launch)
     ln0 = lanes[0]
     barrier()
     ts = time.perf_counter()
-    for _ in range(args.steps):
-        ln0.step()
-    barrier()
+    merged_equals_single = None
+    if not args.merged_launches_only:
+        for k in range(args.steps):
+            ln0.step(1, k % M)
+        barrier()
+        covered = min(args.steps, M) * B
+        merged_equals_single = bool(torch.equal(ln0.d_Q[:covered], merged_Q[:covered])) and bool(torch.equal(ln0.d_it[:covered], merged_it[:covered]))
     serial_elapsed = time.perf_counter() - ts
+    # ---- the launches of the timed region once more, alone on the GPU, with HIP events around every launch
+    # of the dominant kernel (on its launch stream) for the roofline: a launch's duration is then the
+    # kernel's own and matches the rocprofv3 summary
     h.set_profiling(True)
-    kern_ms, kern_launches = 0.0, 0
-    for _ in range(args.steps):
-        ln0.step()
+    kern_ms, kern_launches, prof_steps = 0.0, 0, 0
+    plan = launch_plan(args.steps)
+    for m in plan:
+        ln0.step(m)
         ms, nl = h.last_kernel_time()
         kern_ms += ms
         kern_launches += nl
+        prof_steps += m
     barrier()
     h.set_profiling(False)
+    ln0.step(M)  # full outputs again for the quality gate
+    barrier()
     d_it, d_st, d_cost, d_Q = ln0.d_it, ln0.d_st, ln0.d_cost, ln0.d_Q
-    same = all(bool(torch.equal(l.d_Q, d_Q)) and bool(torch.equal(l.d_it, d_it)) for l in lanes[1:])
 
     # the same solve through the host-pointer entry point (H2D/D2H of per-instance data included)
     host_rate = None
-    if rank == 0:
+    if rank == 0 and not args.merged_launches_only:
         hs = max(2, min(5, args.steps))
-        h.solve_batch(0, qc, RT.reshape(B, 1, 16), 1, S, base, Q0)
+        hargs = (0, qc[:B], RT[:B].reshape(B, 1, 16), 1, S[:B], base[:B], Q0[:B])
+        h.solve_batch(*hargs)
         th = time.perf_counter()
         for _ in range(hs):
-            h.solve_batch(0, qc, RT.reshape(B, 1, 16), 1, S, base, Q0)
+            h.solve_batch(*hargs)
         host_rate = B * hs / (time.perf_counter() - th)
 
     iters = d_it.cpu().numpy().astype(np.int64)
@@ -192,14 +223,17 @@ def main():
     cost = d_cost.cpu().numpy()
     Qsol = d_Q.cpu().numpy()
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    it_sum = torch.tensor([float(iters.sum())], dtype=torch.float64, device=dev)
+    # iterations done inside the timed region: a launch of m steps solves this lane's batches 0 .. m-1
+    per_batch_it = iters.reshape(M, B).sum(axis=1)
+    it_timed = float(sum(per_batch_it[:m].sum() for m in plan))
+    it_sum = torch.tensor([it_timed], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         dist.all_reduce(it_sum, op=dist.ReduceOp.SUM)
     elapsed = float(el.item())
     total_traj = world * B * args.steps
     value = total_traj / elapsed
-    iters_per_s = float(it_sum.item()) * args.steps / elapsed
+    iters_per_s = float(it_sum.item()) / elapsed
 
     if rank == 0:
         # quality gate on this rank's batch
@@ -217,21 +251,24 @@ def main():
         # surface point and free waypoint) / HIP-event time of its launches in the timed region
         P = desc.n_points
         bytes_per_inst_launch = (T - 2) * P * 28
-        evals = float((iters + 1).sum()) * args.steps  # each instance is evaluated iters+1 times per solve
+        per_batch_ev = (iters + 1).reshape(M, B).sum(axis=1)  # each instance is evaluated iters+1 times per solve
+        evals = float(sum(per_batch_ev[:m].sum() for m in plan))
         alg_bytes = evals * bytes_per_inst_launch
         avg_launch_us = 1e3 * kern_ms / max(kern_launches, 1)
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
         traffic = args.traffic
         tj = os.path.join(ROOT, "profiles", "traffic.json")
-        if traffic is None and os.path.exists(tj) and (args.robot, args.grid, B) == ("panda_5k", 128, 64):  # measured on this workload only
-            traffic = json.load(open(tj)).get("k_obstacle_gram_hbm_bytes_per_launch")
+        if traffic is None and os.path.exists(tj):  # quoted only for the workload and launch size it was measured on
+            tr = json.load(open(tj))
+            if (args.robot, args.grid, B * max(plan)) == (tr.get("robot"), tr.get("grid"), tr.get("instances_per_launch")):
+                traffic = tr.get("k_obstacle_gram_hbm_bytes_per_launch")
         roofline = {"bound": "hbm", "kernel": "k_obstacle_gram", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "alg_bytes_per_launch": round(alg_bytes / max(kern_launches, 1)),
                     "avg_launch_us": round(avg_launch_us, 2), "launches": kern_launches,
-                    "kernel_time_frac_of_serial_step": round(kern_ms * 1e-3 / serial_elapsed, 3),
-                    "measured": "HIP events on the launch stream over K serial steps (pipeline depth 1) run right after the "
-                                "timed region, so that launches of other batches do not stretch the durations"}
+                    "instances_per_launch": B * max(plan),
+                    "measured": "HIP events on the launch stream over the K steps' launches (the timed region's launch size, one "
+                                "lane) run right after the timed region, so that launches of other lanes do not stretch the durations"}
 
         cpu_baseline = None
         if not args.no_cpu_baseline:
@@ -242,13 +279,13 @@ def main():
             cores = o.num_threads()
             # pilot on the batch itself, then repeat it so the timed sample is ~10-20 s of CPU work
             tc = time.perf_counter()
-            Qo, _, fo, ito, _ = o.solve_batch(0, qc, RT.reshape(B, 1, 16), 1, S, base, Q0, n_threads=cores)
+            cq, cr, cs_, cb, c0 = qc[:B], RT[:B].reshape(B, 1, 16), S[:B], base[:B], Q0[:B]  # the first batch
+            Qo, _, fo, ito, _ = o.solve_batch(0, cq, cr, 1, cs_, cb, c0, n_threads=cores)
             t_pilot = time.perf_counter() - tc
             reps = int(min(max(np.ceil(args.cpu_seconds / max(t_pilot, 1e-3)), 1), 64))
             tile = lambda a: np.concatenate([a] * reps)
             tc = time.perf_counter()
-            _, _, _, ito_all, _ = o.solve_batch(0, tile(qc), tile(RT.reshape(B, 1, 16)), 1, tile(S), tile(base), tile(Q0),
-                                                n_threads=cores)
+            _, _, _, ito_all, _ = o.solve_batch(0, tile(cq), tile(cr), 1, tile(cs_), tile(cb), tile(c0), n_threads=cores)
             tcpu = time.perf_counter() - tc
             ns = B * reps
             cpu_baseline = {"value": round(ns / tcpu, 3), "unit": "trajectories/s", "cores": cores, "kind": "port",
@@ -256,7 +293,8 @@ def main():
                                       "OpenMP over instances, same algorithm in FP64 (oracle/gto_oracle.c)",
                             "iters_per_s": round(float(ito_all.sum()) / tcpu, 1),
                             "single_core_value": round(ns / tcpu / cores, 4),
-                            "max_abs_dQ_vs_gpu": float(np.abs(Qo - Qsol).max())}
+                            "max_abs_dQ_vs_gpu": float(np.abs(Qo - Qsol[:B]).max()),
+                            "iters_equal_gpu": bool(np.array_equal(ito, iters[:B]))}
 
         out = {
             "metric": "grasp trajectories/sec", "value": round(value, 2), "unit": "trajectories/s",
@@ -267,14 +305,16 @@ def main():
                                     f"BASELINE configs[1]: Panda 7-DoF, 1 scene x {B} goal grasps per GPU, T={int(T)}, ") +
                                    f"{P} surface points, {args.grid}^3 f32 SDF cost field",
                        "batch_per_gpu": B, "T": int(T), "surface_points": int(P), "grid": args.grid,
-                       "max_iter": args.max_iter, "pipeline_depth": D,
+                       "max_iter": args.max_iter, "steps_in_flight": D * M,
                        "parallelism": f"instances sharded over {world} GPU(s), no collective"},
-            "pipeline": {"depth": D, "what": "steps in flight per GPU: one solver handle + HIP stream + host thread each",
-                         "serial_ms_per_step": round(1e3 * serial_elapsed / args.steps, 3),
-                         "serial_trajectories_per_s": round(B * args.steps / serial_elapsed, 2),
-                         "lanes_bit_identical": same},
+            "pipeline": {"lanes": D, "merge": M, "steps_in_flight": D * M, "launch_sizes_in_steps": sorted(set(plan)),
+                         "what": "per GPU: `lanes` solver handles (HIP stream + host thread each), every launch of a lane "
+                                 "solves `merge` consecutive steps' batches (different grasp sets of the scene) at once",
+                         "serial_ms_per_step": None if args.merged_launches_only else round(1e3 * serial_elapsed / args.steps, 3),
+                         "serial_trajectories_per_s": None if args.merged_launches_only else round(B * args.steps / serial_elapsed, 2),
+                         "lanes_bit_identical": same, "merged_equals_single_batch_solves": merged_equals_single},
             "sqp_iters_per_s": round(iters_per_s, 1),
-            "host_api_trajectories_per_s": round(host_rate, 2),
+            "host_api_trajectories_per_s": None if host_rate is None else round(host_rate, 2),
             "iters_mean": round(float(iters.mean()), 2), "iters_max": int(iters.max()),
             "status_counts": {str(k): int((status == k).sum()) for k in np.unique(status)},
             "quality": {"max_joint_limit_violation": viol, "goal_err_pos_max_m": round(float(err_pos.max()), 5),

@@ -44,7 +44,7 @@ struct gto_handle {
   int dbg_cut = 0;
   size_t dbg_extra_lds = 0;  // GTO_DEBUG_EXTRA_LDS: occupancy experiments  // GTO_DEBUG_CUT: timing experiments only, results are garbage
   int n_groups = 1;
-  int obs_tg = 2;  // waypoints per workgroup of the obstacle kernel: two share the table staging, the FK barriers and the launch overhead
+  int obs_tg = 3;  // waypoints per workgroup of the obstacle kernel: they share the table staging, the FK barriers and the launch overhead
   long long* dbg = nullptr;
   hipStream_t gstream[GTO_MAX_GROUPS] = {nullptr};
   hipEvent_t ev_fork = nullptr, ev_join[GTO_MAX_GROUPS] = {nullptr};

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch.multiprocessing as mp
 
-from grasptrajopt_amd.parallel import BatchPipeline, shard_by_scene, shard_range
+from grasptrajopt_amd.parallel import BatchPipeline, merge_batches, shard_by_scene, shard_range, split_results
 
 
 def test_shard_range_partitions_everything():
@@ -59,6 +59,40 @@ def test_batch_pipeline_orders_results_and_reuses_handles():
     assert el < 0.9 * (6 * 0.05 + 6 * 0.01)  # batches overlapped
     with pytest.raises(ValueError):
         BatchPipeline([])
+
+
+def test_merged_batches_split_back_exactly(oracle_mod):
+    """Folding several batches into one solve_batch call (ragged goal sets, scalar and per-instance
+    arguments, different batch sizes) gives every batch exactly the result it gets alone: run on the oracle,
+    whose solve_batch has the SolverHandle signature."""
+    from helpers import Problem
+    probs = [Problem("panda", B=3, scene_seed=1, n=32, res=0.07, n_goals=2), Problem("panda", B=2, scene_seed=1, n=32, res=0.07),
+             Problem("panda", B=4, scene_seed=1, n=32, res=0.07, n_goals=3)]
+    o = oracle_mod.Oracle(probs[0].desc, probs[0].cfg["link_ee"], probs[0].cfg["link_gripper"], oracle_mod.reference_opts(max_iter=3))
+    for p in probs:
+        p.finish(o.eval_fk)
+    o.set_scene(*probs[0].scene_args())
+    batches = [(0, p.qc, p.goals, p.n_goals, p.S, p.base, p.Q0) for p in probs]
+    batches[1] = (np.zeros(2, np.int32), probs[1].qc, probs[1].goals, 1, np.tile(probs[1].S.reshape(1, 16), (2, 1)), probs[1].base[0], probs[1].Q0)
+    merged, sizes = merge_batches(batches)
+    assert sizes == [3, 2, 4] and merged[2].shape == (9, 3, 16) and merged[3].tolist() == [2] * 3 + [1] * 2 + [3] * 4
+    alone = [o.solve_batch(*b, n_threads=1) for b in batches]
+
+    class Lane:
+        def solve_batch(self, *a):
+            return o.solve_batch(*a, n_threads=1)
+
+    with BatchPipeline([Lane(), Lane()]) as pipe:
+        for merge in (1, 2, 3):
+            got = pipe.solve_batches(batches, merge=merge)
+            assert len(got) == 3
+            for a, b in zip(alone, got):
+                for x, y in zip(a, b):
+                    np.testing.assert_array_equal(x, y)
+    parts = split_results(o.solve_batch(*merged, n_threads=1), sizes)
+    np.testing.assert_array_equal(parts[2][0], alone[2][0])
+    with pytest.raises(ValueError):
+        merge_batches([batches[0], batches[1][:4] + (None,) + batches[1][5:]])
 
 
 def test_batch_pipeline_propagates_errors():
