@@ -32,11 +32,12 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s sp
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=96)
+    ap.add_argument("--steps", type=int, default=512)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="goal grasps (instances) per GPU per step")
     ap.add_argument("--pipeline", type=int, default=4, help="lanes per GPU: solver handles, each with its stream and host thread")
-    ap.add_argument("--merge", type=int, default=4, help="steps (batches) a lane folds into one launch; steps in flight = pipeline x merge")
+    ap.add_argument("--merge", type=int, default=32, help="steps (batches) a lane hands to the solver in one call; the solver keeps "
+                    "GTO_SLOTS (256) of their instances in flight and refills slots as instances finish")
     ap.add_argument("--max-iter", type=int, default=100, help="iteration cap (reference IPOPT cap: 100)")
     ap.add_argument("--robot", default="panda_5k")
     ap.add_argument("--grid", type=int, default=128)
@@ -83,6 +84,7 @@ def main():
     opts.max_iter = args.max_iter
     T, ndof, B = opts.T, desc.ndof, args.batch
     D, M = max(1, args.pipeline), max(1, args.merge)
+    slots = int(os.environ.get("GTO_SLOTS", "256"))  # instances a solver call keeps in flight (gto_api.hip)
 
     # this rank's shard of the global problem list: scene = global rank id, 64 grasps each
     lo, hi = shard_range(world * B, rank, world)
@@ -260,15 +262,15 @@ def main():
         tj = os.path.join(ROOT, "profiles", "traffic.json")
         if traffic is None and os.path.exists(tj):  # quoted only for the workload and launch size it was measured on
             tr = json.load(open(tj))
-            if (args.robot, args.grid, B * max(plan)) == (tr.get("robot"), tr.get("grid"), tr.get("instances_per_launch")):
+            if (args.robot, args.grid, B * max(plan), slots) == (tr.get("robot"), tr.get("grid"), tr.get("instances_per_call"), tr.get("slots")):
                 traffic = tr.get("k_obstacle_gram_hbm_bytes_per_launch")
         roofline = {"bound": "hbm", "kernel": "k_obstacle_gram", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "alg_bytes_per_launch": round(alg_bytes / max(kern_launches, 1)),
                     "avg_launch_us": round(avg_launch_us, 2), "launches": kern_launches,
-                    "instances_per_launch": B * max(plan),
-                    "measured": "HIP events on the launch stream over the K steps' launches (the timed region's launch size, one "
-                                "lane) run right after the timed region, so that launches of other lanes do not stretch the durations"}
+                    "instances_per_call": B * max(plan), "slots": slots,
+                    "measured": "HIP events on the launch stream around every launch of the kernel while ONE lane repeats the timed "
+                                "region's solver calls right after it, so that launches of other lanes do not stretch the durations"}
 
         cpu_baseline = None
         if not args.no_cpu_baseline:
@@ -305,11 +307,13 @@ def main():
                                     f"BASELINE configs[1]: Panda 7-DoF, 1 scene x {B} goal grasps per GPU, T={int(T)}, ") +
                                    f"{P} surface points, {args.grid}^3 f32 SDF cost field",
                        "batch_per_gpu": B, "T": int(T), "surface_points": int(P), "grid": args.grid,
-                       "max_iter": args.max_iter, "steps_in_flight": D * M,
+                       "max_iter": args.max_iter, "steps_per_call": M, "lanes": D,
                        "parallelism": f"instances sharded over {world} GPU(s), no collective"},
-            "pipeline": {"lanes": D, "merge": M, "steps_in_flight": D * M, "launch_sizes_in_steps": sorted(set(plan)),
-                         "what": "per GPU: `lanes` solver handles (HIP stream + host thread each), every launch of a lane "
-                                 "solves `merge` consecutive steps' batches (different grasp sets of the scene) at once",
+            "pipeline": {"lanes": D, "steps_per_call": M, "slots_per_lane": slots,
+                         "calls_in_steps": sorted(set(plan)),
+                         "what": "per GPU: `lanes` solver handles (HIP stream + host thread each); every solver call of a lane gets "
+                                 "`steps_per_call` consecutive steps' batches (different grasp sets of the scene) and keeps at most "
+                                 "`slots_per_lane` of their instances in flight, handing a finished instance's slot to the next",
                          "serial_ms_per_step": None if args.merged_launches_only else round(1e3 * serial_elapsed / args.steps, 3),
                          "serial_trajectories_per_s": None if args.merged_launches_only else round(B * args.steps / serial_elapsed, 2),
                          "lanes_bit_identical": same, "merged_equals_single_batch_solves": merged_equals_single},

@@ -37,7 +37,7 @@ struct gto_handle {
   SceneDev* d_scenes = nullptr;
   size_t d_scenes_cap = 0;
   // solve workspace (grown on demand)
-  DevBuf state, Qcur, Qtry, vis, screw, blocks, goalblk, ssfixed, ndone, qref, margin, qf;
+  DevBuf state, Qcur, Qtry, vis, screw, blocks, goalblk, ssfixed, ndone, qref, margin, qf, alist;
   int32_t* h_ndone = nullptr;  // pinned
   int check_every = 4;
   hipEvent_t ev_chk[2][GTO_MAX_GROUPS] = {{nullptr}};
@@ -57,6 +57,7 @@ struct gto_handle {
   int last_launches = 0;
   size_t lm_lds = 0;
   int base_lds_set = 0;
+  int slots = 256;  // instances in flight inside one solve call (GTO_SLOTS); a finished instance hands its slot to the next one
   bool ik_attr_set = false;
 };
 
@@ -154,6 +155,7 @@ int gto_create(const gto_robot_desc* d, const gto_solver_opts* opts, int device,
   if (const char* e = getenv("GTO_CHECK_EVERY")) h->check_every = atoi(e);
   if (const char* e = getenv("GTO_DEBUG_CUT")) h->dbg_cut = atoi(e);
   if (const char* e = getenv("GTO_DEBUG_EXTRA_LDS")) h->dbg_extra_lds = (size_t)atoi(e);
+  if (const char* e = getenv("GTO_SLOTS")) h->slots = std::max(1, atoi(e));
   if (const char* e = getenv("GTO_OBS_TG")) h->obs_tg = std::max(1, std::min(GTO_MAX_TG, atoi(e)));
   if (getenv("GTO_DEBUG_TIMING")) { (void)hipMalloc((void**)&h->dbg, 48 * sizeof(long long)); (void)hipMemset(h->dbg, 0, 48 * sizeof(long long)); }
   RobotDev& rb = h->rb;
@@ -425,7 +427,7 @@ void gto_destroy(gto_handle* h) {
   (void)hipFree(h->d_plink);
   (void)hipFree(h->d_perm);
   (void)hipFree(h->d_chunks);
-  DevBuf* bufs[] = {&h->state, &h->Qcur, &h->Qtry, &h->vis, &h->screw, &h->blocks, &h->goalblk, &h->ssfixed, &h->ndone, &h->qref, &h->margin, &h->qf};
+  DevBuf* bufs[] = {&h->state, &h->Qcur, &h->Qtry, &h->vis, &h->screw, &h->blocks, &h->goalblk, &h->ssfixed, &h->ndone, &h->qref, &h->margin, &h->qf, &h->alist};
   if (h->h_ndone) (void)hipHostFree(h->h_ndone);
   for (int g = 0; g < GTO_MAX_GROUPS; ++g) {
     if (h->gstream[g]) (void)hipStreamDestroy(h->gstream[g]);
@@ -663,6 +665,7 @@ static int ensure_workspace(gto_handle* h, int B) {
   if ((rc = ensure(h, h->ssfixed, (size_t)B * 4 * sizeof(double)))) return rc;
   if ((rc = ensure(h, h->ndone, 64))) return rc;
   if ((rc = ensure(h, h->qf, (size_t)B * T * rb.n_frames * sizeof(double)))) return rc;
+  if ((rc = ensure(h, h->alist, ((size_t)3 * B + 16) * sizeof(int32_t)))) return rc;
   if ((rc = ensure(h, h->qref, (size_t)B * T * GTO_MAX_OPT * sizeof(double)))) return rc;
   if ((rc = ensure(h, h->margin, (size_t)B * T * sizeof(int32_t)))) return rc;
   if (!h->h_ndone) HIPCHK(h, hipHostMalloc((void**)&h->h_ndone, 2 * GTO_MAX_GROUPS * sizeof(int32_t) + 64));
@@ -690,6 +693,10 @@ static BatchPtrs make_ptrs(gto_handle* h, const int32_t* scene_id, const double*
   bp.ss_fixed = (double*)h->ssfixed.p;
   bp.n_done = (int32_t*)h->ndone.p;
   bp.qf = (double*)h->qf.p;
+  bp.alist = nullptr;  // slots only exist inside the solve loop
+  bp.acount = nullptr;
+  bp.cap = 0;
+  bp.n_total = 0;
   bp.qref = (double*)h->qref.p;
   bp.margin = (int32_t*)h->margin.p;
   bp.dbg = h->dbg;
@@ -699,7 +706,7 @@ static BatchPtrs make_ptrs(gto_handle* h, const int32_t* scene_id, const double*
 static inline int obstacle_grid(int B, int nG) { return 8 * ((B + 7) / 8) * nG; }
 
 static int launch_obstacle(gto_handle* h, hipStream_t st, const BatchPtrs& bp, const SolveParams& sp, int B, int t_begin,
-                           int nT, int fixed_mode, bool timed, bool with_goal_terms = false) {
+                           int nT, int fixed_mode, bool timed, bool with_goal_terms = false, int lcur = 0, int n_slots = 0) {
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (timed) {
     size_t need = (size_t)(h->last_launches + 1) * 2;
@@ -715,12 +722,13 @@ static int launch_obstacle(gto_handle* h, hipStream_t st, const BatchPtrs& bp, c
   // waypoints per workgroup: groups of h->obs_tg (the two pinned waypoints form one group)
   const int TG = fixed_mode ? 1 : std::max(1, std::min(h->obs_tg, nT));  // the init pass has 4 virtual waypoints
   const int nG = (nT + TG - 1) / TG;
-  const int n_regular = obstacle_grid(B, nG);
+  const int nb = n_slots > 0 ? n_slots : B;  // workgroups are laid out for the slots in flight; B stays the batch (strides)
+  const int n_regular = obstacle_grid(nb, nG);
   const int cap_active = TG * h->rb.n_chunks;
   const ObsLds lay(TG, h->rb.n_frames, h->rb.n_links, cap_active);
   const size_t lds = (size_t)lay.total_doubles * sizeof(double) + h->dbg_extra_lds;
-  hipLaunchKernelGGL(k_obstacle_gram, dim3(n_regular + (with_goal_terms ? B : 0)), dim3(256), lds, st, h->d_rb, h->d_px, h->d_py,
-                     h->d_pz, h->d_chunks, h->d_scenes, bp, sp, B, t_begin, nT, fixed_mode, n_regular, TG, cap_active);
+  hipLaunchKernelGGL(k_obstacle_gram, dim3(n_regular + (with_goal_terms ? nb : 0)), dim3(256), lds, st, h->d_rb, h->d_px, h->d_py,
+                     h->d_pz, h->d_chunks, h->d_scenes, bp, sp, B, t_begin, nT, fixed_mode, n_regular, TG, cap_active, lcur);
   if (timed) {
     HIPCHK(h, hipEventRecord(e1, st));
     h->last_launches++;
@@ -761,6 +769,17 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
   int G = h->n_groups;
   while (G > 1 && B / G < 8) --G;
   if ((rc = ensure_group_streams(h, G))) return rc;
+  // Slots (one group only): at most W instances are in flight; an instance that finishes hands its slot to the
+  // next one that has not started (k_lm_step), so every round works on a full house until the batch runs out,
+  // instead of dragging the tail of its slowest instances through ever emptier rounds.
+  const bool slots_on = G == 1;
+  const int W = slots_on ? std::min(B, h->slots) : B;
+  if (slots_on) {
+    bp.alist = (int32_t*)h->alist.p;
+    bp.acount = bp.alist + 3 * (size_t)B;
+    bp.cap = W;
+    bp.n_total = B;
+  }
   struct Group {
     int off, n;
     BatchPtrs bp;
@@ -802,20 +821,24 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
   // one round = evaluate the trial trajectory (obstacle kernel) + accept/solve/new trial (step kernel);
   // instances that are done exit both kernels immediately
   int n_live = G, n_checks = 0;
-  for (int k = 0; k <= sp.max_iter && n_live > 0; ++k) {
+  // with slots an instance may start late: enough rounds for every slot to serve its share one after the other
+  const int max_rounds = slots_on ? ((B + W - 1) / W + 1) * (sp.max_iter + 2) : sp.max_iter;
+  for (int k = 0; k <= max_rounds && n_live > 0; ++k) {
     for (int g = 0; g < G; ++g) {
       Group& gr = grp[g];
       if (!gr.live) continue;
-      // round 0 evaluates the seed, whose goal terms k_lm_init already produced
-      if ((rc = launch_obstacle(h, gr.st, gr.bp, sp, gr.n, 2, T - 2, 0, h->profiling, k > 0))) return rc;
-      hipLaunchKernelGGL(k_lm_step, dim3(gr.n), dim3(256), h->lm_lds, gr.st, h->d_rb, gr.bp, sp, gr.n);
+      const int nb = slots_on ? W : gr.n, lcur = k % 3;
+      // round 0 evaluates the seed, whose goal terms k_lm_init already produced (with slots the goal
+      // workgroups skip fresh instances themselves)
+      if ((rc = launch_obstacle(h, gr.st, gr.bp, sp, gr.n, 2, T - 2, 0, h->profiling, slots_on || k > 0, lcur, nb))) return rc;
+      hipLaunchKernelGGL(k_lm_step, dim3(nb), dim3(256), h->lm_lds, gr.st, h->d_rb, gr.bp, sp, gr.n, lcur);
     }
     // Early exit.  Every few rounds the finished-instance counters are copied back (4 bytes) and an event
     // is recorded, but the host only LOOKS at the copy of the previous check: by then the GPU has long
     // passed that point, so the host never waits on the GPU's critical path and the queue never drains
     // (a blocking read-back every 8 rounds cost 25-30 us of idle GPU each).  The price is a few rounds of
     // empty launches after the last instance finishes.
-    if (h->check_every > 0 && (k % h->check_every) == h->check_every - 1 && k < sp.max_iter) {
+    if (h->check_every > 0 && (k % h->check_every) == h->check_every - 1 && k < max_rounds) {
       const int p = n_checks & 1;
       for (int g = 0; g < G; ++g) {
         if (!grp[g].live) continue;

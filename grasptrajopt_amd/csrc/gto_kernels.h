@@ -55,6 +55,13 @@ struct BatchPtrs {
   int32_t* n_done;   // [1]     instances that have finished
   double* qf;        // [B][T][F] joint value of every frame of the trial trajectory (0 for fixed joints)
   double* qref;      // [B][T][GTO_MAX_OPT] configuration at which `margin` was measured
+  // slots: the solve loop keeps at most `cap` instances in flight.  alist[r % 3] holds the ids the kernels of
+  // round r work on (acount[r % 3] of them); the step kernel appends to list (r+1) % 3 every instance that goes
+  // on, and for every instance that finishes the next id not yet started (acount[3] = next id, n_total ids in all).
+  // Null outside the solve loop: the kernels then index the batch directly.
+  int32_t* alist;    // [3][cap]
+  int32_t* acount;   // [4]
+  int32_t cap, n_total;
   int32_t* margin;   // [B][T] voxels of clearance left at qref when the whole waypoint was in free space, else -1
   long long* dbg;    // optional: phase timestamps of instance 0's step kernel (GTO_DEBUG_TIMING)
 };
@@ -640,19 +647,22 @@ __global__ void k_dist_relax(const uint8_t* __restrict__ in, uint8_t* __restrict
 //   main loop one link-uniform chunk of 64 Morton-sorted surface points per wave step (sparse wrench lists)
 //   epilogue  per-link 6x6 wrench Grams -> J^T J (n x n), J^T r (n), sum c^2 per waypoint
 struct ObsLds {  // dynamic LDS layout (offsets in doubles), computed identically on host and device
-  int vis, screw, gram, out, list, active, total_doubles;
+  int vis, screw, uni, gram, list, out, active, total_doubles;
   __host__ __device__ ObsLds(int TG, int F, int L, int cap_active) {
     int o = 0;
     vis = o;    o += TG * L * 12;
     screw = o;  o += TG * GTO_MAX_OPT * 6;
-    gram = o;   o += TG * L * GTO_GRAM;  // every (waypoint, link) is folded by exactly one wave
-    out = o;    o += TG * BLK_STRIDE;
-    // also, in the prologue: operand table, sin/cos [TG][F][2] and scratch of fk_mfma_tree; in the epilogue
-    // s_u; in the goal workgroups their scratch
+    // One region, two tenants.  Prologue: operand table, sin/cos [TG][F][2] and scratch of fk_mfma_tree (in the
+    // goal workgroups: their scratch).  After the kinematics: Gram accumulators, wrench lists, surviving chunks.
+    uni = o;
     const int fk = fk_tab_doubles(F, L, GTO_MAX_OPT) + TG * F * 2 + fk_scratch_doubles(F, TG);
-    list = o;   o += 4 * GTO_LIST_CAP * 8 > fk ? 4 * GTO_LIST_CAP * 8 : fk;
-    active = o; o += cap_active * 2;  // int4 per entry
-    total_doubles = o;
+    gram = o;   o += TG * L * GTO_GRAM;  // every (waypoint, link) is folded by exactly one wave
+    // wrench lists in the loop; in the epilogue s_u [L][GTO_MAX_OPT][6] and behind it the output blocks
+    const int lst = 4 * GTO_LIST_CAP * 8, epi = L * GTO_MAX_OPT * 6 + TG * BLK_STRIDE;
+    list = o;   o += lst > epi ? lst : epi;
+    out = list + L * GTO_MAX_OPT * 6;
+    active = o; o += cap_active;  // int2 per entry
+    total_doubles = (o - uni > fk ? o : uni + fk);
   }
 };
 
@@ -662,13 +672,13 @@ __device__ __forceinline__ void trial_goal_terms_wave(const RobotDev* rb, const 
                                              double* s_gaff, double* s_gscr);
 
 #ifndef GTO_OBS_MIN_WAVES
-#define GTO_OBS_MIN_WAVES 4  // waves per SIMD the register allocator must leave room for: four workgroups per CU (28 KB of LDS each)
+#define GTO_OBS_MIN_WAVES 5  // waves per SIMD the register allocator must leave room for: five workgroups per CU (31 KB of LDS each at three waypoints per workgroup)
 #endif
 __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const RobotDev* __restrict__ rb, const double* __restrict__ px,
                                                        const double* __restrict__ py, const double* __restrict__ pz,
                                                        const Chunk* __restrict__ chunks, const SceneDev* __restrict__ scenes,
                                                        BatchPtrs bp, SolveParams sp, int B, int t_begin, int nT,
-                                                       int fixed_mode, int n_regular, int TG, int cap_active) {
+                                                       int fixed_mode, int n_regular, int TG, int cap_active, int lcur) {
   extern __shared__ __attribute__((aligned(16))) double smem_obs[];
   __shared__ int s_wcount[4];
   __shared__ int s_nactive;
@@ -683,19 +693,24 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
   double* s_gram = smem_obs + lay.gram;
   double* s_out = smem_obs + lay.out;
   double* s_list = smem_obs + lay.list;
-  double* s_ktab = s_list;                      // prologue only
-  double* s_sc = s_list + fk_tab_doubles(F, L, n);  // prologue only
-  int4* s_active = reinterpret_cast<int4*>(smem_obs + lay.active);
+  double* s_ktab = smem_obs + lay.uni;          // prologue only
+  double* s_sc = s_ktab + fk_tab_doubles(F, L, n);  // prologue only
+  int2* s_active = reinterpret_cast<int2*>(smem_obs + lay.active);  // (link | waypoint << 16, start | count << 16)
   double* s_u = s_list;    // [L][GTO_MAX_OPT][6] in the epilogue
 
   // Extra workgroups (blockIdx >= n_regular), one per instance: goal-set terms and velocity term of the
   // trial trajectory.  The step kernel only needs them at its NEXT launch, so they ride in the shadow
   // of the obstacle evaluation instead of sitting on the serial path between two launches.
+  const bool listed = bp.alist != nullptr && !fixed_mode;  // solve loop: B = slots, the instance comes from this round's list
+  const int n_act = listed ? bp.acount[lcur] : B;
   if (bid >= n_regular) {
-    const int bg = bid - n_regular;
-    if (bg >= B || bp.state[bg].done) return;
+    const int gi_ = bid - n_regular;
+    if (gi_ >= n_act) return;
+    const int bg = listed ? bp.alist[lcur * bp.cap + gi_] : gi_;
+    // a fresh instance evaluates its seed, whose goal terms k_lm_init already produced
+    if (bp.state[bg].done || (listed && bp.state[bg].first)) return;
     if (tid < 64) {
-      double* s_fr2 = s_list;                          // [2][GTO_MAX_FRAMES*12] (list region is >= 2560 doubles)
+      double* s_fr2 = smem_obs + lay.uni;              // [2][GTO_MAX_FRAMES*12] (the region holds the FK table: > 976 doubles)
       double* s_q2 = s_fr2 + 2 * GTO_MAX_FRAMES * 12;  // [2][GTO_MAX_DOF]
       double* s_ga = s_q2 + 2 * GTO_MAX_DOF;           // [48]
       double* s_gs = s_ga + 48;                        // [2][GTO_MAX_OPT*6]
@@ -706,9 +721,10 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
   // blockIdx -> (instance, waypoint group), bijective, with b % 8 == blockIdx % 8
   const int nG = (nT + TG - 1) / TG;
   const int xcd = bid & 7, kb = bid >> 3;
-  const int b = (kb / nG) * 8 + xcd;
+  const int bi = (kb / nG) * 8 + xcd;
   const int grp_id = kb % nG;
-  if (b >= B) return;
+  if (bi >= n_act) return;
+  const int b = listed ? bp.alist[lcur * bp.cap + bi] : bi;
   const InstState* st = bp.state + b;
   // fixed mode evaluates four "virtual waypoints": 0,1 = the two pinned waypoints (all links, value only);
   // 2,3 = the links no optimised joint moves, under c_all and under c_obs (their sum of c^2 is the same
@@ -778,9 +794,7 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
     s_sc[2 * idx] = a;
     s_sc[2 * idx + 1] = c;
   }
-  for (int i = tid; i < ng * L * GTO_GRAM; i += 256) s_gram[i] = 0.0;
   if (tid < 4 * GTO_MAX_TG) (&s_ssw[0][0])[tid] = 0.0;
-  for (int i = tid; i < ng * BLK_STRIDE; i += 256) s_out[i] = 0.0;
   if (tid < GTO_MAX_TG) s_touched[tid] = 0u;
   if (tid == 0) s_nactive = 0;
   __syncthreads();
@@ -792,6 +806,9 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
                  dbg_wg ? bp.dbg + 20 : nullptr);
   }
   __syncthreads();
+  // the kinematics scratch is dead: its region now holds the Gram accumulators (the barriers of the broad
+  // phase separate this from their first use)
+  for (int i = tid; i < ng * L * GTO_GRAM; i += 256) s_gram[i] = 0.0;
   if (dbg_wg && tid == 0) bp.dbg[11] = clock64();
   if (sp.dbg_cut == 1) return;
 
@@ -811,11 +828,11 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
   for (int base_c = 0; base_c < ng * C; base_c += 256) {
     const int gi = base_c + tid;
     bool keep = false;
-    int4 desc4 = make_int4(0, 0, 0, 0);
+    int2 desc2 = make_int2(0, 0);
     if (gi < ng * C) {
       const int kq = gi / C, ci = gi % C;
       const Chunk cc = chunks[ci];
-      desc4 = make_int4(cc.link | (kq << 16), cc.start, cc.count, ci);
+      desc2 = make_int2(cc.link | (kq << 16), cc.start | (cc.count << 16));
       const bool is_static = cc.pad != 0;  // link not moved by any optimised joint
       const double* V = s_vis + (kq * L + cc.link) * 12;
       const double u0 = (V[0] * cc.cx + V[1] * cc.cy + V[2] * cc.cz + V[3] + bx - sc.ox) * sc.rinv;
@@ -849,7 +866,7 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
     for (int w = 0; w < wave; ++w) woff += s_wcount[w];
     if (keep) {
       const int pos = woff + __popcll(bm & ((1ull << lane) - 1ull));
-      if (pos < cap_active) s_active[pos] = desc4;
+      if (pos < cap_active) s_active[pos] = desc2;
     }
     __syncthreads();
     if (tid == 0) s_nactive = min(s_nactive + s_wcount[0] + s_wcount[1] + s_wcount[2] + s_wcount[3], cap_active);
@@ -947,8 +964,8 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
     float fval;    // field value (value-only mode)
   };
   auto load_chunk = [&](int c, ChunkLite& ch, double& x0, double& x1, double& x2) {
-    const int4 d4 = s_active[c];
-    ch = {d4.x, d4.y, d4.z};
+    const int2 d2 = s_active[c];
+    ch = {d2.x, d2.y & 0xffff, d2.y >> 16};
     x0 = x1 = x2 = 0.0;
     if (lane < ch.count) {
       x0 = px[ch.start + lane];
@@ -1057,6 +1074,9 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
 #undef GTO_DRAIN
   if (dbg_wg && tid == 0) bp.dbg[13] = clock64();
   if (sp.dbg_cut == 3) return;
+  __syncthreads();
+  // the wrench lists are dead: their region now holds s_u and, behind it, the output blocks
+  for (int i = tid; i < ng * BLK_STRIDE; i += 256) s_out[i] = 0.0;
   __syncthreads();
   // fold the four per-wave copies in wave order: the result does not depend on which wave ran first
   {
@@ -1381,6 +1401,13 @@ __global__ __launch_bounds__(256) void k_lm_init(const RobotDev* __restrict__ rb
     st->argmin_cur = 0;
   }
   for (int t = tid; t < T; t += 256) bp.margin[(size_t)b * T + t] = -1;
+  if (bp.alist && tid == 0) {  // the first `cap` instances take the slots; the rest wait for one to free up
+    if (b < bp.cap) bp.alist[b] = b;
+    if (b == 0) {
+      const int w = bp.cap < bp.n_total ? bp.cap : bp.n_total;
+      bp.acount[0] = w, bp.acount[1] = 0, bp.acount[2] = 0, bp.acount[3] = w;
+    }
+  }
   // seed: optimised rows of Q0, first two waypoints pinned to qc, the rest clipped into the bounds
   const double* Q0b = bp.Q0 + (size_t)b * rb->ndof * T;
   double* Qt = bp.Qtry + (size_t)b * n * T;
@@ -1453,8 +1480,14 @@ __device__ __forceinline__ double matvec8(double Z, double zc) {
 // One workgroup of four wavefronts per instance.  Lane (r,c) = (lane>>3, lane&7) of a wave owns entry
 // (r,c) of the 8x8 blocks; the data-parallel phases (assembly, projected step, predicted decrease) are
 // spread over the four waves by waypoint, the serial block recursion runs on wave 0.
-__global__ __launch_bounds__(256) void k_lm_step(const RobotDev* __restrict__ rb, BatchPtrs bp, SolveParams sp, int B) {
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+__global__ __launch_bounds__(256) void k_lm_step(const RobotDev* __restrict__ rb, BatchPtrs bp, SolveParams sp, int B, int lcur) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool listed = bp.alist != nullptr;
+  if (listed && blockIdx.x == 0 && tid == 0) bp.acount[(lcur + 2) % 3] = 0;  // the list the round after next appends to
+  if (listed && (int)blockIdx.x >= bp.acount[lcur]) return;
+  const int b = listed ? bp.alist[lcur * bp.cap + blockIdx.x] : blockIdx.x;
+  int32_t* const list_next = listed ? bp.alist + ((lcur + 1) % 3) * bp.cap : nullptr;
+  int32_t* const count_next = listed ? bp.acount + (lcur + 1) % 3 : nullptr;
   InstState* st = bp.state + b;
   if (st->done) return;
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -1587,6 +1620,10 @@ __global__ __launch_bounds__(256) void k_lm_step(const RobotDev* __restrict__ rb
       st->status = (STATUS);                      \
       st->argmin_cur = argmin_cur;                \
       atomicAdd(bp.n_done, 1);                    \
+      if (listed) { /* the freed slot takes the next instance that has not started yet */ \
+        const int nid = atomicAdd(bp.acount + 3, 1);                \
+        if (nid < bp.n_total) list_next[atomicAdd(count_next, 1)] = nid; \
+      }                                           \
     }                                             \
     return;                                       \
   } while (0)
@@ -1862,6 +1899,7 @@ __global__ __launch_bounds__(256) void k_lm_step(const RobotDev* __restrict__ rb
     st->status = status;
     st->evals = k + 1;
     st->argmin_cur = argmin_cur;
+    if (listed) list_next[atomicAdd(count_next, 1)] = b;  // keeps its slot
   }
 #undef GTO_FINISH
   if (bp.dbg && b == 0 && tid == 0) bp.dbg[7] = clock64();

@@ -228,6 +228,31 @@ def test_ragged_batches_and_scene_table(capi, oracle_mod):
     h.close()
 
 
+@pytest.mark.parametrize("slots", [1, 5, 8, 64])
+def test_slots_hand_over_to_waiting_instances(capi, oracle_mod, monkeypatch, slots):
+    """A solve call keeps at most GTO_SLOTS instances in flight; an instance that finishes hands its slot to
+    the next one that has not started.  Whatever the number of slots (fewer than, equal to, more than the batch),
+    every instance gets bit-for-bit the trajectory it gets with all instances in flight from the start, and the
+    oracle's iteration counts and status."""
+    prob = Problem("panda", B=13, scene_seed=2, n_goals=2)
+    h, o = make_pair(capi, oracle_mod, prob, max_iter=12)  # default: 256 slots, the whole batch in flight
+    ref = h.solve_batch(*prob.solve_args())
+    monkeypatch.setenv("GTO_SLOTS", str(slots))
+    h2 = capi.SolverHandle(prob.desc, prob.cfg["link_ee"], prob.cfg["link_gripper"], oracle_mod.reference_opts(max_iter=12), device=0)
+    h2.set_scene(*prob.scene_args())
+    for _ in range(2):  # the second call reuses the workspace and the lists of the first
+        got = h2.solve_batch(*prob.solve_args())
+        for a, b in zip(ref, got):
+            np.testing.assert_array_equal(a, b)
+    Qo, _, fo, ito, sto = o.solve_batch(*prob.solve_args())
+    np.testing.assert_array_equal(got[3], ito)
+    np.testing.assert_array_equal(got[4], sto)
+    np.testing.assert_allclose(got[0], Qo, rtol=0, atol=1e-7)
+    assert len(set(ito.tolist())) > 1  # instances finish at different rounds: slots are handed over mid-solve
+    h2.close()
+    h.close()
+
+
 def test_full_size_properties(capi, oracle_mod):
     """BASELINE.json configs[1] sizes (Panda, ~5k surface points, 128^3 field, 64 goals, T=50):
     too slow for the scalar oracle end-to-end, so checked through size-independent properties."""
