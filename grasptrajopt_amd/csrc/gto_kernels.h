@@ -657,10 +657,10 @@ struct ObsLds {  // dynamic LDS layout (offsets in doubles), computed identicall
     uni = o;
     const int fk = fk_tab_doubles(F, L, GTO_MAX_OPT) + TG * F * 2 + fk_scratch_doubles(F, TG);
     gram = o;   o += TG * L * GTO_GRAM;  // every (waypoint, link) is folded by exactly one wave
-    // wrench lists in the loop; in the epilogue s_u [L][GTO_MAX_OPT][6] and behind it the output blocks
-    const int lst = 4 * GTO_LIST_CAP * 8, epi = L * GTO_MAX_OPT * 6 + TG * BLK_STRIDE;
+    // wrench lists in the loop; in the epilogue s_u [TG][L][GTO_MAX_OPT][6] and behind it the output blocks
+    const int lst = 4 * GTO_LIST_CAP * 8, epi = TG * L * GTO_MAX_OPT * 6 + TG * BLK_STRIDE;
     list = o;   o += lst > epi ? lst : epi;
-    out = list + L * GTO_MAX_OPT * 6;
+    out = list + TG * L * GTO_MAX_OPT * 6;
     active = o; o += cap_active;  // int2 per entry
     total_doubles = (o - uni > fk ? o : uni + fk);
   }
@@ -696,7 +696,7 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
   double* s_ktab = smem_obs + lay.uni;          // prologue only
   double* s_sc = s_ktab + fk_tab_doubles(F, L, n);  // prologue only
   int2* s_active = reinterpret_cast<int2*>(smem_obs + lay.active);  // (link | waypoint << 16, start | count << 16)
-  double* s_u = s_list;    // [L][GTO_MAX_OPT][6] in the epilogue
+  double* s_u = s_list;    // [TG][L][GTO_MAX_OPT][6] in the epilogue
 
   // Extra workgroups (blockIdx >= n_regular), one per instance: goal-set terms and velocity term of the
   // trial trajectory.  The step kernel only needs them at its NEXT launch, so they ride in the shadow
@@ -1087,52 +1087,52 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
   // projection of the per-link wrench Grams onto the joint screws, over the links that were touched:
   //   JtJ[i][j] = sum_l [i,j in anc(l)] s_i^T W_l s_j ,  Jtr[i] = sum_l [i in anc(l)] s_i . v_l
   if (!fixed_mode) {
-    for (int kq = 0; kq < ng; ++kq) {
-      const unsigned touched = s_touched[kq];
-      if (!touched) continue;  // block-uniform
-      const double* gram = s_gram + kq * L * GTO_GRAM;
-      const double* screw = s_screw + kq * GTO_MAX_OPT * 6;
-      __syncthreads();  // s_u reuse between waypoints
-      for (int idx = tid; idx < L * n; idx += 256) {
-        const int l = idx / n, j = idx % n;
-        if (!((touched >> l) & 1u)) continue;
-        const double* W = gram + l * GTO_GRAM;
-        const double* sj = screw + 6 * j;
-        const bool on = (rb->link_anc[l] >> j) & 1u;
+    // all waypoints of the group at once: s_u [ng][L][GTO_MAX_OPT][6] in the dead list region
+    for (int idx = tid; idx < ng * L * n; idx += 256) {
+      const int kq = idx / (L * n), r_ = idx - kq * L * n, l = r_ / n, j = r_ - l * n;
+      if (!((s_touched[kq] >> l) & 1u)) continue;
+      const double* W = s_gram + (kq * L + l) * GTO_GRAM;
+      const double* sj = s_screw + kq * GTO_MAX_OPT * 6 + 6 * j;
+      const bool on = (rb->link_anc[l] >> j) & 1u;
 #pragma unroll
-        for (int r = 0; r < 6; ++r) {
-          double u = 0.0;
-          if (on) {
+      for (int r = 0; r < 6; ++r) {
+        double u = 0.0;
+        if (on) {
 #pragma unroll
-            for (int c = 0; c < 6; ++c) u += W[sym6(r, c)] * sj[c];
-          }
-          s_u[(l * GTO_MAX_OPT + j) * 6 + r] = u;
+          for (int c = 0; c < 6; ++c) u += W[sym6(r, c)] * sj[c];
         }
+        s_u[((kq * L + l) * GTO_MAX_OPT + j) * 6 + r] = u;
       }
-      __syncthreads();
-      // one thread per output entry, links summed in order (deterministic, no atomics)
-      if (tid < 64) {
-        const int i = tid >> 3, j = tid & 7;
+    }
+    __syncthreads();
+    // one thread per output entry, links summed in order (deterministic, no atomics)
+    for (int idx = tid; idx < ng * 72; idx += 256) {
+      const int kq = idx / 72, e = idx - kq * 72;
+      const unsigned touched = s_touched[kq];
+      if (!touched) continue;  // the block stays zero
+      const double* screw = s_screw + kq * GTO_MAX_OPT * 6;
+      if (e < 64) {
+        const int i = e >> 3, j = e & 7;
         double v = 0.0;
         if (i < n && j < n) {
           const double* si = screw + 6 * i;
           for (int l = 0; l < L; ++l) {
             const uint32_t anc = rb->link_anc[l];
             if (((touched >> l) & 1u) && ((anc >> i) & 1u) && ((anc >> j) & 1u)) {
-              const double* u = s_u + (l * GTO_MAX_OPT + j) * 6;
+              const double* u = s_u + ((kq * L + l) * GTO_MAX_OPT + j) * 6;
               v += si[0] * u[0] + si[1] * u[1] + si[2] * u[2] + si[3] * u[3] + si[4] * u[4] + si[5] * u[5];
             }
           }
         }
-        s_out[kq * BLK_STRIDE + BLK_JTJ + tid] = v;
-      } else if (tid < 72) {
-        const int i = tid - 64;
+        s_out[kq * BLK_STRIDE + BLK_JTJ + e] = v;
+      } else {
+        const int i = e - 64;
         double v = 0.0;
         if (i < n) {
           const double* si = screw + 6 * i;
           for (int l = 0; l < L; ++l)
             if (((touched >> l) & 1u) && ((rb->link_anc[l] >> i) & 1u)) {
-              const double* vv = gram + l * GTO_GRAM + 21;
+              const double* vv = s_gram + (kq * L + l) * GTO_GRAM + 21;
               v += si[0] * vv[0] + si[1] * vv[1] + si[2] * vv[2] + si[3] * vv[3] + si[4] * vv[4] + si[5] * vv[5];
             }
         }
