@@ -13,7 +13,6 @@
 #include "gto_kernels.h"
 
 #define GTO_VERSION 1000
-#define GTO_MAX_GROUPS 8
 
 static std::string g_create_error;
 
@@ -40,14 +39,11 @@ struct gto_handle {
   DevBuf state, Qcur, Qtry, vis, screw, blocks, goalblk, ssfixed, ndone, qref, margin, qf, alist;
   int32_t* h_ndone = nullptr;  // pinned
   int check_every = 4;
-  hipEvent_t ev_chk[2][GTO_MAX_GROUPS] = {{nullptr}};
+  hipEvent_t ev_chk[2] = {nullptr, nullptr};
   int dbg_cut = 0;
   size_t dbg_extra_lds = 0;  // GTO_DEBUG_EXTRA_LDS: occupancy experiments  // GTO_DEBUG_CUT: timing experiments only, results are garbage
-  int n_groups = 1;
   int obs_tg = 3;  // waypoints per workgroup of the obstacle kernel: they share the table staging, the FK barriers and the launch overhead
   long long* dbg = nullptr;
-  hipStream_t gstream[GTO_MAX_GROUPS] = {nullptr};
-  hipEvent_t ev_fork = nullptr, ev_join[GTO_MAX_GROUPS] = {nullptr};
   // staging for the host-pointer entry points
   DevBuf in[8], out[8];
   // profiling of the dominant kernel
@@ -151,7 +147,6 @@ int gto_create(const gto_robot_desc* d, const gto_solver_opts* opts, int device,
     (void)hipGetDevice(&h->device);
   }
   h->opts = *opts;
-  if (const char* e = getenv("GTO_GROUPS")) h->n_groups = std::max(1, std::min(GTO_MAX_GROUPS, atoi(e)));
   if (const char* e = getenv("GTO_CHECK_EVERY")) h->check_every = atoi(e);
   if (const char* e = getenv("GTO_DEBUG_CUT")) h->dbg_cut = atoi(e);
   if (const char* e = getenv("GTO_DEBUG_EXTRA_LDS")) h->dbg_extra_lds = (size_t)atoi(e);
@@ -429,13 +424,8 @@ void gto_destroy(gto_handle* h) {
   (void)hipFree(h->d_chunks);
   DevBuf* bufs[] = {&h->state, &h->Qcur, &h->Qtry, &h->vis, &h->screw, &h->blocks, &h->goalblk, &h->ssfixed, &h->ndone, &h->qref, &h->margin, &h->qf, &h->alist};
   if (h->h_ndone) (void)hipHostFree(h->h_ndone);
-  for (int g = 0; g < GTO_MAX_GROUPS; ++g) {
-    if (h->gstream[g]) (void)hipStreamDestroy(h->gstream[g]);
-    if (h->ev_join[g]) (void)hipEventDestroy(h->ev_join[g]);
-    for (int p = 0; p < 2; ++p)
-      if (h->ev_chk[p][g]) (void)hipEventDestroy(h->ev_chk[p][g]);
-  }
-  if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+  for (int p = 0; p < 2; ++p)
+    if (h->ev_chk[p]) (void)hipEventDestroy(h->ev_chk[p]);
   for (DevBuf* b : bufs) (void)hipFree(b->p);
   for (auto& b : h->in) (void)hipFree(b.p);
   for (auto& b : h->out) (void)hipFree(b.p);
@@ -624,15 +614,6 @@ int gto_last_kernel_time(gto_handle* h, double* total_ms, int32_t* launches) {
 }
 
 // -------------------------------------------------------------------------------------------------
-static int ensure_group_streams(gto_handle* h, int G) {
-  if (!h->ev_fork) HIPCHK(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-  for (int g = 0; g < G; ++g) {
-    if (!h->gstream[g]) HIPCHK(h, hipStreamCreateWithFlags(&h->gstream[g], hipStreamNonBlocking));
-    if (!h->ev_join[g]) HIPCHK(h, hipEventCreateWithFlags(&h->ev_join[g], hipEventDisableTiming));
-  }
-  return GTO_OK;
-}
-
 static SolveParams make_params(const gto_handle* h, int n_max, bool use_standoff) {
   const gto_solver_opts& o = h->opts;
   SolveParams sp;
@@ -668,10 +649,9 @@ static int ensure_workspace(gto_handle* h, int B) {
   if ((rc = ensure(h, h->alist, ((size_t)3 * B + 16) * sizeof(int32_t)))) return rc;
   if ((rc = ensure(h, h->qref, (size_t)B * T * GTO_MAX_OPT * sizeof(double)))) return rc;
   if ((rc = ensure(h, h->margin, (size_t)B * T * sizeof(int32_t)))) return rc;
-  if (!h->h_ndone) HIPCHK(h, hipHostMalloc((void**)&h->h_ndone, 2 * GTO_MAX_GROUPS * sizeof(int32_t) + 64));
+  if (!h->h_ndone) HIPCHK(h, hipHostMalloc((void**)&h->h_ndone, 64));
   for (int p = 0; p < 2; ++p)
-    for (int g = 0; g < GTO_MAX_GROUPS; ++g)
-      if (!h->ev_chk[p][g]) HIPCHK(h, hipEventCreateWithFlags(&h->ev_chk[p][g], hipEventDisableTiming));
+    if (!h->ev_chk[p]) HIPCHK(h, hipEventCreateWithFlags(&h->ev_chk[p], hipEventDisableTiming));
   return GTO_OK;
 }
 
@@ -763,114 +743,45 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
   h->last_ms = 0.0;
   if (h->dbg) HIPCHK(h, hipMemsetAsync(h->dbg + 40, 0, 8 * sizeof(long long), st));
 
-  // The batch is split into up to GTO_MAX_GROUPS independent groups, each with its own HIP stream: the
-  // step kernel of one group (latency-bound, few workgroups) overlaps the obstacle kernel of the
-  // others (throughput-bound), so neither phase leaves the GPU idle.  Groups share nothing.
-  int G = h->n_groups;
-  while (G > 1 && B / G < 8) --G;
-  if ((rc = ensure_group_streams(h, G))) return rc;
-  // Slots (one group only): at most W instances are in flight; an instance that finishes hands its slot to the
-  // next one that has not started (k_lm_step), so every round works on a full house until the batch runs out,
-  // instead of dragging the tail of its slowest instances through ever emptier rounds.
-  const bool slots_on = G == 1;
-  const int W = slots_on ? std::min(B, h->slots) : B;
-  if (slots_on) {
-    bp.alist = (int32_t*)h->alist.p;
-    bp.acount = bp.alist + 3 * (size_t)B;
-    bp.cap = W;
-    bp.n_total = B;
-  }
-  struct Group {
-    int off, n;
-    BatchPtrs bp;
-    hipStream_t st;
-    bool live;
-  } grp[GTO_MAX_GROUPS];
-  const size_t ndof = h->rb.ndof, nopt = h->rb.n_opt;
-  HIPCHK(h, hipMemsetAsync(bp.n_done, 0, GTO_MAX_GROUPS * sizeof(int32_t), st));
-  if (G > 1) HIPCHK(h, hipEventRecord(h->ev_fork, st));
-  for (int g = 0; g < G; ++g) {
-    Group& gr = grp[g];
-    gr.off = (int)(((long)B * g) / G);
-    gr.n = (int)(((long)B * (g + 1)) / G) - gr.off;
-    gr.st = (G == 1) ? st : h->gstream[g];
-    gr.live = true;
-    const size_t o = gr.off;
-    gr.bp = bp;
-    gr.bp.scene_id += o;
-    gr.bp.qc += o * ndof;
-    gr.bp.goals += o * n_max * 16;
-    gr.bp.n_goals += o;
-    if (gr.bp.standoff) gr.bp.standoff += o * 16;
-    gr.bp.base_pos += o * 3;
-    gr.bp.Q0 += o * ndof * T;
-    gr.bp.state += o;
-    gr.bp.Qcur += o * nopt * T;
-    gr.bp.Qtry += o * nopt * T;
-    gr.bp.blocks += 2 * o * T * BLK_STRIDE;  // the two slots of a group are contiguous: [2][n][T][..]
-    gr.bp.goalblk += 2 * o * 2 * BLK_STRIDE;
-    gr.bp.ss_fixed += o * 4;
-    gr.bp.n_done += g;
-    gr.bp.qf += o * T * h->rb.n_frames;
-    gr.bp.qref += o * T * GTO_MAX_OPT;
-    gr.bp.margin += o * T;
-    if (G > 1) HIPCHK(h, hipStreamWaitEvent(gr.st, h->ev_fork, 0));
-    hipLaunchKernelGGL(k_lm_init, dim3(gr.n), dim3(256), 0, gr.st, h->d_rb, gr.bp, sp, gr.n, 0);
-    if ((rc = launch_obstacle(h, gr.st, gr.bp, sp, gr.n, 0, 4, 1, false))) return rc;
-  }
-  // one round = evaluate the trial trajectory (obstacle kernel) + accept/solve/new trial (step kernel);
-  // instances that are done exit both kernels immediately
-  int n_live = G, n_checks = 0;
-  // with slots an instance may start late: enough rounds for every slot to serve its share one after the other
-  const int max_rounds = slots_on ? ((B + W - 1) / W + 1) * (sp.max_iter + 2) : sp.max_iter;
-  for (int k = 0; k <= max_rounds && n_live > 0; ++k) {
-    for (int g = 0; g < G; ++g) {
-      Group& gr = grp[g];
-      if (!gr.live) continue;
-      const int nb = slots_on ? W : gr.n, lcur = k % 3;
-      // round 0 evaluates the seed, whose goal terms k_lm_init already produced (with slots the goal
-      // workgroups skip fresh instances themselves)
-      if ((rc = launch_obstacle(h, gr.st, gr.bp, sp, gr.n, 2, T - 2, 0, h->profiling, slots_on || k > 0, lcur, nb))) return rc;
-      hipLaunchKernelGGL(k_lm_step, dim3(nb), dim3(256), h->lm_lds, gr.st, h->d_rb, gr.bp, sp, gr.n, lcur);
-    }
-    // Early exit.  Every few rounds the finished-instance counters are copied back (4 bytes) and an event
-    // is recorded, but the host only LOOKS at the copy of the previous check: by then the GPU has long
-    // passed that point, so the host never waits on the GPU's critical path and the queue never drains
-    // (a blocking read-back every 8 rounds cost 25-30 us of idle GPU each).  The price is a few rounds of
-    // empty launches after the last instance finishes.
+  // Slots: at most W instances are in flight; an instance that finishes hands its slot to the next one that has
+  // not started (k_lm_step), so every round works on a full house until the batch runs out, instead of
+  // dragging the tail of its slowest instances through ever emptier rounds.
+  const int W = std::min(B, h->slots);
+  bp.alist = (int32_t*)h->alist.p;
+  bp.acount = bp.alist + 3 * (size_t)B;
+  bp.cap = W;
+  bp.n_total = B;
+  const size_t ndof = h->rb.ndof;
+  HIPCHK(h, hipMemsetAsync(bp.n_done, 0, sizeof(int32_t), st));
+  hipLaunchKernelGGL(k_lm_init, dim3(B), dim3(256), 0, st, h->d_rb, bp, sp, B, 0);
+  if ((rc = launch_obstacle(h, st, bp, sp, B, 0, 4, 1, false))) return rc;
+  // one round = evaluate the trial trajectories of the slots (obstacle kernel) + accept/solve/new trial (step
+  // kernel).  An instance may start late: enough rounds for every slot to serve its share one after the other.
+  const int max_rounds = ((B + W - 1) / W + 1) * (sp.max_iter + 2);
+  int n_checks = 0;
+  bool live = true;
+  for (int k = 0; k <= max_rounds && live; ++k) {
+    const int lcur = k % 3;
+    // the goal workgroups skip fresh instances themselves: k_lm_init already produced the seed's goal terms
+    if ((rc = launch_obstacle(h, st, bp, sp, B, 2, T - 2, 0, h->profiling, true, lcur, W))) return rc;
+    hipLaunchKernelGGL(k_lm_step, dim3(W), dim3(256), h->lm_lds, st, h->d_rb, bp, sp, B, lcur);
+    // Early exit.  Every few rounds the finished-instance counter is copied back (4 bytes) and an event is
+    // recorded, but the host only LOOKS at the copy of the previous check: by then the GPU has long passed that
+    // point, so the host never waits on the GPU's critical path and the queue never drains (a blocking
+    // read-back every 8 rounds cost 25-30 us of idle GPU each).  The price is a few rounds of empty launches
+    // after the last instance finishes.
     if (h->check_every > 0 && (k % h->check_every) == h->check_every - 1 && k < max_rounds) {
       const int p = n_checks & 1;
-      for (int g = 0; g < G; ++g) {
-        if (!grp[g].live) continue;
-        HIPCHK(h, hipMemcpyAsync(h->h_ndone + p * GTO_MAX_GROUPS + g, grp[g].bp.n_done, sizeof(int32_t),
-                                 hipMemcpyDeviceToHost, grp[g].st));
-        HIPCHK(h, hipEventRecord(h->ev_chk[p][g], grp[g].st));
-      }
+      HIPCHK(h, hipMemcpyAsync(h->h_ndone + p, bp.n_done, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+      HIPCHK(h, hipEventRecord(h->ev_chk[p], st));
       if (n_checks > 0) {
-        for (int g = 0; g < G; ++g) {
-          if (!grp[g].live) continue;
-          HIPCHK(h, hipEventSynchronize(h->ev_chk[1 - p][g]));
-          if (h->h_ndone[(1 - p) * GTO_MAX_GROUPS + g] >= grp[g].n) {
-            grp[g].live = false;
-            --n_live;
-          }
-        }
+        HIPCHK(h, hipEventSynchronize(h->ev_chk[1 - p]));
+        if (h->h_ndone[1 - p] >= B) live = false;
       }
       ++n_checks;
     }
   }
-  for (int g = 0; g < G; ++g) {
-    Group& gr = grp[g];
-    const size_t o = gr.off;
-    hipLaunchKernelGGL(k_lm_finalize, dim3(gr.n), dim3(64), 0, gr.st, h->d_rb, gr.bp, sp, gr.n,
-                       Q_out ? Q_out + o * ndof * T : nullptr, dQ_out ? dQ_out + o * ndof * (T - 1) : nullptr,
-                       cost_out ? cost_out + o : nullptr, iters_out ? iters_out + o : nullptr,
-                       status_out ? status_out + o : nullptr);
-    if (G > 1) {
-      HIPCHK(h, hipEventRecord(h->ev_join[g], gr.st));
-      HIPCHK(h, hipStreamWaitEvent(st, h->ev_join[g], 0));
-    }
-  }
+  hipLaunchKernelGGL(k_lm_finalize, dim3(B), dim3(64), 0, st, h->d_rb, bp, sp, B, Q_out, dQ_out, cost_out, iters_out, status_out);
   HIPCHK(h, hipGetLastError());
   if (h->dbg) {
     HIPCHK(h, hipStreamSynchronize(st));
