@@ -45,7 +45,7 @@ def main():
     ap.add_argument("--merged-launches-only", action="store_true",
                     help="skip the one-batch-per-launch passes (serial latency, host API): every launch of the run then has the "
                          "timed region's size, which is what the per-launch PMC averages of tools/pmc_pass.sh need")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the CPU-baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=16.0, help="target duration of the CPU-baseline sample")
     ap.add_argument("--traffic", type=float, default=None,
                     help="HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes (see profiles/)")
     args = ap.parse_args()
@@ -278,7 +278,7 @@ def main():
             oracle.build()
             o = oracle.Oracle(desc, cfg["link_ee"], cfg["link_gripper"], opts, n_gripper_points=100)
             o.set_scene(0, sc.c_all, sc.c_obs, sc.shape, sc.origin, sc.res)
-            cores = o.num_threads()
+            cores = o.usable_cores()  # affinity mask capped by the cgroup CPU quota
             # pilot on the batch itself, then repeat it so the timed sample is ~10-20 s of CPU work
             tc = time.perf_counter()
             cq, cr, cs_, cb, c0 = qc[:B], RT[:B].reshape(B, 1, 16), S[:B], base[:B], Q0[:B]  # the first batch
@@ -290,11 +290,18 @@ def main():
             _, _, _, ito_all, _ = o.solve_batch(0, tile(cq), tile(cr), 1, tile(cs_), tile(cb), tile(c0), n_threads=cores)
             tcpu = time.perf_counter() - tc
             ns = B * reps
+            # one thread, a few instances: the per-core rate without the machine's other cores competing for memory
+            n1 = int(min(max(round(4.0 * (B / max(t_pilot, 1e-3)) / cores), 2), 8))
+            t1 = time.perf_counter()
+            o.solve_batch(0, cq[:n1], cr[:n1], 1, cs_[:n1], cb[:n1], c0[:n1], n_threads=1)
+            t1 = time.perf_counter() - t1
             cpu_baseline = {"value": round(ns / tcpu, 3), "unit": "trajectories/s", "cores": cores, "kind": "port",
                             "sample": f"{reps} x the {B} instances of this workload ({ns} solves), {tcpu:.1f} s, "
-                                      "OpenMP over instances, same algorithm in FP64 (oracle/gto_oracle.c)",
+                                      "OpenMP over instances, same algorithm in FP64 (oracle/gto_oracle.c); cores = CPUs this "
+                                      f"process may use (affinity and cgroup quota) of {os.cpu_count()} hardware threads on the host",
                             "iters_per_s": round(float(ito_all.sum()) / tcpu, 1),
                             "single_core_value": round(ns / tcpu / cores, 4),
+                            "single_thread": {"value": round(n1 / t1, 4), "sample": f"the first {n1} instances on one thread, {t1:.1f} s"},
                             "max_abs_dQ_vs_gpu": float(np.abs(Qo - Qsol[:B]).max()),
                             "iters_equal_gpu": bool(np.array_equal(ito, iters[:B]))}
 

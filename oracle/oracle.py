@@ -384,3 +384,27 @@ class Oracle:
     @staticmethod
     def num_threads():
         return lib().orc_num_threads()
+
+    @staticmethod
+    def usable_cores():
+        """CPUs this process may actually use: the affinity mask capped by the cgroup CPU quota (a container on a
+        256-thread host may be limited to 16 CPUs' worth of time: more OpenMP threads than that only add contention)."""
+        import math
+        n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        quota = None
+        try:
+            with open("/sys/fs/cgroup/cpu.max") as fh:  # cgroup v2: "<quota|max> <period>"
+                q, p = fh.read().split()
+                if q != "max":
+                    quota = float(q) / float(p)
+        except (OSError, ValueError):
+            try:
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as fq, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fp:
+                    q, p = float(fq.read()), float(fp.read())
+                    if q > 0:
+                        quota = q / p
+            except (OSError, ValueError):
+                pass
+        if quota is not None:
+            n = min(n, max(1, int(math.floor(quota))))
+        return max(1, n)

@@ -40,7 +40,7 @@ def main():
         t0 = time.perf_counter()
         yo, qo, co, io, so = orc.solve_base_batch(QC, goals, effort_weight=w)
         to = time.perf_counter() - t0
-        print(f"effort {w}: GPU {args.sets / tg:9.1f} sets/s  oracle {args.sets / to:8.1f} sets/s ({oracle.Oracle.num_threads()} threads)")
+        print(f"effort {w}: GPU {args.sets / tg:9.1f} sets/s  oracle {args.sets / to:8.1f} sets/s ({oracle.Oracle.usable_cores()} threads)")
         print(f"  max|dy| {np.abs(yg - yo).max():.3e}  max|dq| {np.abs(qg - qo).max():.3e}  max|dcost| {np.abs(cg - co).max():.3e}"
               f"  iters equal {np.array_equal(ig, io)} (mean {ig.mean():.1f}, max {ig.max()})  status equal {np.array_equal(sg, so)}")
         print("  y[0] gpu", yg[0], "oracle", yo[0], "planted", ystar[0], "cost", cg[0])
