@@ -170,10 +170,10 @@ def main():
     run_steps(pipe, args.warmup * D * M)  # every lane sees >= W warmup launches
     barrier()
     # ---- timed region: exactly K steps (batches), up to D x M of them in flight
-    t0 = time.perf_counter()
+    t0, c0 = time.perf_counter(), time.process_time()
     run_steps(pipe, args.steps)
     barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed, host_cpu = time.perf_counter() - t0, time.process_time() - c0
     pipe.close()
     merged_Q, merged_it = lanes[0].d_Q.clone(), lanes[0].d_it.clone()
     same = all(bool(torch.equal(l.d_Q, merged_Q)) and bool(torch.equal(l.d_it, merged_it)) for l in lanes[1:])
@@ -323,6 +323,7 @@ def main():
                                  "`slots_per_lane` of their instances in flight, handing a finished instance's slot to the next",
                          "serial_ms_per_step": None if args.merged_launches_only else round(1e3 * serial_elapsed / args.steps, 3),
                          "serial_trajectories_per_s": None if args.merged_launches_only else round(B * args.steps / serial_elapsed, 2),
+                         "host_cpu_cores_busy": round(host_cpu / elapsed, 2),
                          "lanes_bit_identical": same, "merged_equals_single_batch_solves": merged_equals_single},
             "sqp_iters_per_s": round(iters_per_s, 1),
             "host_api_trajectories_per_s": None if host_rate is None else round(host_rate, 2),

@@ -8,6 +8,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <chrono>
+#include <thread>
 #include <vector>
 
 #include "gto_kernels.h"
@@ -775,7 +777,14 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
       HIPCHK(h, hipMemcpyAsync(h->h_ndone + p, bp.n_done, sizeof(int32_t), hipMemcpyDeviceToHost, st));
       HIPCHK(h, hipEventRecord(h->ev_chk[p], st));
       if (n_checks > 0) {
-        HIPCHK(h, hipEventSynchronize(h->ev_chk[1 - p]));
+        // sleep-poll instead of hipEventSynchronize: the runtime spins there, one host core per lane, and a node
+        // with 8 GPUs x 4 lanes may not have 32 cores to burn; the check is four rounds old, 50 us do not matter
+        for (;;) {
+          const hipError_t qe = hipEventQuery(h->ev_chk[1 - p]);
+          if (qe == hipSuccess) break;
+          if (qe != hipErrorNotReady) HIPCHK(h, qe);
+          std::this_thread::sleep_for(std::chrono::microseconds(50));
+        }
         if (h->h_ndone[1 - p] >= B) live = false;
       }
       ++n_checks;
