@@ -38,7 +38,7 @@ struct gto_handle {
   SceneDev* d_scenes = nullptr;
   size_t d_scenes_cap = 0;
   // solve workspace (grown on demand)
-  DevBuf state, Qcur, Qtry, vis, screw, blocks, goalblk, ssfixed, ndone, qref, margin, qf, alist;
+  DevBuf state, Qcur, Qtry, vis, screw, blocks, goalblk, ssfixed, ndone, qref, margin, qf, slotbuf, qfs;
   int32_t* h_ndone = nullptr;  // pinned
   int check_every = 4;
   hipEvent_t ev_chk[2] = {nullptr, nullptr};
@@ -424,7 +424,7 @@ void gto_destroy(gto_handle* h) {
   (void)hipFree(h->d_plink);
   (void)hipFree(h->d_perm);
   (void)hipFree(h->d_chunks);
-  DevBuf* bufs[] = {&h->state, &h->Qcur, &h->Qtry, &h->vis, &h->screw, &h->blocks, &h->goalblk, &h->ssfixed, &h->ndone, &h->qref, &h->margin, &h->qf, &h->alist};
+  DevBuf* bufs[] = {&h->state, &h->Qcur, &h->Qtry, &h->vis, &h->screw, &h->blocks, &h->goalblk, &h->ssfixed, &h->ndone, &h->qref, &h->margin, &h->qf, &h->slotbuf, &h->qfs};
   if (h->h_ndone) (void)hipHostFree(h->h_ndone);
   for (int p = 0; p < 2; ++p)
     if (h->ev_chk[p]) (void)hipEventDestroy(h->ev_chk[p]);
@@ -648,7 +648,8 @@ static int ensure_workspace(gto_handle* h, int B) {
   if ((rc = ensure(h, h->ssfixed, (size_t)B * 4 * sizeof(double)))) return rc;
   if ((rc = ensure(h, h->ndone, 64))) return rc;
   if ((rc = ensure(h, h->qf, (size_t)B * T * rb.n_frames * sizeof(double)))) return rc;
-  if ((rc = ensure(h, h->alist, ((size_t)3 * B + 16) * sizeof(int32_t)))) return rc;
+  if ((rc = ensure(h, h->slotbuf, ((size_t)std::min(B, h->slots) + 16) * sizeof(int32_t)))) return rc;
+  if ((rc = ensure(h, h->qfs, (size_t)std::min(B, h->slots) * T * rb.n_frames * sizeof(double)))) return rc;
   if ((rc = ensure(h, h->qref, (size_t)B * T * GTO_MAX_OPT * sizeof(double)))) return rc;
   if ((rc = ensure(h, h->margin, (size_t)B * T * sizeof(int32_t)))) return rc;
   if (!h->h_ndone) HIPCHK(h, hipHostMalloc((void**)&h->h_ndone, 64));
@@ -675,8 +676,9 @@ static BatchPtrs make_ptrs(gto_handle* h, const int32_t* scene_id, const double*
   bp.ss_fixed = (double*)h->ssfixed.p;
   bp.n_done = (int32_t*)h->ndone.p;
   bp.qf = (double*)h->qf.p;
-  bp.alist = nullptr;  // slots only exist inside the solve loop
-  bp.acount = nullptr;
+  bp.slot_inst = nullptr;  // slots only exist inside the solve loop
+  bp.next = nullptr;
+  bp.qfs = nullptr;
   bp.cap = 0;
   bp.n_total = 0;
   bp.qref = (double*)h->qref.p;
@@ -688,7 +690,7 @@ static BatchPtrs make_ptrs(gto_handle* h, const int32_t* scene_id, const double*
 static inline int obstacle_grid(int B, int nG) { return 8 * ((B + 7) / 8) * nG; }
 
 static int launch_obstacle(gto_handle* h, hipStream_t st, const BatchPtrs& bp, const SolveParams& sp, int B, int t_begin,
-                           int nT, int fixed_mode, bool timed, bool with_goal_terms = false, int lcur = 0, int n_slots = 0) {
+                           int nT, int fixed_mode, bool timed, bool with_goal_terms = false, int n_slots = 0) {
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (timed) {
     size_t need = (size_t)(h->last_launches + 1) * 2;
@@ -710,7 +712,7 @@ static int launch_obstacle(gto_handle* h, hipStream_t st, const BatchPtrs& bp, c
   const ObsLds lay(TG, h->rb.n_frames, h->rb.n_links, cap_active);
   const size_t lds = (size_t)lay.total_doubles * sizeof(double) + h->dbg_extra_lds;
   hipLaunchKernelGGL(k_obstacle_gram, dim3(n_regular + (with_goal_terms ? nb : 0)), dim3(256), lds, st, h->d_rb, h->d_px, h->d_py,
-                     h->d_pz, h->d_chunks, h->d_scenes, bp, sp, B, t_begin, nT, fixed_mode, n_regular, TG, cap_active, lcur);
+                     h->d_pz, h->d_chunks, h->d_scenes, bp, sp, B, t_begin, nT, fixed_mode, n_regular, TG, cap_active);
   if (timed) {
     HIPCHK(h, hipEventRecord(e1, st));
     h->last_launches++;
@@ -749,8 +751,9 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
   // not started (k_lm_step), so every round works on a full house until the batch runs out, instead of
   // dragging the tail of its slowest instances through ever emptier rounds.
   const int W = std::min(B, h->slots);
-  bp.alist = (int32_t*)h->alist.p;
-  bp.acount = bp.alist + 3 * (size_t)B;
+  bp.slot_inst = (int32_t*)h->slotbuf.p;
+  bp.next = bp.slot_inst + W;
+  bp.qfs = (double*)h->qfs.p;
   bp.cap = W;
   bp.n_total = B;
   const size_t ndof = h->rb.ndof;
@@ -763,10 +766,9 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
   int n_checks = 0;
   bool live = true;
   for (int k = 0; k <= max_rounds && live; ++k) {
-    const int lcur = k % 3;
     // the goal workgroups skip fresh instances themselves: k_lm_init already produced the seed's goal terms
-    if ((rc = launch_obstacle(h, st, bp, sp, B, 2, T - 2, 0, h->profiling, true, lcur, W))) return rc;
-    hipLaunchKernelGGL(k_lm_step, dim3(W), dim3(256), h->lm_lds, st, h->d_rb, bp, sp, B, lcur);
+    if ((rc = launch_obstacle(h, st, bp, sp, B, 2, T - 2, 0, h->profiling, true, W))) return rc;
+    hipLaunchKernelGGL(k_lm_step, dim3(W), dim3(256), h->lm_lds, st, h->d_rb, bp, sp, B);
     // Early exit.  Every few rounds the finished-instance counter is copied back (4 bytes) and an event is
     // recorded, but the host only LOOKS at the copy of the previous check: by then the GPU has long passed that
     // point, so the host never waits on the GPU's critical path and the queue never drains (a blocking

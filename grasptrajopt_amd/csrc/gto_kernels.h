@@ -55,12 +55,14 @@ struct BatchPtrs {
   int32_t* n_done;   // [1]     instances that have finished
   double* qf;        // [B][T][F] joint value of every frame of the trial trajectory (0 for fixed joints)
   double* qref;      // [B][T][GTO_MAX_OPT] configuration at which `margin` was measured
-  // slots: the solve loop keeps at most `cap` instances in flight.  alist[r % 3] holds the ids the kernels of
-  // round r work on (acount[r % 3] of them); the step kernel appends to list (r+1) % 3 every instance that goes
-  // on, and for every instance that finishes the next id not yet started (acount[3] = next id, n_total ids in all).
-  // Null outside the solve loop: the kernels then index the batch directly.
-  int32_t* alist;    // [3][cap]
-  int32_t* acount;   // [4]
+  // slots: the solve loop keeps at most `cap` instances in flight.  slot_inst[i] is the instance slot i works on
+  // (-1: none left); the step kernel of a slot whose instance finishes puts the next instance that has not
+  // started into it (*next = id of that instance, n_total ids in all).  The joint values of the slot's trial
+  // trajectory live in qfs, indexed by slot, so that the obstacle kernel needs no instance id to start its
+  // kinematics.  Null outside the solve loop: the kernels then index the batch directly.
+  int32_t* slot_inst;  // [cap]
+  int32_t* next;       // [1]
+  double* qfs;         // [cap][T][F]
   int32_t cap, n_total;
   int32_t* margin;   // [B][T] voxels of clearance left at qref when the whole waypoint was in free space, else -1
   long long* dbg;    // optional: phase timestamps of instance 0's step kernel (GTO_DEBUG_TIMING)
@@ -678,7 +680,7 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
                                                        const double* __restrict__ py, const double* __restrict__ pz,
                                                        const Chunk* __restrict__ chunks, const SceneDev* __restrict__ scenes,
                                                        BatchPtrs bp, SolveParams sp, int B, int t_begin, int nT,
-                                                       int fixed_mode, int n_regular, int TG, int cap_active, int lcur) {
+                                                       int fixed_mode, int n_regular, int TG, int cap_active) {
   extern __shared__ __attribute__((aligned(16))) double smem_obs[];
   __shared__ int s_wcount[4];
   __shared__ int s_nactive;
@@ -701,12 +703,13 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
   // Extra workgroups (blockIdx >= n_regular), one per instance: goal-set terms and velocity term of the
   // trial trajectory.  The step kernel only needs them at its NEXT launch, so they ride in the shadow
   // of the obstacle evaluation instead of sitting on the serial path between two launches.
-  const bool listed = bp.alist != nullptr && !fixed_mode;  // solve loop: B = slots, the instance comes from this round's list
-  const int n_act = listed ? bp.acount[lcur] : B;
+  const bool listed = bp.slot_inst != nullptr && !fixed_mode;  // solve loop: workgroups are laid out over the slots
+  const int n_act = listed ? bp.cap : B;
   if (bid >= n_regular) {
     const int gi_ = bid - n_regular;
     if (gi_ >= n_act) return;
-    const int bg = listed ? bp.alist[lcur * bp.cap + gi_] : gi_;
+    const int bg = listed ? bp.slot_inst[gi_] : gi_;
+    if (bg < 0) return;  // empty slot
     // a fresh instance evaluates its seed, whose goal terms k_lm_init already produced
     if (bp.state[bg].done || (listed && bp.state[bg].first)) return;
     if (tid < 64) {
@@ -724,7 +727,8 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
   const int bi = (kb / nG) * 8 + xcd;
   const int grp_id = kb % nG;
   if (bi >= n_act) return;
-  const int b = listed ? bp.alist[lcur * bp.cap + bi] : bi;
+  const int b = listed ? bp.slot_inst[bi] : bi;
+  if (b < 0) return;  // empty slot
   const InstState* st = bp.state + b;
   // fixed mode evaluates four "virtual waypoints": 0,1 = the two pinned waypoints (all links, value only);
   // 2,3 = the links no optimised joint moves, under c_all and under c_obs (their sum of c^2 is the same
@@ -740,7 +744,7 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
   // of them: ONE memory round trip for the instance state, the culling inputs, the joint values of the
   // frames (bp.qf, written by the step kernel) and the operand table of fk_mfma_tree.
   if (sp.dbg_cut == 6) return;
-  const int done = st->done, slot_cur = st->slot;
+  const int done = listed ? 0 : st->done, slot_cur = st->slot;  // a slot never holds a finished instance
   const bool cull_try = TG == 1 && !fixed_mode;
   const int mg = cull_try ? bp.margin[(size_t)b * T + t0w] : -1;
   double dq_try = 0.0, dq_ref = 0.0;
@@ -748,7 +752,9 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
     dq_try = bp.Qtry[((size_t)b * n + tid) * T + t0w];
     dq_ref = bp.qref[((size_t)b * T + t0w) * GTO_MAX_OPT + tid];
   }
-  const double qfv = tid < ng * F ? bp.qf[((size_t)b * T + t0w) * F + tid] : 0.0;
+  // joint values of the group's waypoints: by slot in the solve loop (no dependence on the instance id)
+  const double* __restrict__ qfp = listed ? bp.qfs + ((size_t)bi * T + t0w) * F : bp.qf + ((size_t)b * T + t0w) * F;
+  const double qfv = tid < ng * F ? qfp[tid] : 0.0;
   const int jtv = tid < ng * F ? rb->joint_type[tid % F] : GTO_JOINT_FIXED;
   const int nt = fk_tab_doubles(F, L, n);  // rb->fk_tab is packed for exactly this (F, L, n)
   double tabv[6];
@@ -787,7 +793,7 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
   }
   for (int idx = tid + 256; idx < ng * F; idx += 256) {  // waypoint groups of very large robots
     const int jt = rb->joint_type[idx % F];
-    const double qv = bp.qf[((size_t)b * T + t0w) * F + idx];
+    const double qv = qfp[idx];
     double a = 0.0, c = 1.0;
     if (jt == GTO_JOINT_REVOLUTE) sincos(qv, &a, &c);
     else if (jt == GTO_JOINT_PRISMATIC) a = qv;
@@ -1401,12 +1407,9 @@ __global__ __launch_bounds__(256) void k_lm_init(const RobotDev* __restrict__ rb
     st->argmin_cur = 0;
   }
   for (int t = tid; t < T; t += 256) bp.margin[(size_t)b * T + t] = -1;
-  if (bp.alist && tid == 0) {  // the first `cap` instances take the slots; the rest wait for one to free up
-    if (b < bp.cap) bp.alist[b] = b;
-    if (b == 0) {
-      const int w = bp.cap < bp.n_total ? bp.cap : bp.n_total;
-      bp.acount[0] = w, bp.acount[1] = 0, bp.acount[2] = 0, bp.acount[3] = w;
-    }
+  if (bp.slot_inst && tid == 0) {  // the first `cap` instances take the slots; the rest wait for one to free up
+    if (b < bp.cap) bp.slot_inst[b] = b;
+    if (b == 0) *bp.next = bp.cap;
   }
   // seed: optimised rows of Q0, first two waypoints pinned to qc, the rest clipped into the bounds
   const double* Q0b = bp.Q0 + (size_t)b * rb->ndof * T;
@@ -1434,6 +1437,7 @@ __global__ __launch_bounds__(256) void k_lm_init(const RobotDev* __restrict__ rb
         v = j >= 0 ? Qt[(size_t)j * T + t] : Q0b[(size_t)dq * T + t];
       }
       qf[idx] = v;
+      if (bp.slot_inst && b < bp.cap) bp.qfs[(size_t)b * T * F + idx] = v;  // slot b starts with instance b
     }
   }
   if (tid < 64) trial_goal_terms_wave(rb, bp, sp, B, b, tid, 1, st, s_q, s_fr, s_gaff, s_gscr);
@@ -1480,14 +1484,13 @@ __device__ __forceinline__ double matvec8(double Z, double zc) {
 // One workgroup of four wavefronts per instance.  Lane (r,c) = (lane>>3, lane&7) of a wave owns entry
 // (r,c) of the 8x8 blocks; the data-parallel phases (assembly, projected step, predicted decrease) are
 // spread over the four waves by waypoint, the serial block recursion runs on wave 0.
-__global__ __launch_bounds__(256) void k_lm_step(const RobotDev* __restrict__ rb, BatchPtrs bp, SolveParams sp, int B, int lcur) {
+__global__ __launch_bounds__(256) void k_lm_step(const RobotDev* __restrict__ rb, BatchPtrs bp, SolveParams sp, int B) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool listed = bp.alist != nullptr;
-  if (listed && blockIdx.x == 0 && tid == 0) bp.acount[(lcur + 2) % 3] = 0;  // the list the round after next appends to
-  if (listed && (int)blockIdx.x >= bp.acount[lcur]) return;
-  const int b = listed ? bp.alist[lcur * bp.cap + blockIdx.x] : blockIdx.x;
-  int32_t* const list_next = listed ? bp.alist + ((lcur + 1) % 3) * bp.cap : nullptr;
-  int32_t* const count_next = listed ? bp.acount + (lcur + 1) % 3 : nullptr;
+  const bool listed = bp.slot_inst != nullptr;  // solve loop: one workgroup per slot
+  const int slot_id = blockIdx.x;
+  const int b = listed ? bp.slot_inst[slot_id] : slot_id;
+  if (b < 0) return;  // empty slot
+  __shared__ int s_nid;
   InstState* st = bp.state + b;
   if (st->done) return;
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -1510,7 +1513,7 @@ __global__ __launch_bounds__(256) void k_lm_step(const RobotDev* __restrict__ rb
   const int nF = rb->n_frames, my_frame = (tid & 7) < n ? rb->opt_frame[tid & 7] : 0;
   // ... and its limits: every (waypoint, joint) item of this thread has joint index tid & 7
   const double my_lo = (tid & 7) < n ? rb->lower[tid & 7] : 0.0, my_hi = (tid & 7) < n ? rb->upper[tid & 7] : 0.0;
-  double* __restrict__ qfb = bp.qf + (size_t)b * T * nF;
+  double* __restrict__ qfb = listed ? bp.qfs + (size_t)slot_id * T * nF : bp.qf + (size_t)b * T * nF;  // joint values of the trial, by frame
 
   // ---- P0: objective of the trial point (every wave computes it: cheaper than a broadcast)
   double fo = 0.0;
@@ -1621,9 +1624,17 @@ __global__ __launch_bounds__(256) void k_lm_step(const RobotDev* __restrict__ rb
       st->argmin_cur = argmin_cur;                \
       atomicAdd(bp.n_done, 1);                    \
       if (listed) { /* the freed slot takes the next instance that has not started yet */ \
-        const int nid = atomicAdd(bp.acount + 3, 1);                \
-        if (nid < bp.n_total) list_next[atomicAdd(count_next, 1)] = nid; \
+        const int nid = atomicAdd(bp.next, 1);    \
+        s_nid = nid < bp.n_total ? nid : -1;      \
+        bp.slot_inst[slot_id] = s_nid;            \
       }                                           \
+    }                                             \
+    if (listed) { /* ... and the joint values of its seed (k_lm_init left them in qf) */ \
+      __syncthreads();                            \
+      const int nid = s_nid;                      \
+      if (nid >= 0)                               \
+        for (int i_ = tid; i_ < sp.T * rb->n_frames; i_ += 256)     \
+          bp.qfs[(size_t)slot_id * sp.T * rb->n_frames + i_] = bp.qf[(size_t)nid * sp.T * rb->n_frames + i_]; \
     }                                             \
     return;                                       \
   } while (0)
@@ -1899,7 +1910,6 @@ __global__ __launch_bounds__(256) void k_lm_step(const RobotDev* __restrict__ rb
     st->status = status;
     st->evals = k + 1;
     st->argmin_cur = argmin_cur;
-    if (listed) list_next[atomicAdd(count_next, 1)] = b;  // keeps its slot
   }
 #undef GTO_FINISH
   if (bp.dbg && b == 0 && tid == 0) bp.dbg[7] = clock64();
