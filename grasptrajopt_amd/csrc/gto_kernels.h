@@ -1,15 +1,22 @@
 // gto_kernels.h — HIP kernels of the GTO inner solver for CDNA4 (gfx950, wave64).
 //
-//   k_obstacle_gram   the dominant kernel: one workgroup per (instance, waypoint); every lane owns
-//                     surface points: visual transform from LDS -> world point -> exact voxel index ->
-//                     nearest-voxel cost + 6 central-difference neighbours gathered from the f32 field
-//                     -> wrench (y x grad, grad) -> per-lane 6x6 Gram accumulation -> wave reduction
-//                     -> per-link LDS accumulators -> projection onto the joint screws -> J^T J, J^T r
-//   k_lm_init/k_lm_step  one wavefront per instance: accept/reject, bound active set, block-tridiagonal
-//                     solve, projected step, forward kinematics + goal-set terms of the new trial
+//   k_obstacle_gram   the dominant kernel: one workgroup per (slot, group of three waypoints).  Prologue: joint
+//                     values of the slot's trial -> forward kinematics as a parallel prefix over the kinematic
+//                     tree on the FP64 matrix cores (fk_mfma_tree).  Broad phase: bounding spheres of the 64-point
+//                     chunks against a Chebyshev distance field.  Loop over the surviving chunks: visual transform
+//                     from LDS -> world point -> exact voxel index -> ONE 32-B record (nearest-voxel cost + the three
+//                     central differences) -> wrench (y x grad, grad) appended to a per-wave list -> 6x6 Gram per
+//                     (waypoint, link) folded with v_mfma_f64_16x16x4.  Epilogue: projection onto the joint screws
+//                     -> J^T J, J^T r, sum c^2 per waypoint.  Extra workgroups: goal-set and velocity terms.
+//   k_lm_init/k_lm_step  one workgroup (four wavefronts) per instance / slot: accept/reject, bound active set,
+//                     block-tridiagonal solve from both ends, projected step, new trial; hands a finished instance's
+//                     slot to the next one of the call
 //   k_lm_finalize     assemble Q / dQ / cost / status
-// Roofline: HBM/L2-gather bound (28 B of field gathers per point-waypoint); MFMA is not
-// used: the only dense algebra is 7x7 blocks, <1 % of the flops.
+//   k_ik_solve, k_base_solve   whole Levenberg-Marquardt loops in one workgroup (IK pre-filter, base placement)
+//   k_depth_backproject, k_depth_sdf   cost field from a depth image
+// Bound: latency and instruction issue, not HBM or MFMA (DESIGN.md sections 5-6): the field of a scene is
+// L2-resident and the broad phase skips 97 % of the chunks; SURVEY.md 8d's algorithmic 28 B per point-waypoint
+// are what bench.py prices the kernel against.
 #pragma once
 #include "gto_device.h"
 
