@@ -1944,7 +1944,10 @@ __host__ __device__ inline int ik_lds_doubles(int F, int L, int n) {
          2 * 64 + 2 * 8 + 8 + 8 + 8 + GTO_MAX_DOF + 16;
 }
 
-__global__ __launch_bounds__(256) void k_ik_solve(const RobotDev* __restrict__ rb, const double* __restrict__ px,
+#ifndef GTO_IK_MIN_WAVES
+#define GTO_IK_MIN_WAVES 3  // measured: 1 wave/SIMD (254 VGPRs) 268 k IK/s with the collision term, 2 (248, no scratch) 387 k, 3 (168 VGPRs, 288 B scratch) 423 k
+#endif
+__global__ __launch_bounds__(256, GTO_IK_MIN_WAVES) void k_ik_solve(const RobotDev* __restrict__ rb, const double* __restrict__ px,
                                                   const double* __restrict__ py, const double* __restrict__ pz,
                                                   const Chunk* __restrict__ chunks, const SceneDev* __restrict__ scenes,
                                                   const int32_t* __restrict__ scene_id, const double* __restrict__ q0,
