@@ -711,7 +711,7 @@ static int launch_obstacle(gto_handle* h, hipStream_t st, const BatchPtrs& bp, c
   const int cap_active = TG * h->rb.n_chunks;
   const ObsLds lay(TG, h->rb.n_frames, h->rb.n_links, cap_active);
   const size_t lds = (size_t)lay.total_doubles * sizeof(double) + h->dbg_extra_lds;
-  hipLaunchKernelGGL(k_obstacle_gram, dim3(n_regular + (with_goal_terms ? nb : 0)), dim3(256), lds, st, h->d_rb, h->d_px, h->d_py,
+  hipLaunchKernelGGL(k_obstacle_gram, dim3(n_regular + (with_goal_terms ? (nb + 3) / 4 : 0)), dim3(256), lds, st, h->d_rb, h->d_px, h->d_py,
                      h->d_pz, h->d_chunks, h->d_scenes, bp, sp, B, t_begin, nT, fixed_mode, n_regular, TG, cap_active);
   if (timed) {
     HIPCHK(h, hipEventRecord(e1, st));

@@ -655,6 +655,7 @@ __global__ void k_dist_relax(const uint8_t* __restrict__ in, uint8_t* __restrict
 //             list of chunks that can touch a non-zero voxel
 //   main loop one link-uniform chunk of 64 Morton-sorted surface points per wave step (sparse wrench lists)
 //   epilogue  per-link 6x6 wrench Grams -> J^T J (n x n), J^T r (n), sum c^2 per waypoint
+#define GTO_GOAL_SCRATCH (2 * GTO_MAX_FRAMES * 12 + 2 * GTO_MAX_DOF + 48 + 2 * GTO_MAX_OPT * 6)  // doubles per goal wavefront
 struct ObsLds {  // dynamic LDS layout (offsets in doubles), computed identically on host and device
   int vis, screw, uni, gram, list, out, active, total_doubles;
   __host__ __device__ ObsLds(int TG, int F, int L, int cap_active) {
@@ -672,6 +673,7 @@ struct ObsLds {  // dynamic LDS layout (offsets in doubles), computed identicall
     out = list + TG * L * GTO_MAX_OPT * 6;
     active = o; o += cap_active;  // int2 per entry
     total_doubles = (o - uni > fk ? o : uni + fk);
+    if (total_doubles < 4 * GTO_GOAL_SCRATCH) total_doubles = 4 * GTO_GOAL_SCRATCH;  // the goal workgroups: four wavefronts
   }
 };
 
@@ -713,19 +715,19 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
   const bool listed = bp.slot_inst != nullptr && !fixed_mode;  // solve loop: workgroups are laid out over the slots
   const int n_act = listed ? bp.cap : B;
   if (bid >= n_regular) {
-    const int gi_ = bid - n_regular;
+    // four instances per workgroup, one per wavefront: a goal workgroup holds a whole workgroup's LDS and wave
+    // slots for one long serial job, so packing four of them into one costs a quarter of the slot time
+    const int gi_ = (bid - n_regular) * 4 + wave;
     if (gi_ >= n_act) return;
     const int bg = listed ? bp.slot_inst[gi_] : gi_;
     if (bg < 0) return;  // empty slot
     // a fresh instance evaluates its seed, whose goal terms k_lm_init already produced
     if (bp.state[bg].done || (listed && bp.state[bg].first)) return;
-    if (tid < 64) {
-      double* s_fr2 = smem_obs + lay.uni;              // [2][GTO_MAX_FRAMES*12] (the region holds the FK table: > 976 doubles)
-      double* s_q2 = s_fr2 + 2 * GTO_MAX_FRAMES * 12;  // [2][GTO_MAX_DOF]
-      double* s_ga = s_q2 + 2 * GTO_MAX_DOF;           // [48]
-      double* s_gs = s_ga + 48;                        // [2][GTO_MAX_OPT*6]
-      trial_goal_terms_wave(rb, bp, sp, B, bg, tid, 1 - bp.state[bg].slot, bp.state + bg, s_q2, s_fr2, s_ga, s_gs);
-    }
+    double* s_fr2 = smem_obs + wave * GTO_GOAL_SCRATCH;  // [2][GTO_MAX_FRAMES*12]
+    double* s_q2 = s_fr2 + 2 * GTO_MAX_FRAMES * 12;      // [2][GTO_MAX_DOF]
+    double* s_ga = s_q2 + 2 * GTO_MAX_DOF;               // [48]
+    double* s_gs = s_ga + 48;                            // [2][GTO_MAX_OPT*6]
+    trial_goal_terms_wave(rb, bp, sp, B, bg, lane, 1 - bp.state[bg].slot, bp.state + bg, s_q2, s_fr2, s_ga, s_gs);
     return;
   }
   // blockIdx -> (instance, waypoint group), bijective, with b % 8 == blockIdx % 8
