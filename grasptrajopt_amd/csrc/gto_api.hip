@@ -383,6 +383,7 @@ int gto_create(const gto_robot_desc* d, const gto_solver_opts* opts, int device,
             up((void**)&h->d_chunks, chunks.data(), chunks.size() * sizeof(Chunk));
   if (!ok) { gto_destroy(h); return fail(nullptr, GTO_ERR_ALLOC, "device allocation failed in gto_create"); }
   h->lm_lds = lm_lds_bytes(opts->T);
+  if (const char* e = getenv("GTO_DEBUG_STEP_EXTRA_LDS")) h->lm_lds += (size_t)atoi(e);  // occupancy experiments
   if (h->lm_lds > 160 * 1024) { gto_destroy(h); return fail(nullptr, GTO_ERR_UNSUPPORTED, "T too large for the step kernel's LDS"); }
   {
     const ObsLds lay(GTO_MAX_TG, rb.n_frames, rb.n_links, GTO_MAX_TG * rb.n_chunks);
