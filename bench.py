@@ -29,6 +29,17 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
+def plan_calls(n, lanes, merge):
+    """Split n steps (batches) into solver calls of at most `merge` batches, a multiple of `lanes` calls when n allows,
+    sizes within one of each other: every lane gets the same amount of work and exactly n steps are run."""
+    if n <= 0:
+        return []
+    L = max(-(-n // merge), min(n, lanes))
+    if L % lanes and n >= lanes * (L // lanes + 1):
+        L = lanes * (L // lanes + 1)
+    return [n // L + (1 if i < n % L else 0) for i in range(L)]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -153,13 +164,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    def launch_plan(n):
-        """Split n steps (batches) into launches of at most M batches, a multiple of D launches when n allows,
-        sizes within one of each other: every lane gets the same amount of work."""
-        L = max(-(-n // M), min(n, D))
-        if L % D and n >= D * (L // D + 1):
-            L = D * (L // D + 1)
-        return [n // L + (1 if i < n % L else 0) for i in range(L)]
+    launch_plan = lambda n: plan_calls(n, D, M)
 
     def run_steps(pipe, n):
         futs = [pipe.submit("step", m) for m in launch_plan(n)]

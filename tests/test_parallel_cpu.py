@@ -141,3 +141,24 @@ def test_two_rank_gloo_sharded_solve_equals_single_process(tmp_path, oracle_mod)
         np.testing.assert_array_equal(z["Q"], single["Q"])      # same code on every rank: bit-identical
         np.testing.assert_array_equal(z["cost"], single["cost"])
         np.testing.assert_array_equal(z["iters"], single["iters"])
+
+
+def test_bench_call_plan_times_exactly_k_steps():
+    """bench.py splits its K timed steps into solver calls: never more than `merge` batches per call, exactly K in
+    total, sizes within one of each other, a multiple of the lane count when K allows."""
+    import importlib.util
+    import pathlib
+    spec = importlib.util.spec_from_file_location("bench", pathlib.Path(__file__).resolve().parents[1] / "bench.py")
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for lanes in (1, 2, 4):
+        for merge in (1, 4, 32):
+            for n in list(range(0, 70)) + [96, 127, 128, 129, 512, 1000]:
+                plan = bench.plan_calls(n, lanes, merge)
+                assert sum(plan) == n and all(1 <= m <= merge for m in plan)
+                if plan:
+                    assert max(plan) - min(plan) <= 1
+                    if n >= lanes * merge:
+                        assert len(plan) % lanes == 0 or len(plan) == -(-n // merge)
+    assert bench.plan_calls(512, 4, 32) == [32] * 16
+    assert bench.plan_calls(5, 4, 32) == [2, 1, 1, 1]
