@@ -48,7 +48,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="goal grasps (instances) per GPU per step")
     ap.add_argument("--pipeline", type=int, default=4, help="lanes per GPU: solver handles, each with its stream and host thread")
     ap.add_argument("--merge", type=int, default=32, help="steps (batches) a lane hands to the solver in one call; the solver keeps "
-                    "GTO_SLOTS (256) of their instances in flight and refills slots as instances finish")
+                    "GTO_SLOTS (384) of their instances in flight and refills slots as instances finish")
     ap.add_argument("--max-iter", type=int, default=100, help="iteration cap (reference IPOPT cap: 100)")
     ap.add_argument("--robot", default="panda_5k")
     ap.add_argument("--grid", type=int, default=128)
@@ -95,7 +95,7 @@ def main():
     opts.max_iter = args.max_iter
     T, ndof, B = opts.T, desc.ndof, args.batch
     D, M = max(1, args.pipeline), max(1, args.merge)
-    slots = int(os.environ.get("GTO_SLOTS", "256"))  # instances a solver call keeps in flight (gto_api.hip)
+    slots = int(os.environ.get("GTO_SLOTS", "384"))  # instances a solver call keeps in flight (gto_api.hip)
 
     # this rank's shard of the global problem list: scene = global rank id, 64 grasps each
     lo, hi = shard_range(world * B, rank, world)

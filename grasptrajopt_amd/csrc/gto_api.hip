@@ -55,7 +55,7 @@ struct gto_handle {
   int last_launches = 0;
   size_t lm_lds = 0;
   int base_lds_set = 0;
-  int slots = 256;  // instances in flight inside one solve call (GTO_SLOTS); a finished instance hands its slot to the next one
+  int slots = 384;  // instances in flight inside one solve call (GTO_SLOTS); a finished instance hands its slot to the next one
   bool ik_attr_set = false;
 };
 

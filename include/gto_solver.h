@@ -148,7 +148,7 @@ int gto_drop_scene(gto_handle* h, int32_t scene_id);
  * Outputs (any may be NULL):
  *   Q_out [B, ndof, T], dQ_out [B, ndof, T-1], cost_out [B] (objective f, Appendix A of SURVEY.md),
  *   iters_out [B], status_out [B] (GTO_STATUS_*).
- * B may be as large as the caller has work: the solver keeps at most 256 instances in flight (environment
+ * B may be as large as the caller has work: the solver keeps at most 384 instances in flight (environment
  * GTO_SLOTS when the handle is created) and hands the slot of an instance that finishes to the next one that
  * has not started, so large calls keep the GPU full to the end; every instance gets bit for bit the result it
  * gets in a call of its own.  Device workspace: ~75 KB per instance of the call.
