@@ -44,6 +44,8 @@ struct gto_handle {
   hipEvent_t ev_chk[2] = {nullptr, nullptr};
   int dbg_cut = 0;
   size_t dbg_extra_lds = 0;  // GTO_DEBUG_EXTRA_LDS: occupancy experiments  // GTO_DEBUG_CUT: timing experiments only, results are garbage
+  int obs_tg_few = 2;  // ... when few instances are in flight (one small batch, the tail of a call): lower latency per round; results do not depend on the group size
+  int few_instances = 64;
   int obs_tg = 3;  // waypoints per workgroup of the obstacle kernel: they share the table staging, the FK barriers and the launch overhead
   long long* dbg = nullptr;
   // staging for the host-pointer entry points
@@ -153,7 +155,9 @@ int gto_create(const gto_robot_desc* d, const gto_solver_opts* opts, int device,
   if (const char* e = getenv("GTO_DEBUG_CUT")) h->dbg_cut = atoi(e);
   if (const char* e = getenv("GTO_DEBUG_EXTRA_LDS")) h->dbg_extra_lds = (size_t)atoi(e);
   if (const char* e = getenv("GTO_SLOTS")) h->slots = std::max(1, atoi(e));
-  if (const char* e = getenv("GTO_OBS_TG")) h->obs_tg = std::max(1, std::min(GTO_MAX_TG, atoi(e)));
+  if (const char* e = getenv("GTO_OBS_TG")) h->obs_tg = h->obs_tg_few = std::max(1, std::min(GTO_MAX_TG, atoi(e)));
+  if (const char* e = getenv("GTO_OBS_TG_FEW")) h->obs_tg_few = std::max(1, std::min(GTO_MAX_TG, atoi(e)));
+  if (const char* e = getenv("GTO_FEW_INSTANCES")) h->few_instances = atoi(e);
   if (getenv("GTO_DEBUG_TIMING")) { (void)hipMalloc((void**)&h->dbg, 48 * sizeof(long long)); (void)hipMemset(h->dbg, 0, 48 * sizeof(long long)); }
   RobotDev& rb = h->rb;
   memset(&rb, 0, sizeof rb);
@@ -691,7 +695,7 @@ static BatchPtrs make_ptrs(gto_handle* h, const int32_t* scene_id, const double*
 static inline int obstacle_grid(int B, int nG) { return 8 * ((B + 7) / 8) * nG; }
 
 static int launch_obstacle(gto_handle* h, hipStream_t st, const BatchPtrs& bp, const SolveParams& sp, int B, int t_begin,
-                           int nT, int fixed_mode, bool timed, bool with_goal_terms = false, int n_slots = 0) {
+                           int nT, int fixed_mode, bool timed, bool with_goal_terms = false, int n_slots = 0, int tg = 0) {
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (timed) {
     size_t need = (size_t)(h->last_launches + 1) * 2;
@@ -705,7 +709,7 @@ static int launch_obstacle(gto_handle* h, hipStream_t st, const BatchPtrs& bp, c
     HIPCHK(h, hipEventRecord(e0, st));
   }
   // waypoints per workgroup: groups of h->obs_tg (the two pinned waypoints form one group)
-  const int TG = fixed_mode ? 1 : std::max(1, std::min(h->obs_tg, nT));  // the init pass has 4 virtual waypoints
+  const int TG = fixed_mode ? 1 : std::max(1, std::min(tg > 0 ? tg : h->obs_tg, nT));  // the init pass has 4 virtual waypoints
   const int nG = (nT + TG - 1) / TG;
   const int nb = n_slots > 0 ? n_slots : B;  // workgroups are laid out for the slots in flight; B stays the batch (strides)
   const int n_regular = obstacle_grid(nb, nG);
@@ -764,11 +768,14 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
   // one round = evaluate the trial trajectories of the slots (obstacle kernel) + accept/solve/new trial (step
   // kernel).  An instance may start late: enough rounds for every slot to serve its share one after the other.
   const int max_rounds = ((B + W - 1) / W + 1) * (sp.max_iter + 2);
-  int n_checks = 0;
+  int n_checks = 0, known_done = 0;
   bool live = true;
   for (int k = 0; k <= max_rounds && live; ++k) {
     // the goal workgroups skip fresh instances themselves: k_lm_init already produced the seed's goal terms
-    if ((rc = launch_obstacle(h, st, bp, sp, B, 2, T - 2, 0, h->profiling, true, W))) return rc;
+    // instances in flight, as far as the host knows (the finished-counter it has seen is a few rounds old)
+    const int in_flight = std::min(W, B - known_done);
+    const int tg = in_flight <= h->few_instances ? h->obs_tg_few : h->obs_tg;
+    if ((rc = launch_obstacle(h, st, bp, sp, B, 2, T - 2, 0, h->profiling, true, W, tg))) return rc;
     hipLaunchKernelGGL(k_lm_step, dim3(W), dim3(256), h->lm_lds, st, h->d_rb, bp, sp, B);
     // Early exit.  Every few rounds the finished-instance counter is copied back (4 bytes) and an event is
     // recorded, but the host only LOOKS at the copy of the previous check: by then the GPU has long passed that
@@ -788,7 +795,8 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
           if (qe != hipErrorNotReady) HIPCHK(h, qe);
           std::this_thread::sleep_for(std::chrono::microseconds(50));
         }
-        if (h->h_ndone[1 - p] >= B) live = false;
+        known_done = h->h_ndone[1 - p];
+        if (known_done >= B) live = false;
       }
       ++n_checks;
     }

@@ -694,7 +694,6 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
   __shared__ int s_wcount[4];
   __shared__ int s_nactive;
   __shared__ unsigned s_touched[GTO_MAX_TG];  // per waypoint of the group: links whose Gram got a contribution
-  __shared__ double s_ssw[4][GTO_MAX_TG];     // per wave: sum of c^2 of each waypoint of the group
 
   const int bid = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int L = rb->n_links, n = rb->n_opt, T = sp.T, ndof = rb->ndof, F = rb->n_frames;
@@ -809,7 +808,6 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
     s_sc[2 * idx] = a;
     s_sc[2 * idx + 1] = c;
   }
-  if (tid < 4 * GTO_MAX_TG) (&s_ssw[0][0])[tid] = 0.0;
   if (tid < GTO_MAX_TG) s_touched[tid] = 0u;
   if (tid == 0) s_nactive = 0;
   __syncthreads();
@@ -926,7 +924,8 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
   double* gram_w = s_gram;
   const int mcol = lane & 15, mrow = lane >> 4;                // D column; D rows mrow (reg 0) and mrow + 4 (reg 1)
   // packed Gram index of D entry (row, col), row <= col < 7: 21 wrench-Gram entries, then c * wrench (6), then c^2
-  auto gram_index = [](int row, int col) { return col < 6 ? sym6(row, col) : (row < 6 ? 21 + row : 27); };
+  // (the c^2 corner of the fold is not kept: slot 27 of a key holds the sum of c^2 over ALL its points, below)
+  auto gram_index = [](int row, int col) { return col < 6 ? sym6(row, col) : (row < 6 ? 21 + row : -1); };
   const int gk0 = (mrow <= mcol && mcol < 7) ? gram_index(mrow, mcol) : -1;
   const int gk1 = (mrow + 4 <= mcol && mcol < 7) ? gram_index(mrow + 4, mcol) : -1;
   gto_v4f64 gD = {0.0, 0.0, 0.0, 0.0};
@@ -956,15 +955,12 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
     if (w1_) gdst_[gk1] += gD[1];                                                            \
     if (__ballot(w0_ || w1_) && lane == 0) atomicOr(&s_touched[fk_], 1u << fl_);             \
     gD = gto_v4f64{0.0, 0.0, 0.0, 0.0};                                                      \
-  } while (0)
-  // the sum of c^2 belongs to the waypoint, not to the link: it is only reduced when the waypoint changes
-#define GTO_FLUSH_SS(kq_)                                                                    \
-  do {                                                                                       \
+    /* sum of c^2 of the key: reduced per key, summed over the links in link order in the epilogue, so the  \
+       value does not depend on how the chunks were dealt to the waves (nor on the group size) */ \
     const double sw_ = wave_sum(ss);                                                         \
-    if (lane == 0) s_ssw[wave][kq_] += sw_;                                                  \
+    if (lane == 0) gdst_[27] += sw_;                                                         \
     ss = 0.0;                                                                                \
   } while (0)
-
   // Two-stage software pipeline over the wave's chunks.  Stage A of chunk c+1 (transform, voxel index,
   // ISSUE of the 32-B record gather) runs before stage B of chunk c (consume the record, append wrenches),
   // and the point coordinates of chunk c+2 are requested before that: three memory round trips (points,
@@ -1044,7 +1040,6 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
     if (cur.key != cur_key) {
       if (cur_key >= 0) {
         GTO_FLUSH(cur_key);
-        if ((cur_key >> 16) != (cur.key >> 16)) GTO_FLUSH_SS(cur_key >> 16);
       }
       cur_key = cur.key;
     }
@@ -1082,9 +1077,7 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
   }
   if (cur_key >= 0) {
     GTO_FLUSH(cur_key);
-    GTO_FLUSH_SS(cur_key >> 16);
   }
-#undef GTO_FLUSH_SS
 #undef GTO_FLUSH
 #undef GTO_DRAIN
   if (dbg_wg && tid == 0) bp.dbg[13] = clock64();
@@ -1093,9 +1086,11 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
   // the wrench lists are dead: their region now holds s_u and, behind it, the output blocks
   for (int i = tid; i < ng * BLK_STRIDE; i += 256) s_out[i] = 0.0;
   __syncthreads();
-  // fold the four per-wave copies in wave order: the result does not depend on which wave ran first
-  {
-    if (tid < ng) s_out[tid * BLK_STRIDE + BLK_SS] = ((s_ssw[0][tid] + s_ssw[1][tid]) + s_ssw[2][tid]) + s_ssw[3][tid];
+  // sum of c^2 per waypoint: its keys in link order
+  if (tid < ng) {
+    double v = 0.0;
+    for (int l = 0; l < L; ++l) v += s_gram[(tid * L + l) * GTO_GRAM + 27];
+    s_out[tid * BLK_STRIDE + BLK_SS] = v;
   }
   __syncthreads();
 
