@@ -9,11 +9,16 @@
  *   - building blocks (FK, visual transforms, voxel offsets, SDF value / Jacobian / Hessian,
  *     cost map, seed interpolation) are PINNED against golden vectors produced by executing the
  *     reference's own Python numerics in this container (tests/golden/make_golden.py);
- *   - the assembled objective f(x,p) and the solver iteration are "parity unpinned" against the
- *     reference: CasADi/IPOPT cannot run here and the reference holds no test or stored input
- *     for them.  They restate SURVEY.md Appendix A term by term, are checked
- *     against the pinned building blocks, finite differences and the structural invariants of
- *     the 853 stored plans, and define the algorithm the HIP path must reproduce.
+ *   - the ASSEMBLED OBJECTIVES (trajectory: goal-set + standoff, obstacle, velocity terms and the arg-min goal;
+ *     IK; base placement), the seed construction / scoring / selection and the parameter marshalling are PINNED
+ *     (<= 1e-12 relative) against tests/golden/objective.npz, produced by executing the reference's own
+ *     setup_optimization / plan / plan_goalset code (gto/gto_planner.py:42-245, gto/ik_solver.py:30-76,
+ *     gto/base_planner.py:35-93) with numeric stand-ins for the CasADi layer
+ *     (tests/golden/make_objective_golden.py);
+ *   - "parity unpinned": the solver ITERATION only.  IPOPT cannot run here and the reference stores no
+ *     input for any of its 853 plans; the projected Levenberg-Marquardt iteration below is
+ *     checked against finite differences, the structural invariants of the stored plans and solution-quality
+ *     gates, and defines the algorithm the HIP path must reproduce.
  *
  * Every function cites the reference file:line it follows (paths under /root/reference).
  */
@@ -1408,6 +1413,24 @@ int orc_solve_base_batch(const gto_robot_desc* d, const gto_solver_opts* o, int3
     solve_base_instance(d, o, n_goals[b], n_max, qc + (size_t)b * d->ndof, goals + (size_t)b * n_max * 16, w_effort, max_iter,
                         y_out + 3 * (size_t)b, q_out + (size_t)b * n_max * d->ndof, cost_out ? cost_out + b : NULL,
                         iters_out ? iters_out + b : NULL, status_out ? status_out + b : NULL);
+  return GTO_OK;
+}
+
+/* Base-placement objective at a given point (same contract as gto_eval_base_objective): y [B][3],
+ * q [B][n_max][ndof] one arm configuration per goal (parameter joints taken from row 0), goals [B][n_max][16]. */
+int orc_eval_base_objective(const gto_robot_desc* d, int32_t B, int32_t n_max, const int32_t* n_goals, const double* y,
+                            const double* q, const double* goals, double w_effort, double* cost_out) {
+  if (d->n_opt > NMAX || n_max < 1) return GTO_ERR_UNSUPPORTED;
+  const int n = d->n_opt;
+  double* z = (double*)malloc(sizeof(double) * (3 + (size_t)n * n_max));
+  for (int b = 0; b < B; ++b) {
+    const double* qb = q + (size_t)b * n_max * d->ndof;
+    for (int a = 0; a < 3; ++a) z[a] = y[3 * (size_t)b + a];
+    for (int i = 0; i < n_goals[b]; ++i)
+      for (int j = 0; j < n; ++j) z[3 + i * n + j] = qb[(size_t)i * d->ndof + d->opt_index[j]];
+    base_evaluate(d, n_goals[b], z, qb, goals + (size_t)b * n_max * 16, w_effort, 0, cost_out + b, NULL, NULL);
+  }
+  free(z);
   return GTO_OK;
 }
 

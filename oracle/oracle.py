@@ -329,6 +329,25 @@ class Oracle:
             raise RuntimeError(f"orc_solve_base_batch failed ({rc})")
         return y, q, cost, iters, status
 
+    def eval_base_objective(self, y, q, goals, n_goals=None, effort_weight=0.01):
+        """Base-placement objective (gto/base_planner.py:57-87) at y (B,3), q (B,n_max,ndof), goals (B,n_max,4,4)."""
+        d = self.desc
+        y = _f64(y).reshape(-1, 3)
+        B = y.shape[0]
+        goals = _f64(goals).reshape(B, -1, 16)
+        n_max = goals.shape[1]
+        q = _f64(q).reshape(B, n_max, d.ndof)
+        ng = _i32(np.broadcast_to(np.asarray(n_max if n_goals is None else n_goals), (B,)))
+        cost = np.empty(B)
+        f = self.lib.orc_eval_base_objective
+        f.argtypes = [C.POINTER(CRobotDesc), C.c_int32, C.c_int32, _pi, _pd, _pd, _pd, C.c_double, _pd]
+        f.restype = C.c_int
+        rc = f(C.byref(self._cdesc), B, n_max, _p(ng, _pi), _p(y, _pd), _p(q, _pd), _p(goals, _pd), float(effort_weight),
+               _p(cost, _pd))
+        if rc != 0:
+            raise RuntimeError(f"orc_eval_base_objective failed ({rc})")
+        return cost
+
     def eval_objective(self, scene_id, goals, n_goals, standoff, base_pos, Q):
         d, T = self.desc, self.T
         Q = _f64(Q).reshape(-1, d.ndof, T)
