@@ -143,13 +143,14 @@ def load_library(path: Optional[str] = None):
     lib.gto_plan_cost.argtypes = [H, C.c_int32, C.c_int32, _pd, _pd, _pd, _pd]
     lib.gto_solve_ik_batch.argtypes = [H, C.c_int32, _pi, _pd, _pd, _pd, C.c_int32, _pd, _pd, _pi, _pi]
     lib.gto_solve_base_batch.argtypes = [H, C.c_int32, C.c_int32, _pi, _pd, _pd, C.c_double, C.c_int32, _pd, _pd, _pd, _pi, _pi]
+    lib.gto_eval_base_objective.argtypes = [H, C.c_int32, C.c_int32, _pi, _pd, _pd, _pd, C.c_double, _pd]
     _pu8 = C.POINTER(C.c_uint8)
     lib.gto_depth_sdf_cost.argtypes = [C.c_int, _pf, C.c_int32, C.c_int32, _pd, _pd, _pd, _pd, _pu8, C.c_double, _pd, C.c_int64,
                                        C.c_float, C.c_float, _pf, _pu8, _pf, _pd, _pu8]
     for fn in ("gto_create", "gto_set_opts", "gto_set_scene", "gto_drop_scene", "gto_solve_batch",
                "gto_solve_batch_device", "gto_last_kernel_time", "gto_set_profiling", "gto_set_stream", "gto_share_scene", "gto_eval_fk",
                "gto_eval_points", "gto_eval_objective", "gto_eval_obstacle_normal_eq", "gto_plan_cost", "gto_solve_ik_batch",
-               "gto_solve_base_batch", "gto_depth_sdf_cost"):
+               "gto_solve_base_batch", "gto_eval_base_objective", "gto_depth_sdf_cost"):
         getattr(lib, fn).restype = C.c_int
     if path is None:
         _lib = lib
@@ -161,7 +162,7 @@ EXPORTED_SYMBOLS = (
     "gto_set_scene", "gto_drop_scene", "gto_solve_batch", "gto_solve_batch_device",
     "gto_last_kernel_time", "gto_set_profiling", "gto_set_stream", "gto_share_scene", "gto_eval_fk", "gto_eval_points",
     "gto_eval_objective", "gto_eval_obstacle_normal_eq", "gto_plan_cost", "gto_solve_ik_batch", "gto_solve_base_batch",
-    "gto_depth_sdf_cost",
+    "gto_eval_base_objective", "gto_depth_sdf_cost",
 )
 
 
@@ -375,6 +376,21 @@ class SolverHandle:
                                                       _p(cost, _pd), _p(iters, _pi), _p(status, _pi)),
                         "gto_solve_base_batch")
         return y, q, cost, iters, status
+
+    def eval_base_objective(self, y, q, goals, n_goals=None, effort_weight=0.01):
+        """Base-placement objective (gto/base_planner.py:57-87) at y (B,3), q (B,n_max,ndof), goals (B,n_max,4,4)."""
+        d = self.desc
+        y = _f64(y).reshape(-1, 3)
+        B = y.shape[0]
+        goals = _f64(goals).reshape(B, -1, 16)
+        n_max = goals.shape[1]
+        q = _f64(q).reshape(B, n_max, d.ndof)
+        ng = _i32(np.broadcast_to(np.asarray(n_max if n_goals is None else n_goals), (B,)))
+        cost = np.empty(B)
+        if B:
+            self._check(self.lib.gto_eval_base_objective(self._h, B, n_max, _p(ng, _pi), _p(y, _pd), _p(q, _pd), _p(goals, _pd),
+                                                         float(effort_weight), _p(cost, _pd)), "gto_eval_base_objective")
+        return cost
 
     def plan_cost(self, scene_id, plans, base_pos):
         d, T = self.desc, self.T

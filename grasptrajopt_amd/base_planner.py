@@ -31,7 +31,7 @@ class BasePlanner:
         """gto/base_planner.py:35-96: nothing symbolic to build; records the sizes and binds the handle."""
         self.goal_size = int(goal_size)
         self.base_effort_weight = float(base_effort_weight)
-        self._handle = self.robot.solver_handle(self.link_ee, self.link_gripper)
+        self._handle = self.robot.solver_handle(self.link_ee, self.link_gripper, role="base")
         self._fe = self.robot.desc.frame_index(self.link_ee)
         self._fg = self.robot.desc.frame_index(self.link_gripper)
 

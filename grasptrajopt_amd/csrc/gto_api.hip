@@ -931,13 +931,57 @@ int gto_solve_base_batch(gto_handle* h, int32_t B, int32_t n_max, const int32_t*
   }
   hipLaunchKernelGGL(k_base_solve, dim3(B), dim3(256), lds, h->stream, h->d_rb, (const double*)d_qc, (const double*)d_goals,
                      (const int32_t*)d_ng, sp, effort_weight, n_max, (double*)d_y, (double*)d_q, (double*)d_cost,
-                     (int32_t*)d_it, (int32_t*)d_stat);
+                     (int32_t*)d_it, (int32_t*)d_stat, (const double*)nullptr, (const double*)nullptr);
   HIPCHK(h, hipGetLastError());
   if ((rc = fetch_out(h, 0, q_out, (size_t)B * n_max * ndof * sizeof(double)))) return rc;
   if ((rc = fetch_out(h, 1, y_out, (size_t)B * 3 * sizeof(double)))) return rc;
   if ((rc = fetch_out(h, 2, cost_out, B * sizeof(double)))) return rc;
   if ((rc = fetch_out(h, 3, iters_out, B * sizeof(int32_t)))) return rc;
   if ((rc = fetch_out(h, 4, status_out, B * sizeof(int32_t)))) return rc;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return GTO_OK;
+}
+
+int gto_eval_base_objective(gto_handle* h, int32_t B, int32_t n_max, const int32_t* n_goals, const double* y,
+                            const double* q, const double* goals, double effort_weight, double* cost_out) {
+  if (!h) return GTO_ERR_INVALID_ARG;
+  if (B < 0) return fail(h, GTO_ERR_INVALID_ARG, "B must be >= 0");
+  if (n_max < 1 || n_max > GTO_MAX_BASE_GOALS) return fail(h, GTO_ERR_UNSUPPORTED, "n_max must be in [1, 32]");
+  if (B == 0) return GTO_OK;
+  if (!n_goals || !y || !q || !goals || !cost_out) return fail(h, GTO_ERR_INVALID_ARG, "null input array");
+  for (int b = 0; b < B; ++b)
+    if (n_goals[b] < 1 || n_goals[b] > n_max) return fail(h, GTO_ERR_INVALID_ARG, "n_goals[b] must be in [1, n_max]");
+  HIPCHK(h, hipSetDevice(h->device));
+  const size_t ndof = h->rb.ndof;
+  int rc;
+  // the parameter joints come from the first goal's configuration of every set
+  std::vector<double> qc((size_t)B * ndof);
+  for (int b = 0; b < B; ++b) std::copy(q + (size_t)b * n_max * ndof, q + (size_t)b * n_max * ndof + ndof, qc.begin() + (size_t)b * ndof);
+  const void *d_qc, *d_goals, *d_ng, *d_y0, *d_q0;
+  void *d_q, *d_y, *d_cost;
+  if ((rc = stage_in(h, 1, qc.data(), B * ndof * sizeof(double), &d_qc))) return rc;
+  if ((rc = stage_in(h, 2, goals, (size_t)B * n_max * 16 * sizeof(double), &d_goals))) return rc;
+  if ((rc = stage_in(h, 3, n_goals, B * sizeof(int32_t), &d_ng))) return rc;
+  if ((rc = stage_in(h, 4, y, (size_t)B * 3 * sizeof(double), &d_y0))) return rc;
+  if ((rc = stage_in(h, 6, q, (size_t)B * n_max * ndof * sizeof(double), &d_q0))) return rc;
+  if ((rc = ensure(h, h->out[0], (size_t)B * n_max * ndof * sizeof(double)))) return rc;
+  if ((rc = ensure(h, h->out[1], (size_t)B * 3 * sizeof(double)))) return rc;
+  d_q = h->out[0].p;
+  d_y = h->out[1].p;
+  if ((rc = stage_out(h, 2, cost_out, B * sizeof(double), &d_cost))) return rc;
+  SolveParams sp = make_params(h, 1, false);
+  sp.max_iter = 0;
+  const size_t lds = (size_t)base_lds_doubles(n_max) * sizeof(double);
+  if (lds > 160 * 1024) return fail(h, GTO_ERR_UNSUPPORTED, "goal set too large for the base kernel's LDS");
+  if ((int)lds > h->base_lds_set) {
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_base_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    h->base_lds_set = (int)lds;
+  }
+  hipLaunchKernelGGL(k_base_solve, dim3(B), dim3(256), lds, h->stream, h->d_rb, (const double*)d_qc, (const double*)d_goals,
+                     (const int32_t*)d_ng, sp, effort_weight, n_max, (double*)d_y, (double*)d_q, (double*)d_cost,
+                     (int32_t*)nullptr, (int32_t*)nullptr, (const double*)d_y0, (const double*)d_q0);
+  HIPCHK(h, hipGetLastError());
+  if ((rc = fetch_out(h, 2, cost_out, B * sizeof(double)))) return rc;
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return GTO_OK;
 }

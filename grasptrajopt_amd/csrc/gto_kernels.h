@@ -2249,7 +2249,10 @@ __global__ __launch_bounds__(256) void k_base_solve(const RobotDev* __restrict__
                                                     const double* __restrict__ goals, const int32_t* __restrict__ n_goals,
                                                     SolveParams sp, double w_effort, int n_max, double* __restrict__ y_out,
                                                     double* __restrict__ q_out, double* __restrict__ cost_out,
-                                                    int32_t* __restrict__ iters_out, int32_t* __restrict__ status_out) {
+                                                    int32_t* __restrict__ iters_out, int32_t* __restrict__ status_out,
+                                                    const double* __restrict__ y0, const double* __restrict__ q0) {
+  // y0 [B][3], q0 [B][n_max][ndof]: start point instead of the reference's (zero pose, qc for every goal); null in
+  // the solve, set by gto_eval_base_objective (a run capped at 0 iterations returns the objective at its start)
   extern __shared__ __attribute__((aligned(16))) double smem_base[];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int F = rb->n_frames, n = rb->n_opt, ndof = rb->ndof, ng = n_goals[b], NV = 8 + 8 * n_max;
@@ -2271,8 +2274,12 @@ __global__ __launch_bounds__(256) void k_base_solve(const RobotDev* __restrict__
   for (int i = tid; i < NV; i += 256) {
     double v = 0.0;
     if (i >= 8) {
-      const int j = i & 7;
-      if (j < n) v = fmin(fmax(qc[(size_t)b * ndof + rb->opt_index[j]], rb->lower[j]), rb->upper[j]);
+      const int j = i & 7, gi = (i >> 3) - 1;
+      const double* src = q0 ? q0 + ((size_t)b * n_max + gi) * ndof : qc + (size_t)b * ndof;
+      if (j < n) v = fmin(fmax(src[rb->opt_index[j]], rb->lower[j]), rb->upper[j]);
+    } else if (y0 && i < 3) {
+      v = y0[3 * (size_t)b + i];
+      if (i == 2) v = fmin(fmax(v, -PI_), PI_);
     }
     s_x[i] = v;
     s_xt[i] = v;

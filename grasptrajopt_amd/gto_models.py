@@ -114,21 +114,25 @@ class GTORobotModel:
         return np.asarray(values)[self.optimized_joint_indexes, :]
 
     # ------------------------------------------------------------------ HIP handles
-    def solver_handle(self, link_ee: str, link_gripper: str, opts=None) -> _capi.SolverHandle:
-        """One gto_handle per (link_ee, link_gripper, T, standoff_offset); created on first use."""
+    def solver_handle(self, link_ee: str, link_gripper: str, opts=None, role: str = "planner") -> _capi.SolverHandle:
+        """One gto_handle per (role, link_ee, link_gripper, T, standoff_offset); created on first use.  The role
+        ("planner", "ik", "base") keeps the planner's mutable options (weights, iteration cap) and scenes away
+        from the IK and base solvers, whose weights are the reference's constants (gto/ik_solver.py:70)."""
         o = opts if opts is not None else _capi.default_opts()
-        key = (link_ee, link_gripper, int(o.T), int(o.standoff_offset))
+        key = (role, link_ee, link_gripper, int(o.T), int(o.standoff_offset))
         h = self._handles.get(key)
         if h is None:
             h = _capi.SolverHandle(self.desc, link_ee, link_gripper, o, device=self.device)
             self._handles[key] = h
         return h
 
+    SCRATCH_SCENE = 1  # scene id of one-off evaluations (the planner's own scene is 0)
+
     def _util_handle(self) -> _capi.SolverHandle:
-        if self._handles:
-            return next(iter(self._handles.values()))
+        """Handle of the stand-alone evaluations (FK, surface points, plan cost): its own role, so that a scratch
+        scene never replaces one a solver is using."""
         ln = self.desc.link_names[-1]
-        return self.solver_handle(ln, ln)
+        return self.solver_handle(ln, ln, role="util")
 
     # ------------------------------------------------------------------ FK of the surface points
     def compute_fk_surface_points(self, q_user_input, tf_base=None):
@@ -230,8 +234,8 @@ class GTORobotModel:
         if plan.shape[1] != h.T:
             raise NotImplementedError(f"plans must have T={h.T} waypoints on this handle")
         shape, origin, res = self.field_geometry()
-        h.set_scene(65535, sdf_cost_obstacle, None, shape, origin, res)
-        cost, dist = h.plan_cost(65535, plan[None], base_position)
+        h.set_scene(self.SCRATCH_SCENE, sdf_cost_obstacle, None, shape, origin, res)
+        cost, dist = h.plan_cost(self.SCRATCH_SCENE, plan[None], base_position)
         return float(cost[0]), float(dist[0])
 
     def close(self):

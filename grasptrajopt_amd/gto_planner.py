@@ -81,17 +81,23 @@ class GTOPlanner:
         tf_goal = np.zeros((16, n))
         for i in range(n):
             tf_goal[:, i] = RTs[i].flatten()
+        # parameters first: the parameter-joint rows of every seed are qc's (gto/gto_planner.py:204-205,234), so the
+        # dictionary does not depend on the seed, and the scene is uploaded ONCE for seed scoring and solve
+        qp = np.tile(qc[np.array(self.robot.parameter_joint_indexes, dtype=np.int64)][:, None], (1, self.T))
+        self.solver.reset_parameters({
+            "qc": qc, "tf_goal": tf_goal, "sdf_cost_all": sdf_cost_all, "sdf_cost_obstacle": sdf_cost_obstacle,
+            "base_position": base_position, f"{self.robot_name}/q/p": qp})
         if q_solutions is None:
             Q0 = np.diag(qc) @ np.ones((self.robot.ndof, self.T))
         else:
             # seed = interpolation towards the IK solution with the lowest obstacle cost, ties broken by
-            # joint distance (gto/gto_planner.py:197-215); all candidates are scored in one GPU call
+            # joint distance (gto/gto_planner.py:197-215); all candidates are scored in one GPU call against
+            # c_obs of the scene the solve uses
             q_solutions = np.asarray(q_solutions, dtype=np.float64)
             plans = np.stack([self._seed_from(qc, q_solutions[:, i]) for i in range(q_solutions.shape[1])])
-            shape, origin, res = self.robot.field_geometry()
-            h = self.solver._handle
-            h.set_scene(65535, sdf_cost_obstacle, None, shape, origin, res)
-            cost_all, dist_all = h.plan_cost(65535, plans, base_position)
+            sid = self.solver.ensure_scene()
+            cost_all, dist_all = self.solver._handle.plan_cost(sid, plans, base_position)
+            self.seed_cost_all, self.seed_dist_all = cost_all, dist_all
             ind = np.lexsort((dist_all, cost_all))
             self.seed_index = int(ind[0])
             if interpolate:
@@ -101,9 +107,6 @@ class GTOPlanner:
                 for i in range(self.T + self.standoff_offset, self.T):
                     Q0[:, i] = plans[ind[0]][:, self.T - 1]
         self.solver.reset_initial_seed({f"{self.robot_name}/q/x": self.robot.extract_optimized_dimensions(Q0)})
-        self.solver.reset_parameters({
-            "qc": qc, "tf_goal": tf_goal, "sdf_cost_all": sdf_cost_all, "sdf_cost_obstacle": sdf_cost_obstacle,
-            "base_position": base_position, f"{self.robot_name}/q/p": self.robot.extract_parameter_dimensions(Q0)})
         solution = self.solver.solve()
         return (solution[f"{self.robot_name}/q"].toarray(), solution[f"{self.robot_name}/dq"].toarray(),
                 solution["f"].toarray().flatten())

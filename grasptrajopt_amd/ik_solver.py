@@ -25,7 +25,7 @@ class IKSolver:
 
     def setup_optimization(self):
         """gto/ik_solver.py:30-77: nothing symbolic to build; binds the solver handle."""
-        self._handle = self.robot.solver_handle(self.link_ee, self.link_gripper)
+        self._handle = self.robot.solver_handle(self.link_ee, self.link_gripper, role="ik")
         self._fe = self.robot.desc.frame_index(self.link_ee)
 
     # ------------------------------------------------------------------ batched entry point
@@ -44,7 +44,7 @@ class IKSolver:
             if sdf_cost_obstacle is None:
                 raise ValueError("collision_avoidance=True needs sdf_cost_obstacle")
             shape, origin, res = self.robot.field_geometry()
-            sid = 65534
+            sid = 0  # the IK solver owns its handle
             h.set_scene(sid, sdf_cost_obstacle, None, shape, origin, res)
         q, f, iters, status = h.solve_ik_batch(sid, q_0, RTs.reshape(B, 16), base, self.max_iter)
         # errors as the reference reports them (gto/ik_solver.py:88-93)

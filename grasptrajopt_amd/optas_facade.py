@@ -192,6 +192,7 @@ class Solver:
         self._p_dict = {k: np.zeros(shape) for k, shape in self.opt.parameters.items()}
         for k, v in p.items():
             self._p_dict[k] = np.asarray(v, dtype=np.float64).reshape(self.opt.parameters[k])
+        self._scene_dirty = True
 
     def stats(self) -> Dict:
         return self._stats
@@ -230,10 +231,25 @@ class CasADiSolver(Solver):
         if "max_iter" in so:
             opts.max_iter = int(so["max_iter"])
         self._goal = goal
-        self._handle = prob.robot.solver_handle(goal.link_ee, goal.link_gripper, opts)
+        self._handle = prob.robot.solver_handle(goal.link_ee, goal.link_gripper, opts, role="planner")
         self._handle.set_opts(max_iter=opts.max_iter, w_obstacle=opts.w_obstacle, w_vel=opts.w_vel)
         self._name = prob.robot.get_name()
         return self
+
+    SCENE_ID = 0
+
+    def ensure_scene(self) -> int:
+        """Upload the cost fields of the current parameters (once per reset_parameters) and return the scene id:
+        seed scoring (gto/gto_planner.py:208) and the solve read the same resident scene."""
+        if getattr(self, "_scene_dirty", True):
+            robot, p = self.opt.robot, self._p_dict
+            shape, origin, res = robot.field_geometry()
+            # parameters that were never set are zeros (optas/mx_container.py:121): plan() leaves sdf_cost_all out
+            c_all = p.get("sdf_cost_all", np.zeros(int(np.prod(shape))))
+            c_obs = p.get("sdf_cost_obstacle", np.zeros(int(np.prod(shape))))
+            self._handle.set_scene(self.SCENE_ID, c_all, c_obs, shape, origin, res)
+            self._scene_dirty = False
+        return self.SCENE_ID
 
     def solve(self) -> Dict[str, DM]:
         robot, T, name = self.opt.robot, self.opt.T, self._name
@@ -247,13 +263,10 @@ class CasADiSolver(Solver):
         n = self._goal.goal_size
         # tf_goal column i = RT_i.flatten() row-major (gto/gto_planner.py:188-191)
         goals = p["tf_goal"].T.reshape(1, n, 16)
-        shape, origin, res = robot.field_geometry()
-        c_all = p.get("sdf_cost_all", np.zeros(int(np.prod(shape))))
-        c_obs = p.get("sdf_cost_obstacle", np.zeros(int(np.prod(shape))))
-        self._handle.set_scene(0, c_all, c_obs, shape, origin, res)
+        sid = self.ensure_scene()
         S = self._goal.standoff_pose if self._goal.use_standoff else None
         Q, dQ, cost, iters, status = self._handle.solve_batch(
-            0, p["qc"].reshape(1, ndof), goals, n, S, p["base_position"].reshape(1, 3), Q0[None])
+            sid, p["qc"].reshape(1, ndof), goals, n, S, p["base_position"].reshape(1, 3), Q0[None])
         self._stats = {"iter_count": int(iters[0]), "success": bool(status[0] == 0),
                        "return_status": ("Solve_Succeeded", "Maximum_Iterations_Exceeded", "Numerical_Failure")[int(status[0])]}
         if self._error_on_fail and not self.did_solve():

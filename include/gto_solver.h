@@ -270,6 +270,14 @@ int gto_eval_obstacle_normal_eq(gto_handle* h, int32_t B, const int32_t* scene_i
                                 const double* base_pos, const double* Q, double* JtJ, double* Jtr,
                                 double* sumsq);
 
+/* Base-placement objective of gto/base_planner.py:57-87 at a given point: y [B][3] = (x, y, theta),
+ * q [B][n_max][ndof] one arm configuration per goal (parameter joints of row 0 are used for every goal, as the
+ * reference's q/p parameter), goals [B][n_max][16]:  effort_weight |y|^2 + sum_i sum_k |A(q_i) p_k - B(y) RT_i G p_k|^2.
+ * Evaluated by the solve kernel itself (a run of gto_solve_base_batch's kernel capped at 0 iterations, started
+ * at (y, q)): theta is clipped to [-pi, pi] and q to the joint limits first. */
+int gto_eval_base_objective(gto_handle* h, int32_t B, int32_t n_max, const int32_t* n_goals, const double* y,
+                            const double* q, const double* goals, double effort_weight, double* cost_out);
+
 /* Seed scoring: compute_plan_cost (gto/gto_models.py:204-215): plain sum of c_obs over all
  * waypoints and surface points, and ||q_0 - q_{T-1}||.  plans [n, ndof, T]. */
 int gto_plan_cost(gto_handle* h, int32_t scene_id, int32_t n, const double* plans,

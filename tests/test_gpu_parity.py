@@ -449,3 +449,72 @@ def test_depth_cost_field_matches_reference_golden_and_oracle(capi, oracle_mod):
     assert inside.any() and (~inside).any() and (cost > 0).any()
     np.testing.assert_array_equal(dpc.get_sdf_in_batches(q, batch_size=500), sdf)
     assert dpc.get_sdf(np.zeros((0, 3))).shape == (0,)
+
+
+# ------------------------------------------------------------------------------------------ assembled objectives
+# tests/golden/objective.npz holds what the reference's OWN setup_optimization code computes (executed with numeric
+# stand-ins for CasADi, tests/golden/make_objective_golden.py): these tests tie the HIP path to the reference
+# directly, not through the oracle.
+def _fixture_handle(capi, robot, g, kind=None):
+    from grasptrajopt_amd.robot_desc import load_builtin
+    cfg = cfg_of(robot)
+    d = load_builtin(robot)
+    np.testing.assert_array_equal(g[f"{robot}_points_checksum"], [d.points.sum(), np.abs(d.points).sum()])
+    h = capi.SolverHandle(d, cfg["link_ee"], cfg["link_gripper"], device=0)
+    if kind:
+        h.set_scene(0, g[f"{robot}_field_{kind}_all"], g[f"{robot}_field_{kind}_obs"], g[f"{robot}_grid_shape"],
+                    g[f"{robot}_grid_origin"], float(g[f"{robot}_grid_res"]))
+    return h
+
+
+@pytest.mark.parametrize("robot", ["panda", "fetch"])
+def test_objective_terms_vs_reference_fixture(capi, robot):
+    """gto_eval_objective against the reference's cost expressions (gto/gto_planner.py:84-135): f_goal of the set and of
+    every goal alone, arg-min goal (bit-exact), f_obs on a dense random field (every point's voxel matters) and on a
+    sparse one, f_vel.  1e-10 relative."""
+    g = golden("objective.npz")
+    Q = g[f"{robot}_Q"]
+    for tag in [str(c) for c in g["cases"] if str(c).startswith(robot)]:
+        h = _fixture_handle(capi, robot, g, tag.split("_")[-1])
+        RT = g[tag + "_RT"]
+        n = RT.shape[1]
+        so = g[f"{robot}_standoff"] if "_so1_" in tag else None
+        each = g[tag + "_f_goal_each"]
+        fg, fo, fv, am = h.eval_objective(0, RT.reshape(len(Q), n, 16), n, so, g[tag + "_base"], Q)
+        np.testing.assert_allclose(fg, each.min(axis=1), rtol=1e-10, err_msg=tag)
+        np.testing.assert_array_equal(am, each.argmin(axis=1), err_msg=tag)
+        np.testing.assert_allclose(fo, g[tag + "_f_obs"], rtol=1e-10, err_msg=tag)
+        np.testing.assert_allclose(fv, g[tag + "_f_vel"], rtol=1e-10, err_msg=tag)
+        for k in range(n):
+            fk, _, _, _ = h.eval_objective(0, RT[:, k].reshape(len(Q), 1, 16), 1, so, g[tag + "_base"], Q)
+            np.testing.assert_allclose(fk, each[:, k], rtol=1e-10, err_msg=f"{tag} goal {k}")
+        h.close()
+
+
+@pytest.mark.parametrize("robot", ["panda", "fetch"])
+def test_ik_objective_vs_reference_fixture(capi, robot):
+    """gto_solve_ik_batch capped at 0 iterations returns the objective at its seed: gto/ik_solver.py:46-70."""
+    g = golden("objective.npz")
+    h = _fixture_handle(capi, robot, g, "dense")
+    q, RT, base = g[f"{robot}_ik_q"], g[f"{robot}_ik_RT"].reshape(-1, 16), g[f"{robot}_ik_base"]
+    qo, cost, it, st = h.solve_ik_batch(0, q, RT, base, max_iter=0)
+    np.testing.assert_array_equal(qo, q)
+    np.testing.assert_allclose(cost, g[f"{robot}_ik_cost_pos"] + g[f"{robot}_ik_cost_obstacle"], rtol=1e-10)
+    _, cost0, _, _ = h.solve_ik_batch(None, q, RT, None, max_iter=0)
+    np.testing.assert_allclose(cost0, g[f"{robot}_ik_cost_pos"], rtol=1e-10)
+    h.close()
+
+
+@pytest.mark.parametrize("robot", ["panda", "fetch"])
+@pytest.mark.parametrize("n", [1, 3])
+def test_base_objective_vs_reference_fixture(capi, robot, n):
+    """gto_eval_base_objective (the base-placement kernel started at (y, q) and capped at 0 iterations) against
+    gto/base_planner.py:44-87, both the goal_size == 1 and the goal-set branch."""
+    g = golden("objective.npz")
+    h = _fixture_handle(capi, robot, g)
+    y, Qb, RT = g[f"{robot}_base_n{n}_y"], g[f"{robot}_base_n{n}_Q"], g[f"{robot}_base_n{n}_RT"]
+    q = np.transpose(Qb, (0, 2, 1))
+    eff, pos = g[f"{robot}_base_n{n}_cost_effort"], g[f"{robot}_base_n{n}_cost_pos"]
+    np.testing.assert_allclose(h.eval_base_objective(y, q, RT, effort_weight=0.0), pos, rtol=1e-10)
+    np.testing.assert_allclose(h.eval_base_objective(y, q, RT, effort_weight=0.01), pos + eff, rtol=1e-10)
+    h.close()

@@ -259,3 +259,47 @@ def test_grasp_collision_filter_matches_reference_loop(oracle_mod):
     assert (ratio > 0.01).any() and (ratio <= 0.01).any()
     np.testing.assert_array_equal(filter_grasps(gripper, dpc, RT, q, off), (ratio > 0.01).astype(np.int32))
     gripper.close()
+
+
+@pytest.mark.parametrize("robot_name", ["panda", "fetch"])
+@pytest.mark.parametrize("interpolate", [True, False])
+def test_plan_goalset_seed_vs_reference_fixture(robot_name, interpolate):
+    """Seed construction, scoring and selection of plan_goalset against what the reference's own plan_goalset does
+    (gto/gto_planner.py:185-236 executed with a recording solver, tests/golden/make_objective_golden.py): same winning
+    IK solution, same scores (the reference sums float32), same seed handed to the solver, same parameters."""
+    gz = golden("objective.npz")
+    cfg = cfg_of(robot_name)
+    robot = g.GTORobotModel(desc=g.load_builtin(robot_name), time_derivs=[0, 1], param_joints=cfg["param_joints"],
+                            collision_link_names=cfg["collision_link_names"], device=0)
+    # grid geometry as setup_points_field would leave it (gto/gto_models.py:155-171)
+    robot.origin = gz[f"{robot_name}_grid_origin"].reshape(1, 3)
+    robot.grid_resolution = float(gz[f"{robot_name}_grid_res"])
+    robot.field_shape = tuple(int(v) for v in gz[f"{robot_name}_grid_shape"])
+    robot.field_size = int(np.prod(robot.field_shape))
+    tag = f"{robot_name}_seed_interp{int(interpolate)}"
+    planner = g.GTOPlanner(robot, cfg["link_ee"], cfg["link_gripper"])
+    planner.max_iter = 0  # the solver hands back its (clipped) seed
+    qc = gz[f"{robot_name}_qc"]
+    plan, dQ, cost = planner.plan_goalset(qc, gz[tag + "_RTs"], gz[f"{robot_name}_field_sparse_all"],
+                                          gz[f"{robot_name}_field_sparse_obs"], gz[tag + "_base"], gz[tag + "_q_solutions"],
+                                          use_standoff=True, axis_standoff=cfg["axis_standoff"], interpolate=interpolate)
+    assert planner.seed_index == int(gz[tag + "_index"])
+    np.testing.assert_allclose(planner.seed_cost_all, gz[tag + "_cost_all"], rtol=2e-6)
+    np.testing.assert_allclose(planner.seed_dist_all, gz[tag + "_dist_all"], rtol=1e-13)
+    Q0 = gz[tag + "_Q0"]
+    oi, pi = robot.optimized_joint_indexes, robot.parameter_joint_indexes
+    np.testing.assert_allclose(planner.solver.x0[f"{robot.get_name()}/q/x"], Q0[oi], rtol=0, atol=1e-13)
+    np.testing.assert_array_equal(planner.solver._p_dict[f"{robot.get_name()}/q/p"], Q0[pi])
+    np.testing.assert_array_equal(planner.solver._p_dict["tf_goal"], gz[tag + "_tf_goal"])
+    # the reference passes exactly these; whatever else the problem declares stays at its zero default
+    passed = {str(k) for k in gz[tag + "_param_keys"]}
+    assert passed <= set(planner.solver._p_dict)
+    assert all(not np.any(v) for k, v in planner.solver._p_dict.items() if k not in passed)
+    # the returned plan is that seed with the first two waypoints pinned to qc (Q_1 = Q_0 = qc: initial state + zero
+    # initial velocity, gto/gto_planner.py:59-72) and the rest clipped into the joint limits
+    lo, hi = robot.desc.lower[oi][:, None], robot.desc.upper[oi][:, None]
+    exp = Q0.copy()
+    exp[oi] = np.clip(exp[oi], lo, hi)
+    exp[:, 0] = exp[:, 1] = qc
+    np.testing.assert_allclose(plan, exp, rtol=0, atol=1e-13)
+    robot.close()
