@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "gto_kernels.h"
+#include "gto_traj.h"
 
 #define GTO_VERSION 1000
 
@@ -39,6 +40,13 @@ struct gto_handle {
   size_t d_scenes_cap = 0;
   // solve workspace (grown on demand)
   DevBuf state, Qcur, Qtry, vis, screw, blocks, goalblk, ssfixed, ndone, qref, margin, qf, slotbuf, qfs;
+  DevBuf trajws, evterms, evblocks, counters;  // k_traj_solve: block workspace, evaluation outputs, work counters
+  int traj_nw = 8;        // wavefronts per workgroup (instance) of k_traj_solve: 4, 8 or 16 (GTO_TRAJ_NW)
+  int traj_nw_few = 16;   // ... when a call has few instances (latency matters more than occupancy)
+  int traj_few = 256;     // "few": at most one workgroup per CU
+  int traj_g = 0;         // waypoints per E-phase task (GTO_TRAJ_G), 0 = choose by LDS budget
+  bool legacy = false;    // GTO_LEGACY=1: the round-1 two-kernel solve loop (A/B comparisons)
+  unsigned long long last_counters[4] = {0, 0, 0, 0};
   int32_t* h_ndone = nullptr;  // pinned
   int check_every = 4;
   hipEvent_t ev_chk[2] = {nullptr, nullptr};
@@ -158,6 +166,11 @@ int gto_create(const gto_robot_desc* d, const gto_solver_opts* opts, int device,
   if (const char* e = getenv("GTO_OBS_TG")) h->obs_tg = h->obs_tg_few = std::max(1, std::min(GTO_MAX_TG, atoi(e)));
   if (const char* e = getenv("GTO_OBS_TG_FEW")) h->obs_tg_few = std::max(1, std::min(GTO_MAX_TG, atoi(e)));
   if (const char* e = getenv("GTO_FEW_INSTANCES")) h->few_instances = atoi(e);
+  if (const char* e = getenv("GTO_TRAJ_NW")) { int v = atoi(e); if (v == 4 || v == 8 || v == 16) h->traj_nw = h->traj_nw_few = v; }
+  if (const char* e = getenv("GTO_TRAJ_NW_FEW")) { int v = atoi(e); if (v == 4 || v == 8 || v == 16) h->traj_nw_few = v; }
+  if (const char* e = getenv("GTO_TRAJ_FEW")) h->traj_few = atoi(e);
+  if (const char* e = getenv("GTO_TRAJ_G")) h->traj_g = std::max(0, std::min(4, atoi(e)));
+  if (const char* e = getenv("GTO_LEGACY")) h->legacy = atoi(e) != 0;
   if (getenv("GTO_DEBUG_TIMING")) { (void)hipMalloc((void**)&h->dbg, 48 * sizeof(long long)); (void)hipMemset(h->dbg, 0, 48 * sizeof(long long)); }
   RobotDev& rb = h->rb;
   memset(&rb, 0, sizeof rb);
@@ -227,6 +240,16 @@ int gto_create(const gto_robot_desc* d, const gto_solver_opts* opts, int device,
     double R[9];
     rpy2r(d->visual_rpy + 3 * l, R);
     rt2aff(R, d->visual_xyz + 3 * l, rb.vis_origin[l]);
+  }
+  for (int i = 0; i < d->n_frames; ++i) rb.link_of_frame[i] = -1, rb.xst_slot[i] = -1;
+  for (int l = 0; l < d->n_links; ++l) {
+    if (rb.link_of_frame[rb.link_frame[l]] >= 0) { delete h; return fail(nullptr, GTO_ERR_INVALID_ARG, "two collision links on one frame"); }
+    rb.link_of_frame[rb.link_frame[l]] = l;
+  }
+  rb.n_xst = 0;
+  for (int i = 0; i < d->n_frames; ++i) {
+    const int p = rb.parent[i];
+    if (p >= 0 && p != i - 1 && rb.xst_slot[p] < 0) rb.xst_slot[p] = rb.n_xst++;
   }
   {  // operand table of fk_mfma_tree
     std::memset(rb.fk_tab, 0, sizeof rb.fk_tab);
@@ -429,7 +452,7 @@ void gto_destroy(gto_handle* h) {
   (void)hipFree(h->d_plink);
   (void)hipFree(h->d_perm);
   (void)hipFree(h->d_chunks);
-  DevBuf* bufs[] = {&h->state, &h->Qcur, &h->Qtry, &h->vis, &h->screw, &h->blocks, &h->goalblk, &h->ssfixed, &h->ndone, &h->qref, &h->margin, &h->qf, &h->slotbuf, &h->qfs};
+  DevBuf* bufs[] = {&h->trajws, &h->evterms, &h->evblocks, &h->counters, &h->state, &h->Qcur, &h->Qtry, &h->vis, &h->screw, &h->blocks, &h->goalblk, &h->ssfixed, &h->ndone, &h->qref, &h->margin, &h->qf, &h->slotbuf, &h->qfs};
   if (h->h_ndone) (void)hipHostFree(h->h_ndone);
   for (int p = 0; p < 2; ++p)
     if (h->ev_chk[p]) (void)hipEventDestroy(h->ev_chk[p]);
@@ -732,6 +755,72 @@ static int check_scene_ids_host(gto_handle* h, const int32_t* ids, int B) {
   return GTO_OK;
 }
 
+}  // extern "C"
+
+// One workgroup per instance runs the whole solve (gto_traj.h).  nw wavefronts per workgroup; G waypoints per E-phase
+// task, the largest that keeps two workgroups of eight waves (one of sixteen) on a CU.
+template <int NW>
+static int launch_traj_nw(gto_handle* h, hipStream_t st, const TrajArgs& a, const SolveParams& sp, size_t lds) {
+  static size_t attr_set = 0;  // process-wide per instantiation: only ever raised
+  if (lds > attr_set) {
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_traj_solve<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = lds;
+  }
+  const int grid = 8 * ((a.B + 7) / 8);
+  hipLaunchKernelGGL(k_traj_solve<NW>, dim3(grid), dim3(64 * NW), lds, st, h->d_rb, h->d_px, h->d_py, h->d_pz, h->d_chunks,
+                     h->d_scenes, a, sp);
+  return GTO_OK;
+}
+
+static int launch_traj(gto_handle* h, hipStream_t st, TrajArgs a, const SolveParams& sp) {
+  const RobotDev& rb = h->rb;
+  int rc;
+  if ((rc = ensure(h, h->trajws, (size_t)a.B * 2 * sp.T * BLK_STRIDE * sizeof(double)))) return rc;
+  if ((rc = ensure(h, h->counters, 64))) return rc;
+  a.blocks = (double*)h->trajws.p;
+  a.counters = (unsigned long long*)h->counters.p;
+  a.dbg = h->dbg;
+  const int nw = a.B <= h->traj_few ? h->traj_nw_few : h->traj_nw;
+  const size_t budget = (nw == 16 ? 156 : (nw == 8 ? 78 : 38)) * 1024;  // 1, 2, 4 workgroups per CU
+  int G = h->traj_g;
+  if (G <= 0) {
+    G = 2;
+    for (int g = 3; g >= 2; --g)  // three waypoints per task: 16 tasks for T = 50, two rounds of eight waves
+      if ((size_t)TrajLds(sp.T, rb.n_frames, rb.n_links, rb.n_xst, g, nw).total * sizeof(double) <= budget) { G = g; break; }
+  }
+  a.G = G;
+  const size_t lds = (size_t)TrajLds(sp.T, rb.n_frames, rb.n_links, rb.n_xst, G, nw).total * sizeof(double);
+  if (lds > 160 * 1024) return fail(h, GTO_ERR_UNSUPPORTED, "robot / T too large for the solve kernel's LDS");
+  HIPCHK(h, hipMemsetAsync(a.counters, 0, 4 * sizeof(unsigned long long), st));
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (h->profiling) {
+    while (h->ev.size() < 2) {
+      hipEvent_t e;
+      HIPCHK(h, hipEventCreate(&e));
+      h->ev.push_back(e);
+    }
+    e0 = h->ev[0], e1 = h->ev[1];
+    HIPCHK(h, hipEventRecord(e0, st));
+  }
+  if (nw == 16) rc = launch_traj_nw<16>(h, st, a, sp, lds);
+  else if (nw == 4) rc = launch_traj_nw<4>(h, st, a, sp, lds);
+  else rc = launch_traj_nw<8>(h, st, a, sp, lds);
+  if (rc) return rc;
+  HIPCHK(h, hipGetLastError());
+  if (h->profiling) {
+    HIPCHK(h, hipEventRecord(e1, st));
+    HIPCHK(h, hipStreamSynchronize(st));
+    float ms = 0.f;
+    HIPCHK(h, hipEventElapsedTime(&ms, e0, e1));
+    h->last_ms = ms;
+    h->last_launches = 1;
+    HIPCHK(h, hipMemcpy(h->last_counters, a.counters, sizeof h->last_counters, hipMemcpyDeviceToHost));
+  }
+  return GTO_OK;
+}
+
+extern "C" {
+
 int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_t* scene_id, const double* qc,
                            const double* goals, const int32_t* n_goals, const double* standoff, const double* base_pos,
                            const double* Q0, double* Q_out, double* dQ_out, double* cost_out, int32_t* iters_out,
@@ -743,6 +832,13 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
   if (h->scenes.empty()) return fail(h, GTO_ERR_NO_SCENE, "no scene has been set");
   HIPCHK(h, hipSetDevice(h->device));
   hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+  if (!h->legacy) {
+    TrajArgs a = {};
+    a.scene_id = scene_id, a.qc = qc, a.goals = goals, a.n_goals = n_goals, a.standoff = standoff, a.base_pos = base_pos, a.Q0 = Q0;
+    a.Q_out = Q_out, a.dQ_out = dQ_out, a.cost_out = cost_out, a.iters_out = iters_out, a.status_out = status_out;
+    a.B = B;
+    return launch_traj(h, st, a, make_params(h, n_max, standoff != nullptr));
+  }
   int rc = ensure_workspace(h, B);
   if (rc) return rc;
   SolveParams sp = make_params(h, n_max, standoff != nullptr);

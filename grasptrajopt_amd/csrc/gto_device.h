@@ -32,6 +32,10 @@ struct RobotDev {
   int32_t joint_type[GTO_MAX_FRAMES];
   int32_t q_index[GTO_MAX_FRAMES];
   int32_t opt_of_frame[GTO_MAX_FRAMES];  // optimised-joint slot driven by this frame's joint, or -1
+  int32_t link_of_frame[GTO_MAX_FRAMES]; // collision link attached to this frame, or -1
+  // serial FK walk of k_traj_solve: frames whose transform a later, non-adjacent child needs are parked in LDS
+  int32_t xst_slot[GTO_MAX_FRAMES];      // parking slot of this frame's transform, or -1
+  int32_t n_xst;
   int32_t opt_of_dof[GTO_MAX_DOF];       // optimised-joint slot of actuated joint i, or -1 (parameter joint)
   uint32_t frame_anc[GTO_MAX_FRAMES];    // bit j: optimised joint j moves this frame
   double origin[GTO_MAX_FRAMES][12];     // rt2tr(rpy2r(rpy), xyz)  (optas/models.py:848-857)
