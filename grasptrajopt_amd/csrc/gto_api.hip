@@ -776,7 +776,7 @@ static int launch_traj(gto_handle* h, hipStream_t st, TrajArgs a, const SolvePar
   const RobotDev& rb = h->rb;
   int rc;
   if ((rc = ensure(h, h->trajws, (size_t)a.B * 2 * sp.T * BLK_STRIDE * sizeof(double)))) return rc;
-  if ((rc = ensure(h, h->counters, 64))) return rc;
+  if ((rc = ensure(h, h->counters, 128))) return rc;
   a.blocks = (double*)h->trajws.p;
   a.counters = (unsigned long long*)h->counters.p;
   a.dbg = h->dbg;
@@ -786,12 +786,12 @@ static int launch_traj(gto_handle* h, hipStream_t st, TrajArgs a, const SolvePar
   if (G <= 0) {
     G = 2;
     for (int g = 3; g >= 2; --g)  // three waypoints per task: 16 tasks for T = 50, two rounds of eight waves
-      if ((size_t)TrajLds(sp.T, rb.n_frames, rb.n_links, rb.n_xst, g, nw).total * sizeof(double) <= budget) { G = g; break; }
+      if ((size_t)TrajLds(sp.T, rb.n_frames, rb.n_links, rb.n_chunks, rb.n_opt, rb.n_xst, g, nw).total * sizeof(double) <= budget) { G = g; break; }
   }
   a.G = G;
-  const size_t lds = (size_t)TrajLds(sp.T, rb.n_frames, rb.n_links, rb.n_xst, G, nw).total * sizeof(double);
+  const size_t lds = (size_t)TrajLds(sp.T, rb.n_frames, rb.n_links, rb.n_chunks, rb.n_opt, rb.n_xst, G, nw).total * sizeof(double);
   if (lds > 160 * 1024) return fail(h, GTO_ERR_UNSUPPORTED, "robot / T too large for the solve kernel's LDS");
-  HIPCHK(h, hipMemsetAsync(a.counters, 0, 4 * sizeof(unsigned long long), st));
+  HIPCHK(h, hipMemsetAsync(a.counters, 0, 16 * sizeof(unsigned long long), st));
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (h->profiling) {
     while (h->ev.size() < 2) {
@@ -807,6 +807,26 @@ static int launch_traj(gto_handle* h, hipStream_t st, TrajArgs a, const SolvePar
   else rc = launch_traj_nw<8>(h, st, a, sp, lds);
   if (rc) return rc;
   HIPCHK(h, hipGetLastError());
+  if (h->dbg) {
+    HIPCHK(h, hipStreamSynchronize(st));
+    long long t[48];
+    unsigned long long cn[16];
+    HIPCHK(h, hipMemcpy(t, h->dbg, sizeof t, hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(cn, a.counters, sizeof cn, hipMemcpyDeviceToHost));
+    fprintf(stderr, "[gto dbg] k_traj_solve nw=%d G=%d lds=%zu | last iteration of instance 0 (cycles): E %lld | P0-P2 %lld | P3 solve %lld | P4-P5 %lld\n",
+            nw, G, lds, t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3]);
+    fprintf(stderr, "[gto dbg] one regular task of wave 0: sincos %lld | FK %lld | broad+gather %lld | final flush %lld\n", t[9] - t[8], t[10] - t[9],
+            t[11] - t[10], t[12] - t[11]);
+    fprintf(stderr, "[gto dbg] longest task of that evaluation: %lld cycles, task %lld, %lld chunks gathered (evaluation total %lld chunks)\n", t[13], t[14] >> 16,
+            t[14] & 0xffff, t[15]);
+    {
+      const double tot = (double)(cn[4] + cn[5] + cn[6] + cn[7] + cn[8] + cn[9]);
+      fprintf(stderr, "[gto dbg] wave-cycles of the call (all waves, all instances): sincos %.1f%% | FK %.1f%% | broad %.1f%% | gather %.1f%% | idle at E barrier %.1f%% | S phase %.1f%% | total %.3g wave-cycles, %.0f per evaluation\n",
+              100 * cn[4] / tot, 100 * cn[5] / tot, 100 * cn[6] / tot, 100 * cn[7] / tot, 100 * cn[8] / tot, 100 * cn[9] / tot, tot, tot / (double)cn[2]);
+    }
+    fprintf(stderr, "[gto dbg] certification: %llu of %llu waypoint evaluations certified; no survivors %llu, slack >= 2 %llu\n", cn[11], cn[14], cn[12], cn[13]);
+    fprintf(stderr, "[gto dbg] counters: points gathered %llu, chunk tests %llu, evaluations %llu, instances %llu, waypoints skipped as certified free %llu\n", cn[0], cn[1], cn[2], cn[3], cn[10]);
+  }
   if (h->profiling) {
     HIPCHK(h, hipEventRecord(e1, st));
     HIPCHK(h, hipStreamSynchronize(st));

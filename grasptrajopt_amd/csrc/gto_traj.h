@@ -53,25 +53,29 @@ struct TrajArgs {
 };
 
 struct TrajLds {  // dynamic LDS layout in doubles, identical on host and device
-  int Qc, Qt, ss, ssfix, gaff, goalblk, red, ints, uni;
+  int Qc, Qt, qref, margin, ss, ssfix, gaff, goalblk, red, ints, tab, chk, uni;
   int wstride, oV, oScr, oAli, oGk, oSurv, oSsw;  // per-wave scratch of the E phase (offsets inside a wave's slice)
   int Z, y, e, b, x, act;                          // S phase
   int total;
-  __host__ __device__ TrajLds(int T, int F, int L, int n_xst, int G, int NW) {
+  __host__ __device__ TrajLds(int T, int F, int L, int C, int n_opt, int n_xst, int G, int NW) {
     const int NP = GTO_NB, m = T - 2;
     int o = 0;
     Qc = o;      o += T * NP;
     Qt = o;      o += T * NP;
+    qref = o;    o += T * NP;         // configuration at which a waypoint was certified to be in free space
+    margin = o;  o += (T + 1) / 2;   // ... and its clearance then, in voxels (int; -1: not certified)
     ss = o;      o += T;
     ssfix = o;   o += 4;
     gaff = o;    o += 48;
     goalblk = o; o += 2 * 2 * BLK_STRIDE;
     red = o;     o += 32;
     ints = o;    o += 16;  // 32 ints
+    tab = o;     o += fk_tab_doubles(F, L, n_opt);  // operand table of the kinematics (RobotDev::fk_tab)
+    chk = o;     o += 6 * C;                        // chunk table: 48 B per chunk
     uni = o;
     int w = 0;
     oV = w;      w += G * L * 12;
-    oScr = w;    w += 4 * GTO_MAX_OPT * 6;  // the goal task uses two blocks whatever G is
+    oScr = w;    w += (G > 2 ? G : 2) * GTO_MAX_OPT * 6;  // the goal task uses two blocks whatever G is
     oAli = w;    { const int fk = 4 * F * 2 + n_xst * 64, lst = TRAJ_LIST_CAP * 8; w += fk > lst ? fk : lst; }
     oGk = w;     w += 32;
     oSurv = w;   w += 64;
@@ -113,23 +117,26 @@ __device__ __forceinline__ TrajWp traj_wp(int kind, int g, int G, int blk, int T
 }
 
 template <int NW>
-__global__ __launch_bounds__(64 * NW, NW == 16 ? 4 : 4) void k_traj_solve(
+__global__ __launch_bounds__(64 * NW, 4) void k_traj_solve(
     const RobotDev* __restrict__ rb, const double* __restrict__ px, const double* __restrict__ py, const double* __restrict__ pz,
     const Chunk* __restrict__ chunks, const SceneDev* __restrict__ scenes, TrajArgs a, SolveParams sp) {
   extern __shared__ __attribute__((aligned(16))) double smem_tr[];
   constexpr int NP = GTO_NB;
   constexpr int NT = 64 * NW;
   static_assert(NP == 8, "lane-per-entry layout of the 8x8 blocks");
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tid0 = threadIdx.x, lane0 = tid0 & 63, wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
   // blockIdx -> instance: a contiguous range of instances (one scene's goal sets are neighbours) per XCD
   const int nb8 = (a.B + 7) >> 3;
   const int b = (blockIdx.x & 7) * nb8 + (blockIdx.x >> 3);
   if (b >= a.B) return;
   const int T = sp.T, n = rb->n_opt, ndof = rb->ndof, F = rb->n_frames, L = rb->n_links, C = rb->n_chunks, m = T - 2;
   const int G = a.G;
-  const TrajLds lay(T, F, L, rb->n_xst, G, NW);
+  const int fr_grip = rb->frame_gripper, fr_ee = rb->frame_ee;
+  const TrajLds lay(T, F, L, C, n, rb->n_xst, G, NW);
   double* s_Qc = smem_tr + lay.Qc;
   double* s_Qt = smem_tr + lay.Qt;
+  double* s_qref = smem_tr + lay.qref;
+  int* s_margin = reinterpret_cast<int*>(smem_tr + lay.margin);
   double* s_ss = smem_tr + lay.ss;
   double* s_ssfix = smem_tr + lay.ssfix;
   double* s_gaff = smem_tr + lay.gaff;
@@ -147,7 +154,7 @@ __global__ __launch_bounds__(64 * NW, NW == 16 ? 4 : 4) void k_traj_solve(
   double* s_xst = s_sc + 4 * F * 2;            // [n_xst][64]
   double* s_lst = w_base + lay.oAli;           // wrench list, after the kinematics
   double* s_gk = w_base + lay.oGk;
-  int2* s_surv = reinterpret_cast<int2*>(w_base + lay.oSurv);
+  unsigned short* s_surv16 = reinterpret_cast<unsigned short*>(w_base + lay.oSurv);  // [256]
   double* s_ssw = w_base + lay.oSsw;
   // S phase
   double* s_Z = s_uni + lay.Z;
@@ -167,7 +174,7 @@ __global__ __launch_bounds__(64 * NW, NW == 16 ? 4 : 4) void k_traj_solve(
 
   // ---- seed: optimised rows of Q0, first two waypoints pinned to qc, the rest clipped into the bounds
   // (gto/gto_planner.py:59-72,138); raw: evaluate Q0 as it is
-  for (int idx = tid; idx < T * NP; idx += NT) {
+  for (int idx = tid0; idx < T * NP; idx += NT) {
     const int t = idx / NP, j = idx - t * NP;
     double v = 0.0;
     if (j < n) {
@@ -180,22 +187,31 @@ __global__ __launch_bounds__(64 * NW, NW == 16 ? 4 : 4) void k_traj_solve(
     s_Qc[idx] = v;
     s_Qt[idx] = v;
   }
-  if (tid < 16) s_int[tid] = 0;
-  if (tid < 4) s_ssfix[tid] = 0.0;
-  for (int t = tid; t < T; t += NT) s_ss[t] = 0.0;
+  {
+    const int nt = fk_tab_doubles(F, L, n);
+    double* s_tab_w = smem_tr + lay.tab;
+    for (int i = tid0; i < nt; i += NT) s_tab_w[i] = rb->fk_tab[i];
+    double* s_chk_w = smem_tr + lay.chk;
+    const double* gch = reinterpret_cast<const double*>(chunks);
+    for (int i = tid0; i < 6 * C; i += NT) s_chk_w[i] = gch[i];
+  }
+  if (tid0 < 16) s_int[tid0] = 0;
+  if (tid0 < 4) s_ssfix[tid0] = 0.0;
+  for (int t = tid0; t < T; t += NT) s_ss[t] = 0.0, s_margin[t] = -1;
   __syncthreads();
 
-  // lane roles
-  const int ra = lane >> 4, rc = lane & 3, blk = (lane >> 2) & 3;  // FK: entry (ra, rc) of block blk
-  const int fe = 4 * ra + rc, fet = 4 * rc + ra;
-  const double ident = (ra == rc) ? 1.0 : 0.0;
-  const int r = lane >> 3, c = lane & 7;                           // 8x8 blocks: entry (r, c)
-  const int mcol = lane & 15, mrow = lane >> 4;                    // Gram fold: D column, D rows mrow / mrow + 4
-  auto gram_index = [](int row, int col) { return col < 6 ? sym6(row, col) : (row < 6 ? 21 + row : -1); };
-  const int gk0 = (mrow <= mcol && mcol < 7) ? gram_index(mrow, mcol) : -1;
-  const int gk1 = (mrow + 4 <= mcol && mcol < 7) ? gram_index(mrow + 4, mcol) : -1;
   typedef double gto_v4f64 __attribute__((ext_vector_type(4)));
-  const double* __restrict__ tab = rb->fk_tab;
+  const double* __restrict__ tab = smem_tr + lay.tab;
+  const Chunk* __restrict__ s_chunks = reinterpret_cast<const Chunk*>(smem_tr + lay.chk);
+  // per-frame descriptor, lane f holds frame f's: parent + 1 | (parking slot + 1) << 6 | (link + 1) << 12 |
+  // (optimised joint + 1) << 18 | joint type << 23 | (actuated index + 1) << 25; a wave reads it with v_readlane.
+  // lane l also holds the ancestor mask of collision link l.
+  int fdesc = 0;
+  unsigned ldesc = 0u;
+  if (lane0 < F)
+    fdesc = (rb->parent[lane0] + 1) | ((rb->xst_slot[lane0] + 1) << 6) | ((rb->link_of_frame[lane0] + 1) << 12) |
+            ((rb->opt_of_frame[lane0] + 1) << 18) | (rb->joint_type[lane0] << 23) | ((rb->q_index[lane0] + 1) << 25);
+  if (lane0 < L) ldesc = rb->link_anc[lane0];
   const double* __restrict__ tVo = tab + 64 * F;
   const double* __restrict__ tU = tVo + 16 * L;
   const double* __restrict__ tI = tU + 16 * n;  // link_frame [L], opt_frame [n], prismatic flag [n], parent [F]
@@ -204,34 +220,83 @@ __global__ __launch_bounds__(64 * NW, NW == 16 ? 4 : 4) void k_traj_solve(
   // solver state: uniform over the workgroup, every thread carries it
   double f = INFINITY, lambda = sp.lambda0, nu = 2.0, pred = 0.0;
   int first = 1, k = 0, status = GTO_STATUS_MAX_ITER, slot = 0, argmin_cur = 0;
-  unsigned long long n_pts = 0, n_tests = 0;  // this wave's work counters (lane 0 is authoritative)
+  unsigned long long n_pts = 0, n_tests = 0, n_culled = 0;  // this wave's work counters (lane 0 is authoritative)
+  // profiling (a.dbg set): cycles this wave spent in sincos | FK | broad phase | gather | idle at the end of the E phase | S phase
+  const bool prof = a.dbg != nullptr;
+  long long pc_sc = 0, pc_fk = 0, pc_br = 0, pc_ga = 0, pc_idle = 0, pc_s = 0, pc_t = 0;
   int n_evals = 0;
 
   for (;;) {
     const int trial = first ? slot : 1 - slot;
     // ================================================================================== E phase
-    if (dbg && tid == 0) a.dbg[0] = clock64();
-    if (tid < 4) s_touched[4 * trial + tid] = 0u;
+    if (dbg && tid0 == 0) a.dbg[0] = clock64();
+    if (tid0 < 4) s_touched[4 * trial + tid0] = 0u;
     __syncthreads();
     {
       const int nGrp = (m + G - 1) / G, nFix = first ? (4 + G - 1) / G : 0;
       const int nTasks = 1 + nFix + nGrp;
       for (;;) {
         int tk = 0;
-        if (lane == 0) tk = atomicAdd(&s_int[0], 1);
+        if (lane0 == 0) tk = atomicAdd(&s_int[0], 1);
         tk = __builtin_amdgcn_readfirstlane(tk);
         if (tk >= nTasks) break;
         const int kind = tk == 0 ? 0 : (tk <= nFix ? 1 : 2);
-        const int g = kind == 0 ? 0 : (kind == 1 ? tk - 1 : tk - 1 - nFix);
+        // regular groups are dealt from the goal end backwards: the waypoints near the goal are the ones near obstacles,
+        // their tasks are the long ones and should not start last
+        const int g = kind == 0 ? 0 : (kind == 1 ? tk - 1 : nGrp - 1 - (tk - 1 - nFix));
+        // lane roles, derived from an opaque copy of the lane id inside every task: otherwise the compiler hoists the
+        // per-lane address arithmetic of all phases out of the Levenberg-Marquardt loop and spills hundreds of registers
+        int lane = lane0;
+        asm volatile("" : "+v"(lane));
+        const int ra = lane >> 4, rc = lane & 3, blk = (lane >> 2) & 3;  // FK: entry (ra, rc) of block blk
+        const int fe = 4 * ra + rc, fet = 4 * rc + ra;
+        const double ident = (ra == rc) ? 1.0 : 0.0;
+        const int r = lane >> 3, c = lane & 7;                           // 8x8 blocks: entry (r, c)
+        const int mcol = lane & 15, mrow = lane >> 4;                    // Gram fold: D column, D rows mrow / mrow + 4
+        auto gram_index = [](int row, int col) { return col < 6 ? sym6(row, col) : (row < 6 ? 21 + row : -1); };
+        const int gk0 = (mrow <= mcol && mcol < 7) ? gram_index(mrow, mcol) : -1;
+        const int gk1 = (mrow + 4 <= mcol && mcol < 7) ? gram_index(mrow + 4, mcol) : -1;
+
+        // Temporal culling (exact): a waypoint whose every chunk sphere was at least `margin` voxels clear of any non-zero
+        // voxel at configuration qref, and none of whose surface points can have moved further since
+        // (|dx| <= sum_j |dq_j| reach_j), still contributes exact zeros: no kinematics, no lookups.
+        unsigned cullm = 0u;  // bit blk: block is certified free
+        if (kind == 2 && !a.eval_only && rb->reach[0] >= 0.0) {
+          const int bq = lane >> 3, jq = lane & 7;
+          const TrajWp w = traj_wp(kind, g, G, bq & 3, T, sp.ts);
+          const bool in = lane < 32 && w.t >= 0;
+          double dv = (in && jq < n) ? fabs(s_Qt[w.t * NP + jq] - s_qref[w.t * NP + jq]) * rb->reach[jq] : 0.0;
+          dv = dpp_add<0xB1>(dv);
+          dv = dpp_add<0x4E>(dv);
+          dv = dpp_add<0x141>(dv);  // sum over the eight lanes of the block
+          const int mg = in ? s_margin[w.t] : -1;
+          const bool ok = in && mg >= 0 && (int)ceil(dv * sc.rinv) <= mg;
+          const unsigned long long bm = __ballot(ok && jq == 0);
+          cullm = (unsigned)((bm & 1ull) | ((bm >> 7) & 2ull) | ((bm >> 14) & 4ull) | ((bm >> 21) & 8ull));
+          unsigned validm = 0u;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) validm |= traj_wp(kind, g, G, q, T, sp.ts).t >= 0 ? 1u << q : 0u;
+          cullm &= validm;
+          n_culled += __popc(cullm);
+          if (cullm == validm) {  // the whole group is in certified free space
+            if (lane < 4 && ((validm >> lane) & 1u)) s_ss[traj_wp(kind, g, G, lane, T, sp.ts).t] = 0.0;
+            continue;
+          }
+        }
+        const bool dbg_w = dbg && wave == 0 && kind == 2 && lane == 0;
+        if (dbg_w) a.dbg[8] = clock64();
+        const long long t_task0 = prof ? clock64() : 0;
+        int n_chunks_task = 0;
         // ---- sin / cos of every (block, frame)
         for (int idx = lane; idx < 4 * F; idx += 64) {
           const int bq = idx / F, fq = idx - bq * F;
           const TrajWp w = traj_wp(kind, g, G, bq, T, sp.ts);
           double sn = 0.0, cs = 1.0;
+          const int dsc = __shfl(fdesc, fq, 64);
           if (w.t >= 0) {
-            const int jt = rb->joint_type[fq], dq = rb->q_index[fq];
+            const int jt = (dsc >> 23) & 3, dq = ((dsc >> 25) & 63) - 1;
             if (dq >= 0) {
-              const int j = rb->opt_of_dof[dq];
+              const int j = ((dsc >> 18) & 31) - 1;
               const double qv = j >= 0 ? s_Qt[w.t * NP + j] : Q0b[(size_t)dq * T + w.t];
               if (jt == GTO_JOINT_REVOLUTE) sincos(qv, &sn, &cs);
               else if (jt == GTO_JOINT_PRISMATIC) sn = qv;
@@ -242,6 +307,8 @@ __global__ __launch_bounds__(64 * NW, NW == 16 ? 4 : 4) void k_traj_solve(
         }
         if (lane < 4) s_ssw[lane] = 0.0;
         wave_sync();
+        if (dbg_w) a.dbg[9] = clock64();
+        if (prof) pc_t = clock64(), pc_sc += pc_t - t_task0;
         // ---- forward kinematics: serial walk, one block per waypoint (optas/models.py:826-868).
         // Per frame: L_f = O_f M_f (local; A operand O, B operand M = c0 + cos c1 + sin K), X_f = L_f^T X_parent with the
         // local product already in the A-operand layout of its transpose and X_parent in the layout a D result has.
@@ -258,24 +325,25 @@ __global__ __launch_bounds__(64 * NW, NW == 16 ? 4 : 4) void k_traj_solve(
               const double* kt = tab + 64 * (fq + 1);
               Ot = kt[fet], c0 = kt[16 + fe], c1 = kt[32 + fe], Kk = kt[48 + fe];
             }
-            const int p = rb->parent[fq];
+            const int dsc = __builtin_amdgcn_readlane(fdesc, fq);
+            const int p = (dsc & 63) - 1;
             double Xp = Xprev;
-            if (p != fq - 1 || fq == 0) Xp = p < 0 ? ident : s_xst[rb->xst_slot[p] * 64 + lane];
+            if (p != fq - 1 || fq == 0) Xp = p < 0 ? ident : s_xst[(((__builtin_amdgcn_readlane(fdesc, p < 0 ? 0 : p) >> 6) & 63) - 1) * 64 + lane];
             const double X = __builtin_amdgcn_mfma_f64_4x4x4f64(Lf, Xp, 0.0, 0, 0, 0);
-            const int xs = rb->xst_slot[fq];
+            const int xs = ((dsc >> 6) & 63) - 1;
             if (xs >= 0) {
               s_xst[xs * 64 + lane] = X;
               wave_sync();
             }
-            const int l = rb->link_of_frame[fq];
+            const int l = ((dsc >> 12) & 63) - 1;
             if (l >= 0 && kind != 0) {  // visual transform V^T = Vo^T X (gto/gto_models.py:92-100)
               const double V = __builtin_amdgcn_mfma_f64_4x4x4f64(tVo[16 * l + fe], X, 0.0, 0, 0, 0);
               if (bvalid && blk < G && rc < 3) s_V[(blk * L + l) * 12 + 4 * rc + ra] = V;
             }
-            const int j = rb->opt_of_frame[fq];
+            const int j = ((dsc >> 18) & 31) - 1;
             if (j >= 0) {  // world screw of optimised joint j: (a ; o x a), (0 ; a) for a prismatic joint
               const double S = __builtin_amdgcn_mfma_f64_4x4x4f64(tU[16 * j + fe], X, 0.0, 0, 0, 0);
-              const bool prism = rb->joint_type[fq] == GTO_JOINT_PRISMATIC;
+              const bool prism = ((dsc >> 23) & 3) == GTO_JOINT_PRISMATIC;
               const double av = S, ov = __shfl(S, (lane + 16) & 63, 64);
               const double a1 = quad_perm<1, 2, 0, 3>(av), a2 = quad_perm<2, 0, 1, 3>(av);
               const double o1 = quad_perm<1, 2, 0, 3>(ov), o2 = quad_perm<2, 0, 1, 3>(ov);
@@ -287,13 +355,15 @@ __global__ __launch_bounds__(64 * NW, NW == 16 ? 4 : 4) void k_traj_solve(
               }
             }
             if (kind == 0 && bvalid && rc < 3) {  // gripper and ee frames of the goal task: X = G^T
-              if (fq == rb->frame_gripper) s_gaff[24 * blk + 4 * rc + ra] = X;
-              if (fq == rb->frame_ee) s_gaff[24 * blk + 12 + 4 * rc + ra] = X;
+              if (fq == fr_grip) s_gaff[24 * blk + 4 * rc + ra] = X;
+              if (fq == fr_ee) s_gaff[24 * blk + 12 + 4 * rc + ra] = X;
             }
             Xprev = X;
           }
         }
         wave_sync();
+        if (dbg_w) a.dbg[10] = clock64();
+        if (prof) { const long long t_ = clock64(); pc_fk += t_ - pc_t; pc_t = t_; }
         if (kind == 0) {
           // ---- goal-set terms (gto/gto_planner.py:84-105) and velocity term (:133-135) of the trial
           const GoalOut go = goal_terms_wave(rb, sp, a.goals + (size_t)b * sp.n_max * 16, a.n_goals[b],
@@ -355,7 +425,7 @@ __global__ __launch_bounds__(64 * NW, NW == 16 ? 4 : 4) void k_traj_solve(
             if (w0) s_gk[gk0] = gD[0];
             if (w1) s_gk[gk1] = gD[1];
             wave_sync();
-            const uint32_t anc = rb->link_anc[fl];
+            const uint32_t anc = __builtin_amdgcn_readlane(ldesc, fl);
             const double* sr = s_scr + (fb * GTO_MAX_OPT + r) * 6;
             const double* scc = s_scr + (fb * GTO_MAX_OPT + c) * 6;
             if (r < n && c < n && ((anc >> r) & 1u) && ((anc >> c) & 1u)) {
@@ -390,101 +460,73 @@ __global__ __launch_bounds__(64 * NW, NW == 16 ? 4 : 4) void k_traj_solve(
           double4 rec;
           float fval;
         };
-        auto load_chunk = [&](int ci, ChunkLite& ch, double& x0, double& x1, double& x2) {
-          const int2 d2 = s_surv[ci];
-          ch = {d2.x, d2.y & 0xffff, d2.y >> 16};
-          x0 = x1 = x2 = 0.0;
-          if (lane < ch.count) {
-            x0 = px[ch.start + lane];
-            x1 = py[ch.start + lane];
-            x2 = pz[ch.start + lane];
-          }
-        };
-        auto stage_a = [&](const ChunkLite& ch, double x0, double x1, double x2, Staged& st_) {
-          const int kb = ch.key >> 16, link = ch.key & 0xffff;
-          const TrajWp w = traj_wp(kind, g, G, kb, T, sp.ts);
-          const bool pre = use_all(w);  // gto/gto_planner.py:117-131: c_all before the standoff waypoint
-          const bool need_grad = grad_on && w.mode == 0;
-          const double* V = s_V + (kb * L + link) * 12;
-          const double y0 = V[0] * x0 + V[1] * x1 + V[2] * x2 + V[3];
-          const double y1 = V[4] * x0 + V[5] * x1 + V[6] * x2 + V[7];
-          const double y2 = V[8] * x0 + V[9] * x1 + V[10] * x2 + V[11];
-          const double u0 = fma(y0, sc.rinv, cx), u1 = fma(y1, sc.rinv, cy), u2 = fma(y2, sc.rinv, cz);
-          double k0 = floor(u0), k1 = floor(u1), k2 = floor(u2);
-          const double edge = fmax(fmax(fabs((u0 - k0) - 0.5), fabs((u1 - k1) - 0.5)), fabs((u2 - k2) - 0.5));
-          if (edge > 0.5 - 1e-9) {  // within 1e-9 of a voxel face: the reference's own order decides (gto/gto_models.py:174-187)
-            k0 = floor(((y0 + bx) - sc.ox) / sc.res);
-            k1 = floor(((y1 + by) - sc.oy) / sc.res);
-            k2 = floor(((y2 + bz) - sc.oz) / sc.res);
-          }
-          const int ix = min(max((int)k0, 0), sc.nx - 1);
-          const int iy = min(max((int)k1, 0), sc.ny - 1);
-          const int iz = min(max((int)k2, 0), sc.nz - 1);
-          const int off = iz + nzv * (iy + sc.ny * ix);
-          st_.key = ch.key;
-          st_.count = ch.count;
-          st_.y0 = y0, st_.y1 = y1, st_.y2 = y2;
-          st_.fval = 0.f;
-          st_.rec = make_double4(0.0, 0.0, 0.0, 0.0);
-          if (!need_grad) st_.fval = (pre ? sc.c_all : sc.c_obs)[off];
-          else st_.rec = *reinterpret_cast<const double4*>(&(pre ? sc.r_all : sc.r_obs)[off]);
-        };
-        for (int base_c = 0; base_c < 4 * C; base_c += 64) {
-          // broad phase of 64 candidates: bounding sphere of the chunk against the Chebyshev distance to the nearest
-          // non-zero voxel; a chunk that cannot reach one contributes exact zeros and is skipped
-          const int gi = base_c + lane;
-          const int kq = gi / C, ci = gi - kq * C;
-          bool keep = false;
-          int2 desc2 = make_int2(0, 0);
-          const TrajWp w = traj_wp(kind, g, G, kq < 4 ? kq : 3, T, sp.ts);
-          if (kq < 4 && w.t >= 0) {
-            const Chunk cc = chunks[ci];
-            desc2 = make_int2(cc.link | (kq << 16), cc.start | (cc.count << 16));
-            const bool is_static = cc.pad != 0;
-            // regular waypoints skip the static links (measured once); the static-only blocks skip everything else
-            keep = w.mode == 0 ? !is_static : (w.mode == 1 ? true : is_static);
-            if (keep) {
-              const double* V = s_V + (kq * L + cc.link) * 12;
-              const double u0 = (V[0] * cc.cx + V[1] * cc.cy + V[2] * cc.cz + V[3] + bx - sc.ox) * sc.rinv;
-              const double u1 = (V[4] * cc.cx + V[5] * cc.cy + V[6] * cc.cz + V[7] + by - sc.oy) * sc.rinv;
-              const double u2 = (V[8] * cc.cx + V[9] * cc.cy + V[10] * cc.cz + V[11] + bz - sc.oz) * sc.rinv;
-              const int R = (int)ceil(cc.r * sc.rinv) + 2;
-              const int k0 = (int)floor(u0), k1 = (int)floor(u1), k2 = (int)floor(u2);
-              if (R < GTO_DIST_CAP && k0 - R >= 0 && k1 - R >= 0 && k2 - R >= 0 && k0 + R < sc.nx && k1 + R < sc.ny && k2 + R < sc.nz) {
-                const uint8_t* __restrict__ dist = use_all(w) ? sc.d_all : sc.d_obs;
-                keep = (int)dist[k2 + nzv * (k1 + sc.ny * k0)] <= R;
+        // Survivors of a super-batch: s_surv16[i] = chunk | block << 8.  Gather loop over them as ONE software-pipelined
+        // loop with a single copy of every stage: iteration i requests the point coordinates of chunk i + 2, transforms
+        // chunk i + 1 and issues its record gather, and consumes chunk i; the final pass (i == NA, after the last
+        // super-batch only) folds the open key and emits the last block.
+        auto process_survivors = [&](int NA, bool last) {
+          if (NA == 0 && !last) return;
+          ChunkLite lch = {0, 0, 0}, ach = {0, 0, 0};  // chunk whose points are in flight / are being transformed
+          double n0 = 0.0, n1 = 0.0, n2 = 0.0;
+          Staged cur = {}, nxt = {};
+#pragma unroll 1
+          for (int i = -2; i < NA + (last ? 1 : 0); ++i) {
+            // ---- stage A of chunk i + 1 (its coordinates were requested one iteration ago)
+            ach = lch;
+            const double x0 = n0, x1 = n1, x2 = n2;
+            // ---- stage L: coordinates of chunk i + 2
+            if (i + 2 < NA) {
+              const int e16 = s_surv16[i + 2];
+              const Chunk* cc = s_chunks + (e16 & 0xff);
+              lch = {cc->link | ((e16 >> 8) << 16), cc->start, cc->count};
+              n0 = n1 = n2 = 0.0;
+              if (lane < lch.count) {
+                n0 = px[lch.start + lane];
+                n1 = py[lch.start + lane];
+                n2 = pz[lch.start + lane];
               }
             }
-          }
-          const unsigned long long vm = __ballot(kq < 4 && w.t >= 0);
-          if (!vm) break;  // past the last valid block
-          n_tests += __popcll(vm);
-          const unsigned long long bm = __ballot(keep);
-          const int NA = __popcll(bm);
-          if (!NA) continue;
-          if (keep) s_surv[__popcll(bm & ((1ull << lane) - 1ull))] = desc2;
-          wave_sync();
-          // two-stage software pipeline over the surviving chunks of this batch
-          ChunkLite nch = {0, 0, 0};
-          double n0 = 0.0, n1 = 0.0, n2 = 0.0;
-          Staged cur = {};
-          {
-            ChunkLite ch;
-            double x0, x1, x2;
-            load_chunk(0, ch, x0, x1, x2);
-            if (1 < NA) load_chunk(1, nch, n0, n1, n2);
-            stage_a(ch, x0, x1, x2, cur);
-          }
-#pragma unroll 1
-          for (int ci2 = 0; ci2 < NA; ++ci2) {
-            Staged nxt = {};
-            if (ci2 + 1 < NA) {
-              stage_a(nch, n0, n1, n2, nxt);
-              if (ci2 + 2 < NA) load_chunk(ci2 + 2, nch, n0, n1, n2);
+            cur = nxt;
+            if (i + 1 >= 0 && i + 1 < NA) {
+              const int kb = ach.key >> 16, link = ach.key & 0xffff;
+              const TrajWp w = traj_wp(kind, g, G, kb, T, sp.ts);
+              const bool pre = use_all(w);  // gto/gto_planner.py:117-131: c_all before the standoff waypoint
+              const bool need_grad = grad_on && w.mode == 0;
+              const double* V = s_V + (kb * L + link) * 12;
+              // point in the robot-base frame (gto/gto_planner.py:114-116); the field frame adds base_position
+              const double y0 = V[0] * x0 + V[1] * x1 + V[2] * x2 + V[3];
+              const double y1 = V[4] * x0 + V[5] * x1 + V[6] * x2 + V[7];
+              const double y2 = V[8] * x0 + V[9] * x1 + V[10] * x2 + V[11];
+              const double u0 = fma(y0, sc.rinv, cx), u1 = fma(y1, sc.rinv, cy), u2 = fma(y2, sc.rinv, cz);
+              double k0 = floor(u0), k1 = floor(u1), k2 = floor(u2);
+              const double edge = fmax(fmax(fabs((u0 - k0) - 0.5), fabs((u1 - k1) - 0.5)), fabs((u2 - k2) - 0.5));
+              if (edge > 0.5 - 1e-9) {  // within 1e-9 of a voxel face: the reference's own order decides (gto/gto_models.py:174-187)
+                k0 = floor(((y0 + bx) - sc.ox) / sc.res);
+                k1 = floor(((y1 + by) - sc.oy) / sc.res);
+                k2 = floor(((y2 + bz) - sc.oz) / sc.res);
+              }
+              const int ix = min(max((int)k0, 0), sc.nx - 1);
+              const int iy = min(max((int)k1, 0), sc.ny - 1);
+              const int iz = min(max((int)k2, 0), sc.nz - 1);
+              const int off = iz + nzv * (iy + sc.ny * ix);
+              nxt.key = ach.key;
+              nxt.count = ach.count;
+              nxt.y0 = y0, nxt.y1 = y1, nxt.y2 = y2;
+              nxt.fval = 0.f;
+              nxt.rec = make_double4(0.0, 0.0, 0.0, 0.0);
+              if (!need_grad) nxt.fval = (pre ? sc.c_all : sc.c_obs)[off];
+              else nxt.rec = *reinterpret_cast<const double4*>(&(pre ? sc.r_all : sc.r_obs)[off]);
             }
-            if (cur.key != cur_key) {
+            // ---- stage B: consume chunk i
+            if (i < 0) continue;
+            const int newkey = i < NA ? cur.key : -2;
+            if (newkey != cur_key) {
               if (cur_key >= 0) flush(cur_key);
-              cur_key = cur.key;
+              cur_key = newkey;
+            }
+            if (i == NA) {
+              emit_block();
+              break;
             }
             n_pts += cur.count;
             const bool valid = lane < cur.count;
@@ -518,13 +560,104 @@ __global__ __launch_bounds__(64 * NW, NW == 16 ? 4 : 4) void k_traj_solve(
                 if (am || cnt == TRAJ_LIST_CAP) drain();
               }
             }
-            cur = nxt;
           }
-          wave_sync();  // the survivor list is rewritten by the next batch
+          wave_sync();  // the survivor list is rewritten by the next super-batch
+        };
+        // Broad phase, 256 (block, chunk) candidates at a time in (waypoint, link) order: bounding sphere of the chunk against
+        // the Chebyshev distance to the nearest non-zero voxel; a chunk that cannot reach one contributes exact zeros and is
+        // skipped.  The four distance lookups of a lane are issued together.
+        const int nSB = (4 * C + 255) >> 8;
+        int slk0 = 1 << 20, slk1 = 1 << 20, slk2 = 1 << 20, slk3 = 1 << 20;  // per block: min over this lane's chunks of (distance - radius)
+        int nsv0 = 0, nsv1 = 0, nsv2 = 0, nsv3 = 0;                          // per block: surviving chunks (uniform)
+#pragma unroll 1
+        for (int sb = 0; sb < nSB; ++sb) {
+          int dd[4], Rr[4], e16[4];
+          bool pre_keep[4], vld[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int gi = sb * 256 + 64 * u + lane;
+            const int kq = gi / C, ci = gi - kq * C;
+            const TrajWp w = traj_wp(kind, g, G, kq < 4 ? kq : 3, T, sp.ts);
+            vld[u] = kq < 4 && w.t >= 0 && !((cullm >> kq) & 1u);
+            pre_keep[u] = false;
+            dd[u] = 0, Rr[u] = 0;
+            e16[u] = ci | (kq << 8);
+            if (vld[u]) {
+              const Chunk cc = s_chunks[ci];
+              const bool is_static = cc.pad != 0;
+              // regular waypoints skip the static links (measured once); the static-only blocks skip everything else
+              pre_keep[u] = w.mode == 0 ? !is_static : (w.mode == 1 ? true : is_static);
+              if (pre_keep[u]) {
+                const double* V = s_V + (kq * L + cc.link) * 12;
+                const double u0 = (V[0] * cc.cx + V[1] * cc.cy + V[2] * cc.cz + V[3] + bx - sc.ox) * sc.rinv;
+                const double u1 = (V[4] * cc.cx + V[5] * cc.cy + V[6] * cc.cz + V[7] + by - sc.oy) * sc.rinv;
+                const double u2 = (V[8] * cc.cx + V[9] * cc.cy + V[10] * cc.cz + V[11] + bz - sc.oz) * sc.rinv;
+                const int R = (int)ceil(cc.r * sc.rinv) + 2;
+                const int k0 = (int)floor(u0), k1 = (int)floor(u1), k2 = (int)floor(u2);
+                Rr[u] = R;
+                int sl = -1000;
+                // only spheres inside the grid (no clipped indices) and closer than the cap can be culled
+                if (R < GTO_DIST_CAP && k0 - R >= 0 && k1 - R >= 0 && k2 - R >= 0 && k0 + R < sc.nx && k1 + R < sc.ny && k2 + R < sc.nz) {
+                  const uint8_t* __restrict__ dist = use_all(w) ? sc.d_all : sc.d_obs;
+                  dd[u] = (int)dist[k2 + nzv * (k1 + sc.ny * k0)];
+                  // clearance that also survives a move of the sphere: stay inside the grid and below the cap
+                  sl = min(min(k0, k1), k2) - R;
+                  sl = min(sl, min(min(sc.nx - 1 - k0, sc.ny - 1 - k1), sc.nz - 1 - k2) - R);
+                  sl = min(sl, GTO_DIST_CAP - 1 - R);
+                  sl = min(sl, dd[u] - R);
+                }
+                slk0 = kq == 0 ? min(slk0, sl) : slk0;
+                slk1 = kq == 1 ? min(slk1, sl) : slk1;
+                slk2 = kq == 2 ? min(slk2, sl) : slk2;
+                slk3 = kq == 3 ? min(slk3, sl) : slk3;
+              }
+            }
+          }
+          int NA = 0;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            n_tests += __popcll(__ballot(vld[u]));
+            const bool keep = pre_keep[u] && dd[u] <= Rr[u];
+            const unsigned long long bm = __ballot(keep);
+            if (keep) s_surv16[NA + __popcll(bm & ((1ull << lane) - 1ull))] = (unsigned short)e16[u];
+            NA += __popcll(bm);
+            if (bm) {
+              const int kqu = e16[u] >> 8;
+              nsv0 += __popcll(__ballot(keep && kqu == 0));
+              nsv1 += __popcll(__ballot(keep && kqu == 1));
+              nsv2 += __popcll(__ballot(keep && kqu == 2));
+              nsv3 += __popcll(__ballot(keep && kqu == 3));
+            }
+          }
+          wave_sync();
+          n_chunks_task += NA;
+          if (prof) { const long long t_ = clock64(); pc_br += t_ - pc_t; pc_t = t_; }
+          process_survivors(NA, sb == nSB - 1);
+          if (prof) { const long long t_ = clock64(); pc_ga += t_ - pc_t; pc_t = t_; }
         }
-        if (cur_key >= 0) flush(cur_key);
-        emit_block();
-        wave_sync();
+        if (kind == 2) {  // remember how much room every waypoint of the group had (only if the whole waypoint was culled)
+          const int m0 = wave_min_i32(slk0), m1 = wave_min_i32(slk1), m2 = wave_min_i32(slk2), m3 = wave_min_i32(slk3);
+          const int bq = lane >> 3, jq = lane & 7;
+          const TrajWp w = traj_wp(kind, g, G, bq & 3, T, sp.ts);
+          if (lane < 32 && w.t >= 0 && !((cullm >> bq) & 1u)) {
+            const int mall = bq == 0 ? m0 : (bq == 1 ? m1 : (bq == 2 ? m2 : m3));
+            const int nsv = bq == 0 ? nsv0 : (bq == 1 ? nsv1 : (bq == 2 ? nsv2 : nsv3));
+            s_qref[w.t * NP + jq] = s_Qt[w.t * NP + jq];
+            if (jq == 0) s_margin[w.t] = (nsv == 0 && mall >= 2) ? mall - 2 : -1;
+            if (prof && jq == 0) {
+              atomicAdd(a.counters + 11, (unsigned long long)(nsv == 0 && mall >= 2));
+              atomicAdd(a.counters + 12, (unsigned long long)(nsv == 0));
+              atomicAdd(a.counters + 13, (unsigned long long)(mall >= 2));
+              atomicAdd(a.counters + 14, 1ull);
+            }
+          }
+        }
+        if (dbg && lane == 0) {  // the longest task of this evaluation, and how many chunks it gathered
+          const int dtc = (int)(clock64() - t_task0);
+          if (atomicMax(&s_int[13], dtc) < dtc) s_int[14] = n_chunks_task | (tk << 16);
+          atomicAdd(&s_int[15], n_chunks_task);
+        }
+        if (dbg_w) a.dbg[11] = a.dbg[12] = clock64();
         // sum of c^2 per waypoint: its keys in link order (+ the static links, measured in the first evaluation)
         if (lane < 4) {
           const TrajWp w = traj_wp(kind, g, G, lane, T, sp.ts);
@@ -535,15 +668,24 @@ __global__ __launch_bounds__(64 * NW, NW == 16 ? 4 : 4) void k_traj_solve(
         }
       }
     }
+    if (prof) pc_t = clock64();
     __syncthreads();
+    if (prof) { const long long t_ = clock64(); pc_idle += t_ - pc_t; pc_t = t_; }
     ++n_evals;
-    if (dbg && tid == 0) a.dbg[1] = clock64();
+    if (dbg && tid0 == 0) {
+      a.dbg[1] = clock64();
+      a.dbg[13] = s_int[13], a.dbg[14] = s_int[14], a.dbg[15] = s_int[15];
+      s_int[13] = s_int[14] = s_int[15] = 0;
+    }
     // static links: constant per field, added to every regular waypoint (the sums above hold the moving links)
-    for (int t = 2 + tid; t < T; t += NT) s_ss[t] += s_ssfix[t < sp.ts ? 2 : 3];
-    if (tid == 0) s_int[0] = 0;
+    for (int t = 2 + tid0; t < T; t += NT) s_ss[t] += s_ssfix[t < sp.ts ? 2 : 3];
+    if (tid0 == 0) s_int[0] = 0;
     __syncthreads();
 
     // ================================================================================== S phase
+    int lane = lane0, tid = tid0;
+    asm volatile("" : "+v"(lane), "+v"(tid));
+    const int r = lane >> 3, c = lane & 7;  // 8x8 blocks: entry (r, c)
     // ---- P0: objective of the trial point
     double fo = 0.0;
     for (int t = 2 + lane; t < T; t += 64) fo += s_ss[t];
@@ -874,6 +1016,7 @@ __global__ __launch_bounds__(64 * NW, NW == 16 ? 4 : 4) void k_traj_solve(
     }
     ++k;
     __syncthreads();  // the S-phase arrays are dead: the union region goes back to the waves
+    if (prof) pc_s += clock64() - pc_t;
     if (dbg && tid == 0) a.dbg[4] = clock64();
   }
 
@@ -882,30 +1025,39 @@ __global__ __launch_bounds__(64 * NW, NW == 16 ? 4 : 4) void k_traj_solve(
   if (!a.eval_only) {
     if (a.Q_out) {
       double* Qo = a.Q_out + (size_t)b * ndof * T;
-      for (int idx = tid; idx < ndof * T; idx += NT) {
+      for (int idx = tid0; idx < ndof * T; idx += NT) {
         const int dq = idx / T, t = idx - dq * T, j = rb->opt_of_dof[dq];
         Qo[idx] = j >= 0 ? s_Qc[t * NP + j] : Q0b[idx];
       }
     }
     if (a.dQ_out) {
       double* dQo = a.dQ_out + (size_t)b * ndof * (T - 1);
-      for (int idx = tid; idx < ndof * (T - 1); idx += NT) {
+      for (int idx = tid0; idx < ndof * (T - 1); idx += NT) {
         const int dq = idx / (T - 1), t = idx - dq * (T - 1), j = rb->opt_of_dof[dq];
         dQo[idx] = (j >= 0 && t >= 1) ? (s_Qc[(t + 1) * NP + j] - s_Qc[t * NP + j]) / sp.dt : 0.0;
       }
     }
-    if (tid == 0) {
+    if (tid0 == 0) {
       if (a.cost_out) a.cost_out[b] = f;
       if (a.iters_out) a.iters_out[b] = k;
       if (a.status_out) a.status_out[b] = status;
     }
   }
   if (a.counters) {
-    if (lane == 0) {
+    if (lane0 == 0) {
       atomicAdd(a.counters + 0, n_pts);
       atomicAdd(a.counters + 1, n_tests);
+      atomicAdd(a.counters + 10, n_culled);
+      if (prof) {
+        atomicAdd(a.counters + 4, (unsigned long long)pc_sc);
+        atomicAdd(a.counters + 5, (unsigned long long)pc_fk);
+        atomicAdd(a.counters + 6, (unsigned long long)pc_br);
+        atomicAdd(a.counters + 7, (unsigned long long)pc_ga);
+        atomicAdd(a.counters + 8, (unsigned long long)pc_idle);
+        atomicAdd(a.counters + 9, (unsigned long long)pc_s);
+      }
     }
-    if (tid == 0) {
+    if (tid0 == 0) {
       atomicAdd(a.counters + 2, (unsigned long long)n_evals);
       atomicAdd(a.counters + 3, 1ull);
     }

@@ -15,7 +15,7 @@ for f in glob.glob(os.path.join(out, "*", "**", "*counter_collection.csv"), recu
             agg[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
 lines = []
 for k, cs in sorted(agg.items(), key=lambda kv: -len(kv[1])):
-    if not (k.startswith("k_obstacle") or k.startswith("k_lm_step")):
+    if not (k.startswith("k_obstacle") or k.startswith("k_lm_step") or "k_traj_solve" in k):
         continue
     lines.append(f"## {k}")
     for c, v in sorted(cs.items()):
