@@ -135,6 +135,7 @@ def load_library(path: Optional[str] = None):
     lib.gto_last_kernel_time.argtypes = [H, _pd, _pi]
     lib.gto_set_profiling.argtypes = [H, C.c_int32]
     lib.gto_set_stream.argtypes = [H, C.c_void_p]
+    lib.gto_set_mode.argtypes = [H, C.c_int32]
     lib.gto_share_scene.argtypes = [H, C.c_int32, H, C.c_int32]
     lib.gto_eval_fk.argtypes = [H, C.c_int32, _pd, _pd]
     lib.gto_eval_points.argtypes = [H, C.c_int32, C.c_int32, _pd, _pd, C.c_int32, _pd, _pi, _pd, _pd]
@@ -148,7 +149,7 @@ def load_library(path: Optional[str] = None):
     lib.gto_depth_sdf_cost.argtypes = [C.c_int, _pf, C.c_int32, C.c_int32, _pd, _pd, _pd, _pd, _pu8, C.c_double, _pd, C.c_int64,
                                        C.c_float, C.c_float, _pf, _pu8, _pf, _pd, _pu8]
     for fn in ("gto_create", "gto_set_opts", "gto_set_scene", "gto_drop_scene", "gto_solve_batch",
-               "gto_solve_batch_device", "gto_last_kernel_time", "gto_set_profiling", "gto_set_stream", "gto_share_scene", "gto_eval_fk",
+               "gto_solve_batch_device", "gto_last_kernel_time", "gto_set_profiling", "gto_set_stream", "gto_set_mode", "gto_share_scene", "gto_eval_fk",
                "gto_eval_points", "gto_eval_objective", "gto_eval_obstacle_normal_eq", "gto_plan_cost", "gto_solve_ik_batch",
                "gto_solve_base_batch", "gto_eval_base_objective", "gto_depth_sdf_cost"):
         getattr(lib, fn).restype = C.c_int
@@ -160,7 +161,7 @@ def load_library(path: Optional[str] = None):
 EXPORTED_SYMBOLS = (
     "gto_default_opts", "gto_version", "gto_create", "gto_destroy", "gto_last_error", "gto_set_opts",
     "gto_set_scene", "gto_drop_scene", "gto_solve_batch", "gto_solve_batch_device",
-    "gto_last_kernel_time", "gto_set_profiling", "gto_set_stream", "gto_share_scene", "gto_eval_fk", "gto_eval_points",
+    "gto_last_kernel_time", "gto_set_profiling", "gto_set_stream", "gto_set_mode", "gto_share_scene", "gto_eval_fk", "gto_eval_points",
     "gto_eval_objective", "gto_eval_obstacle_normal_eq", "gto_plan_cost", "gto_solve_ik_batch", "gto_solve_base_batch",
     "gto_eval_base_objective", "gto_depth_sdf_cost",
 )
@@ -282,6 +283,12 @@ class SolverHandle:
         """Bind every launch/copy of this handle to the caller's HIP stream (an int such as
         torch.cuda.Stream.cuda_stream); None restores a private stream."""
         self._check(self.lib.gto_set_stream(self._h, None if stream is None else C.c_void_p(int(stream))), "gto_set_stream")
+
+    MODE_ROUNDS, MODE_SINGLE_LAUNCH = 0, 1
+
+    def set_mode(self, mode: int):
+        """MODE_ROUNDS (default): evaluate / step launches over slots; MODE_SINGLE_LAUNCH: one launch per call."""
+        self._check(self.lib.gto_set_mode(self._h, int(mode)), "gto_set_mode")
 
     def set_profiling(self, enabled: bool):
         self._check(self.lib.gto_set_profiling(self._h, int(enabled)), "gto_set_profiling")

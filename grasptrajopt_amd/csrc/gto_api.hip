@@ -45,7 +45,7 @@ struct gto_handle {
   int traj_nw_few = 16;   // ... when a call has few instances (latency matters more than occupancy)
   int traj_few = 256;     // "few": at most one workgroup per CU
   int traj_g = 0;         // waypoints per E-phase task (GTO_TRAJ_G), 0 = choose by LDS budget
-  bool legacy = false;    // GTO_LEGACY=1: the round-1 two-kernel solve loop (A/B comparisons)
+  int mode = GTO_MODE_ROUNDS;  // gto_set_mode / GTO_MODE: rounds of two launches over slots, or one launch per call (gto_traj.h)
   unsigned long long last_counters[4] = {0, 0, 0, 0};
   int32_t* h_ndone = nullptr;  // pinned
   int check_every = 4;
@@ -170,7 +170,7 @@ int gto_create(const gto_robot_desc* d, const gto_solver_opts* opts, int device,
   if (const char* e = getenv("GTO_TRAJ_NW_FEW")) { int v = atoi(e); if (v == 4 || v == 8 || v == 16) h->traj_nw_few = v; }
   if (const char* e = getenv("GTO_TRAJ_FEW")) h->traj_few = atoi(e);
   if (const char* e = getenv("GTO_TRAJ_G")) h->traj_g = std::max(0, std::min(4, atoi(e)));
-  if (const char* e = getenv("GTO_LEGACY")) h->legacy = atoi(e) != 0;
+  if (const char* e = getenv("GTO_MODE")) h->mode = atoi(e) == GTO_MODE_SINGLE_LAUNCH ? GTO_MODE_SINGLE_LAUNCH : GTO_MODE_ROUNDS;
   if (getenv("GTO_DEBUG_TIMING")) { (void)hipMalloc((void**)&h->dbg, 48 * sizeof(long long)); (void)hipMemset(h->dbg, 0, 48 * sizeof(long long)); }
   RobotDev& rb = h->rb;
   memset(&rb, 0, sizeof rb);
@@ -614,6 +614,13 @@ int gto_drop_scene(gto_handle* h, int32_t id) {
   return sync_scene_table(h);
 }
 
+int gto_set_mode(gto_handle* h, int32_t mode) {
+  if (!h) return GTO_ERR_INVALID_ARG;
+  if (mode != GTO_MODE_ROUNDS && mode != GTO_MODE_SINGLE_LAUNCH) return fail(h, GTO_ERR_INVALID_ARG, "unknown solver mode");
+  h->mode = mode;
+  return GTO_OK;
+}
+
 int gto_set_stream(gto_handle* h, void* stream) {
   if (!h) return GTO_ERR_INVALID_ARG;
   HIPCHK(h, hipSetDevice(h->device));
@@ -852,7 +859,7 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
   if (h->scenes.empty()) return fail(h, GTO_ERR_NO_SCENE, "no scene has been set");
   HIPCHK(h, hipSetDevice(h->device));
   hipStream_t st = stream ? (hipStream_t)stream : h->stream;
-  if (!h->legacy) {
+  if (h->mode == GTO_MODE_SINGLE_LAUNCH) {
     TrajArgs a = {};
     a.scene_id = scene_id, a.qc = qc, a.goals = goals, a.n_goals = n_goals, a.standoff = standoff, a.base_pos = base_pos, a.Q0 = Q0;
     a.Q_out = Q_out, a.dQ_out = dQ_out, a.cost_out = cost_out, a.iters_out = iters_out, a.status_out = status_out;

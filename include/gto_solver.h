@@ -50,6 +50,12 @@ extern "C" {
 #define GTO_GRAD_CENTRAL_DIFF 0 /* gto/sdf_callback.py:90-114 JacFun numerics (shipped default) */
 #define GTO_GRAD_ZERO 1         /* what CasADi AD sees through floor()+gather in the reference   */
 
+/* how gto_solve_batch[_device] runs the Levenberg-Marquardt iterations (same algorithm, same results to round-off) */
+#define GTO_MODE_ROUNDS 0        /* default: rounds of two launches (evaluate / step) over at most 384 instances in flight,
+                                    every evaluation spread over the whole GPU: highest throughput, lowest latency */
+#define GTO_MODE_SINGLE_LAUNCH 1 /* one launch per call, one workgroup per instance runs its whole solve on chip: no
+                                    host in the loop (graph-capturable), counts the surface points it gathers */
+
 /* per-instance solver status (mirrors "return the iterate anyway", optas/solver.py:135) */
 #define GTO_STATUS_CONVERGED 0
 #define GTO_STATUS_MAX_ITER 1
@@ -222,6 +228,10 @@ int gto_solve_ik_batch(gto_handle* h, int32_t B, const int32_t* scene_id, const 
 int gto_solve_base_batch(gto_handle* h, int32_t B, int32_t n_max, const int32_t* n_goals, const double* qc,
                          const double* goals, double effort_weight, int32_t max_iter, double* y_out, double* q_out,
                          double* cost_out, int32_t* iters_out, int32_t* status_out);
+
+/* Select GTO_MODE_ROUNDS (default) or GTO_MODE_SINGLE_LAUNCH for the following solves (environment GTO_MODE sets the
+ * initial value). */
+int gto_set_mode(gto_handle* h, int32_t mode);
 
 /*
  * Bind the handle to the caller's HIP stream (e.g. torch.cuda.current_stream().cuda_stream): every

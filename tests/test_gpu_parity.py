@@ -25,9 +25,10 @@ def capi():
     return _capi
 
 
-def make_pair(capi, oracle_mod, prob, **opt_kw):
+def make_pair(capi, oracle_mod, prob, mode=0, **opt_kw):
     opts = oracle_mod.reference_opts(**opt_kw)
     h = capi.SolverHandle(prob.desc, prob.cfg["link_ee"], prob.cfg["link_gripper"], opts, device=0)
+    h.set_mode(mode)
     o = oracle_mod.Oracle(prob.desc, prob.cfg["link_ee"], prob.cfg["link_gripper"], opts)
     prob.finish(h.eval_fk)
     h.set_scene(*prob.scene_args())
@@ -160,10 +161,11 @@ def test_plan_cost_vs_oracle(capi, oracle_mod):
 
 
 # ------------------------------------------------------------------------------------------ the solve
+@pytest.mark.parametrize("mode", [0, 1])  # rounds of launches over slots | one launch per call (include/gto_solver.h)
 @pytest.mark.parametrize("max_iter", [0, 1, 2, 5])
-def test_solver_iterates_match_oracle_step_by_step(capi, oracle_mod, max_iter):
+def test_solver_iterates_match_oracle_step_by_step(capi, oracle_mod, max_iter, mode):
     prob = Problem("panda", B=5, scene_seed=3)
-    h, o = make_pair(capi, oracle_mod, prob, max_iter=max_iter)
+    h, o = make_pair(capi, oracle_mod, prob, mode=mode, max_iter=max_iter)
     Qg, dQg, fg, itg, stg = h.solve_batch(*prob.solve_args())
     Qo, dQo, fo, ito, sto = o.solve_batch(*prob.solve_args())
     np.testing.assert_array_equal(itg, ito)
@@ -177,9 +179,10 @@ def test_solver_iterates_match_oracle_step_by_step(capi, oracle_mod, max_iter):
 @pytest.mark.parametrize("robot,n_goals,standoff,grad_mode,scene_seed",
                          [("panda", 1, True, 0, 1), ("panda", 1, True, 0, 3), ("panda", 4, True, 0, 3),
                           ("panda", 1, False, 0, 2), ("panda", 1, True, 1, 3), ("fetch", 1, True, 0, 1)])
-def test_full_solve_matches_oracle(capi, oracle_mod, robot, n_goals, standoff, grad_mode, scene_seed):
+@pytest.mark.parametrize("mode", [0, 1])
+def test_full_solve_matches_oracle(capi, oracle_mod, robot, n_goals, standoff, grad_mode, scene_seed, mode):
     prob = Problem(robot, B=6, scene_seed=scene_seed, n_goals=n_goals, use_standoff=standoff)
-    h, o = make_pair(capi, oracle_mod, prob, max_iter=60, grad_mode=grad_mode)
+    h, o = make_pair(capi, oracle_mod, prob, mode=mode, max_iter=60, grad_mode=grad_mode)
     Qg, dQg, fg, itg, stg = h.solve_batch(*prob.solve_args())
     Qo, dQo, fo, ito, sto = o.solve_batch(*prob.solve_args())
     np.testing.assert_array_equal(itg, ito)
@@ -198,10 +201,11 @@ def test_full_solve_matches_oracle(capi, oracle_mod, robot, n_goals, standoff, g
     h.close()
 
 
-def test_ragged_batches_and_scene_table(capi, oracle_mod):
+@pytest.mark.parametrize("mode", [0, 1])
+def test_ragged_batches_and_scene_table(capi, oracle_mod, mode):
     """B not a multiple of 8, several scenes, per-instance goal counts, then the empty batch."""
     prob = Problem("panda", B=11, scene_seed=1, n_goals=3)
-    h, o = make_pair(capi, oracle_mod, prob, max_iter=8)
+    h, o = make_pair(capi, oracle_mod, prob, mode=mode, max_iter=8)
     prob2 = Problem("panda", B=1, scene_seed=2)
     for s in (h, o):
         s.set_scene(9, prob2.scene.c_all, None, prob2.scene.shape, prob2.scene.origin, prob2.scene.res)
@@ -235,7 +239,7 @@ def test_slots_hand_over_to_waiting_instances(capi, oracle_mod, monkeypatch, slo
     every instance gets bit-for-bit the trajectory it gets with all instances in flight from the start, and the
     oracle's iteration counts and status."""
     prob = Problem("panda", B=13, scene_seed=2, n_goals=2)
-    h, o = make_pair(capi, oracle_mod, prob, max_iter=12)  # default: 256 slots, the whole batch in flight
+    h, o = make_pair(capi, oracle_mod, prob, max_iter=12)  # default: 384 slots, the whole batch in flight
     ref = h.solve_batch(*prob.solve_args())
     monkeypatch.setenv("GTO_SLOTS", str(slots))
     h2 = capi.SolverHandle(prob.desc, prob.cfg["link_ee"], prob.cfg["link_gripper"], oracle_mod.reference_opts(max_iter=12), device=0)
