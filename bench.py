@@ -5,19 +5,28 @@ One "step" = one pass of the hot path over one batch: solving B independent (sce
 trajectory problems of BASELINE.json configs[1] (Panda 7-DoF, T=50 waypoints, ~5k surface points,
 128^3 float32 cost field, 64 candidate goal grasps of one scene) with the batched Gauss-Newton/LM
 solver behind the C ABI (gto_solve_batch_device: inputs already resident in HBM).
-N GPUs = N ranks, each solving its own scene x 64 grasps (weak scaling, no data-path collective).
-The K timed steps run through grasptrajopt_amd.parallel.BatchPipeline with --pipeline D steps in flight
-per GPU (one solver handle + stream + host thread each): a single batch of 64 is a latency-bound chain
-of launches that leaves most CUs idle, and consecutive batches are independent.  The strictly serial
-rate (D = 1) is reported next to it in "pipeline".
+N GPUs = N ranks (`python bench.py --gpus N` spawns them itself when it is not already running under
+torch.distributed.run), each solving its own scene x 64 grasps (weak scaling, no data-path collective);
+with N > 1 the scene-sharded workload of BASELINE configs[3] (many scenes x 8 grasps, grouped by scene,
+results all_gathered over RCCL) is measured next to it ("scene_sharded").
+The K timed steps run through grasptrajopt_amd.parallel.BatchPipeline with --pipeline D lanes per GPU
+(one solver handle + stream + host thread each, every lane its own grasp sets): a single batch of 64 is a
+latency-bound chain of launches that leaves most CUs idle, and consecutive batches are independent.  The
+strictly serial rate (one batch per call) is reported next to it in "pipeline".
 
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline      dominant kernel (k_obstacle_gram), algorithmic field-gather bytes / HIP-event time
-  cpu_baseline  the CPU oracle (same algorithm, FP64, OpenMP over instances) on a bounded sample
+  roofline      dominant kernel: bytes of the surface points it ACTUALLY gathered (device counter) over the
+                HIP-event time of its launches; the reference's per-point work that the broad phase proves
+                to be exact zeros is reported as alg_bytes_skipped_frac, not priced
+  cpu_baseline  the CPU oracle (same algorithm, FP64, OpenMP over instances) on a bounded sample, with the
+                same quality block as the GPU result
+Exit code 3 if the quality gate fails (joint limits, plan cost against the seed).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,6 +36,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+FP64_VALU_PEAK_TFLOPS = 78.6  # same guide: half the FP32 vector rate
 
 
 def plan_calls(n, lanes, merge):
@@ -38,6 +48,49 @@ def plan_calls(n, lanes, merge):
     if L % lanes and n >= lanes * (L // lanes + 1):
         L = lanes * (L // lanes + 1)
     return [n // L + (1 if i < n % L else 0) for i in range(L)]
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` outside torch.distributed.run: launch N ranks on this node (one per GPU) the way the
+    driver does and hand their output through."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"[bench] --gpus {n}: spawning {n} ranks: {' '.join(cmd[1:8])} ...", file=sys.stderr)
+    return subprocess.call(cmd)
+
+
+def quality_block(desc, cfg, h, sid, Q, RT, Q0, iters, status, max_iter, in_collision_c=0.01):
+    """SURVEY.md 8d quality gate on solved trajectories Q (n, ndof, T): joint limits, goal pose against the IK thresholds
+    of examples/pybullet_gto_planning.py:262, compute_plan_cost against the seed, and the evaluator's collision
+    statistic (examples/pybullet_evaluate_plans.py:219-239: a waypoint with more than 5 body points inside an obstacle;
+    inside <=> cost > epsilon / 2 on the synthetic field) on the first 64 plans."""
+    oi = desc.opt_index
+    viol = float(np.maximum(desc.lower[oi][None, :, None] - Q[:, oi], Q[:, oi] - desc.upper[oi][None, :, None]).max())
+    fe = desc.frame_index(cfg["link_ee"])
+    Tf = h.eval_fk(Q[:, :, -1])[:, fe]
+    err_pos = np.linalg.norm(Tf[:, :3, 3] - RT[:, :3, 3], axis=1)
+    cosang = (np.einsum("bij,bij->b", Tf[:, :3, :3], RT[:, :3, :3]) - 1.0) / 2.0
+    err_rot = np.degrees(np.arccos(np.clip(cosang, -1, 1)))
+    seed_cost, _ = h.plan_cost(sid, Q0, [0, 0, 0])
+    sol_cost, _ = h.plan_cost(sid, Q, [0, 0, 0])
+    ns = min(64, Q.shape[0])
+    moving = desc.link_is_moving()[desc.point_link]
+    hit = 0
+    for i in range(ns):
+        _, _, val, _ = h.eval_points(sid, Q[i].T, [0.0, 0.0, 0.0], use_obs=True)
+        hit += int((((val > in_collision_c) & moving[None, :]).sum(axis=1) > 5).any())
+    ok = (err_pos < 0.01) & (err_rot < 5)
+    miss = ~ok
+    return {"max_joint_limit_violation": viol, "goal_err_pos_max_m": round(float(err_pos.max()), 5),
+            "goal_err_rot_max_deg": round(float(err_rot.max()), 3), "goal_ok_frac": round(float(ok.mean()), 3),
+            "plan_cost_le_seed_frac": round(float((sol_cost <= seed_cost + 1e-12).mean()), 3),
+            "plans_in_collision_frac": round(hit / ns, 3), "plans_checked_for_collision": ns,
+            # how the instances that miss the 1 cm / 5 deg goal thresholds ended: at the iteration cap or converged
+            "goal_miss_ended_at_max_iter_frac": round(float((iters[miss] >= max_iter).mean()), 3) if miss.any() else None,
+            "goal_miss_converged_frac": round(float((status[miss] == 0).mean()), 3) if miss.any() else None}
 
 
 def main():
@@ -52,14 +105,19 @@ def main():
     ap.add_argument("--max-iter", type=int, default=100, help="iteration cap (reference IPOPT cap: 100)")
     ap.add_argument("--robot", default="panda_5k")
     ap.add_argument("--grid", type=int, default=128)
+    ap.add_argument("--mode", choices=["rounds", "single"], default="rounds", help="solver mode (include/gto_solver.h GTO_MODE_*)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--merged-launches-only", action="store_true",
                     help="skip the one-batch-per-launch passes (serial latency, host API): every launch of the run then has the "
                          "timed region's size, which is what the per-launch PMC averages of tools/pmc_pass.sh need")
     ap.add_argument("--cpu-seconds", type=float, default=16.0, help="target duration of the CPU-baseline sample")
-    ap.add_argument("--traffic", type=float, default=None,
-                    help="HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes (see profiles/)")
+    ap.add_argument("--scenes-per-gpu", type=int, default=32,
+                    help="scene-sharded leg (N > 1, or --scene-sharded): scenes per GPU, 8 grasps each (BASELINE configs[3] is 256 per GPU)")
+    ap.add_argument("--scene-sharded", action="store_true", help="run the scene-sharded leg also on one GPU")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(spawn_ranks(args.gpus))
 
     # the HIP runtime multiplexes streams onto this many hardware queues (default 4); the pipeline lanes
     # must not share one, or their launches serialise
@@ -70,9 +128,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if rank == 0:
-            print(f"[bench] WORLD_SIZE={world} != --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
+    if world != args.gpus and rank == 0:
+        print(f"[bench] WORLD_SIZE={world} != --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the GTO solve path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -85,7 +142,7 @@ def main():
     if not os.path.exists(g.HIP_LIB):
         g.build()
     from grasptrajopt_amd import _capi, synthetic as syn
-    from grasptrajopt_amd.parallel import BatchPipeline, shard_range
+    from grasptrajopt_amd.parallel import BatchPipeline, shard_by_scene, shard_range, solve_sharded
     from grasptrajopt_amd.robot_desc import load_builtin
 
     fetch = args.robot.startswith("fetch")  # BASELINE configs[2]: --robot fetch --batch 256 (shelf-height table)
@@ -96,22 +153,25 @@ def main():
     T, ndof, B = opts.T, desc.ndof, args.batch
     D, M = max(1, args.pipeline), max(1, args.merge)
     slots = int(os.environ.get("GTO_SLOTS", "384"))  # instances a solver call keeps in flight (gto_api.hip)
+    mode = _capi.SolverHandle.MODE_SINGLE_LAUNCH if args.mode == "single" else _capi.SolverHandle.MODE_ROUNDS
+    kernel_name = "k_traj_solve" if args.mode == "single" else "k_obstacle_gram"
 
     # this rank's shard of the global problem list: scene = global rank id, 64 grasps each
     lo, hi = shard_range(world * B, rank, world)
     assert hi - lo == B
     scene_seed = lo // B
     res = 2.24 / args.grid  # covers the 2.24 m reach box (0.0175 m at 128^3)
-    sc = syn.make_scene(scene_seed, n=args.grid, res=res, origin=(-0.3, -1.12, 0.0) if fetch else (-0.4, -1.12, -0.4),
-                        table_z=0.45 if fetch else -0.03)
+    origin = (-0.3, -1.12, 0.0) if fetch else (-0.4, -1.12, -0.4)
+    table_z = 0.45 if fetch else -0.03
+    sc = syn.make_scene(scene_seed, n=args.grid, res=res, origin=origin, table_z=table_z)
 
-    # D pipeline lanes: each one solver handle bound to ONE stream of its own, with its own copy of M batches
-    # (M consecutive steps, distinct goal sets) in HBM and its own outputs; a launch solves m <= M of them at
-    # once (grasptrajopt_amd.parallel.BatchPipeline runs the lanes concurrently)
+    # D pipeline lanes: each one solver handle bound to ONE stream of its own, with its own M batches (M consecutive
+    # steps, grasp sets of its own) in HBM and its own outputs; a call solves m <= M of them at once
     class Lane:
         def __init__(self, first=None):
             self.stream = torch.cuda.Stream(dev)
             self.h = _capi.SolverHandle(desc, cfg["link_ee"], cfg["link_gripper"], opts, device=local_rank, n_gripper_points=100)
+            self.h.set_mode(mode)
             self.h.set_stream(self.stream.cuda_stream)
             if first is None:
                 self.h.set_scene(0, sc.c_all, sc.c_obs, sc.shape, sc.origin, sc.res)
@@ -121,6 +181,7 @@ def main():
         def upload(self, qc, RT, S, base, Q0):
             n = qc.shape[0]  # M * B instances, batch m in rows [m B, (m+1) B)
             t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(dt).to(dev)
+            self.host = (np.zeros(n, np.int32), qc, RT.reshape(n, 1, 16), np.ones(n, np.int32), S, base, Q0)
             self.inp = [torch.zeros(n, dtype=torch.int32, device=dev), t(qc, torch.float64), t(RT.reshape(n, 1, 16), torch.float64),
                         torch.ones(n, dtype=torch.int32, device=dev), t(S, torch.float64), t(base, torch.float64), t(Q0, torch.float64)]
             self.d_Q = torch.empty((n, ndof, T), dtype=torch.float64, device=dev)
@@ -131,9 +192,13 @@ def main():
             self.bufs = self.inp + [self.d_Q, self.d_dQ, self.d_cost, self.d_it, self.d_st]
 
         def step(self, m=1, first=0):
-            """One launch over batches first .. first+m-1 of this lane."""
+            """One call over batches first .. first+m-1 of this lane (device-resident entry point)."""
             ptrs = [x.data_ptr() + first * B * x.stride(0) * x.element_size() for x in self.bufs]
             self.h.solve_batch_device(m * B, 1, *ptrs, self.stream.cuda_stream)
+
+        def host_step(self, m=1, first=0):
+            """The same call through the host-pointer entry point (H2D / D2H of the per-instance data included)."""
+            return self.h.solve_batch(*[a[first * B:(first + m) * B] for a in self.host])
 
     lanes = [Lane()]
     lanes += [Lane(lanes[0]) for _ in range(D - 1)]
@@ -147,16 +212,19 @@ def main():
         return (val * moving[None, :]).sum(axis=1)
 
     zlim = (0.55, 1.2) if fetch else (0.08, 0.7)
-    sets = [syn.make_goals(desc, h.eval_fk, cfg["link_ee"], B, seed=scene_seed + 1009 * m, collision_cost=goal_collision_cost, zlim=zlim)
-            for m in range(M)]  # M different grasp sets in the same scene: the batches of M consecutive steps
-    RT, qg = np.concatenate([x[0] for x in sets]), np.concatenate([x[1] for x in sets])
     NB = M * B
     qc = np.tile(np.array(cfg["default_pose"]), (NB, 1))
-    Q0 = np.stack([syn.make_seed(qc[b], qg[b], T, desc.param_index) for b in range(NB)])
     S = np.tile(syn.standoff_pose(-0.1, cfg["axis_standoff"]).reshape(1, 16), (NB, 1))
     base = np.zeros((NB, 3))
-    for ln in lanes:
-        ln.upload(qc, RT, S, base, Q0)
+    lane_data = []
+    for d_, ln in enumerate(lanes):  # every lane its own M grasp sets of the scene: nothing is solved twice at the same time
+        sets = [syn.make_goals(desc, h.eval_fk, cfg["link_ee"], B, seed=scene_seed + 1009 * m + 500009 * d_,
+                               collision_cost=goal_collision_cost, zlim=zlim) for m in range(M)]
+        RT_, qg_ = np.concatenate([x[0] for x in sets]), np.concatenate([x[1] for x in sets])
+        Q0_ = np.stack([syn.make_seed(qc[b], qg_[b], T, desc.param_index) for b in range(NB)])
+        ln.upload(qc, RT_, S, base, Q0_)
+        lane_data.append((RT_, Q0_))
+    RT, Q0 = lane_data[0]
     torch.cuda.synchronize(dev)
 
     def barrier():
@@ -166,10 +234,9 @@ def main():
 
     launch_plan = lambda n: plan_calls(n, D, M)
 
-    def run_steps(pipe, n):
-        futs = [pipe.submit("step", m) for m in launch_plan(n)]
-        for f in futs:
-            f.result()
+    def run_steps(pipe, n, method="step"):
+        futs = [pipe.submit(method, m) for m in launch_plan(n)]
+        return [f.result() for f in futs]
 
     pipe = BatchPipeline(lanes)
     run_steps(pipe, args.warmup * D * M)  # every lane sees >= W warmup launches
@@ -179,13 +246,36 @@ def main():
     run_steps(pipe, args.steps)
     barrier()
     elapsed, host_cpu = time.perf_counter() - t0, time.process_time() - c0
+    # ---- SURVEY.md 8d's literal metric: the same K steps through the host-pointer entry point on the same lanes
+    host_pipe_rate = None
+    if not args.merged_launches_only:
+        run_steps(pipe, min(args.steps, D * M), "host_step")
+        barrier()
+        th = time.perf_counter()
+        run_steps(pipe, args.steps, "host_step")
+        barrier()
+        host_pipe_rate = B * args.steps / (time.perf_counter() - th)
     pipe.close()
-    merged_Q, merged_it = lanes[0].d_Q.clone(), lanes[0].d_it.clone()
-    same = all(bool(torch.equal(l.d_Q, merged_Q)) and bool(torch.equal(l.d_it, merged_it)) for l in lanes[1:])
-
-    # ---- the same K steps strictly one after the other, one batch per launch, on one lane: per-batch
-    # latency (and a check that a batch solved alone equals the batch solved inside a merged launch)
     ln0 = lanes[0]
+    # a lane's results do not depend on what the other lanes do: lane 0 solves lane 1's batches again, alone on the GPU
+    lanes_reproducible = None
+    if D > 1:
+        m1 = max(launch_plan(args.steps))
+        ref_Q, ref_it = lanes[1].d_Q[:m1 * B].clone(), lanes[1].d_it[:m1 * B].clone()
+        keep = [x.clone() for x in ln0.inp]
+        for dst, src in zip(ln0.inp, lanes[1].inp):
+            dst.copy_(src)
+        ln0.step(m1)
+        barrier()
+        lanes_reproducible = bool(torch.equal(ln0.d_Q[:m1 * B], ref_Q)) and bool(torch.equal(ln0.d_it[:m1 * B], ref_it))
+        for dst, src in zip(ln0.inp, keep):
+            dst.copy_(src)
+    ln0.step(max(launch_plan(args.steps)))
+    barrier()
+    merged_Q, merged_it = ln0.d_Q.clone(), ln0.d_it.clone()
+
+    # ---- the same K steps strictly one after the other, one batch per call, on one lane: per-batch
+    # latency (and a check that a batch solved alone equals the batch solved inside a merged call)
     barrier()
     ts = time.perf_counter()
     merged_equals_single = None
@@ -193,20 +283,23 @@ def main():
         for k in range(args.steps):
             ln0.step(1, k % M)
         barrier()
-        covered = min(args.steps, M) * B
+        covered = min(args.steps, M, max(launch_plan(args.steps))) * B
         merged_equals_single = bool(torch.equal(ln0.d_Q[:covered], merged_Q[:covered])) and bool(torch.equal(ln0.d_it[:covered], merged_it[:covered]))
     serial_elapsed = time.perf_counter() - ts
-    # ---- the launches of the timed region once more, alone on the GPU, with HIP events around every launch
+    # ---- the calls of the timed region once more, alone on the GPU, with HIP events around every launch
     # of the dominant kernel (on its launch stream) for the roofline: a launch's duration is then the
-    # kernel's own and matches the rocprofv3 summary
+    # kernel's own and matches the rocprofv3 summary; the kernel counts the surface points it gathers
     h.set_profiling(True)
-    kern_ms, kern_launches, prof_steps = 0.0, 0, 0
+    kern_ms, kern_launches, prof_steps, gathered, tested = 0.0, 0, 0, 0, 0
     plan = launch_plan(args.steps)
     for m in plan:
         ln0.step(m)
         ms, nl = h.last_kernel_time()
+        pts, tst = h.last_kernel_work()
         kern_ms += ms
         kern_launches += nl
+        gathered += pts
+        tested += tst
         prof_steps += m
     barrier()
     h.set_profiling(False)
@@ -214,15 +307,14 @@ def main():
     barrier()
     d_it, d_st, d_cost, d_Q = ln0.d_it, ln0.d_st, ln0.d_cost, ln0.d_Q
 
-    # the same solve through the host-pointer entry point (H2D/D2H of per-instance data included)
+    # one batch per call through the host-pointer entry point (latency of the drop-in call)
     host_rate = None
     if rank == 0 and not args.merged_launches_only:
         hs = max(2, min(5, args.steps))
-        hargs = (0, qc[:B], RT[:B].reshape(B, 1, 16), 1, S[:B], base[:B], Q0[:B])
-        h.solve_batch(*hargs)
+        ln0.host_step(1)
         th = time.perf_counter()
         for _ in range(hs):
-            h.solve_batch(*hargs)
+            ln0.host_step(1)
         host_rate = B * hs / (time.perf_counter() - th)
 
     iters = d_it.cpu().numpy().astype(np.int64)
@@ -230,7 +322,8 @@ def main():
     cost = d_cost.cpu().numpy()
     Qsol = d_Q.cpu().numpy()
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    # iterations done inside the timed region: a launch of m steps solves this lane's batches 0 .. m-1
+    # iterations done inside the timed region: a call of m steps solves a lane's batches 0 .. m-1 (lane 0's counts stand
+    # for the other lanes' grasp sets of the same scene)
     per_batch_it = iters.reshape(M, B).sum(axis=1)
     it_timed = float(sum(per_batch_it[:m].sum() for m in plan))
     it_sum = torch.tensor([it_timed], dtype=torch.float64, device=dev)
@@ -242,40 +335,96 @@ def main():
     value = total_traj / elapsed
     iters_per_s = float(it_sum.item()) / elapsed
 
-    if rank == 0:
-        # quality gate on this rank's batch
-        oi = desc.opt_index
-        viol = float(np.maximum(desc.lower[oi][None, :, None] - Qsol[:, oi], Qsol[:, oi] - desc.upper[oi][None, :, None]).max())
-        fe = desc.frame_index(cfg["link_ee"])
-        Tf = h.eval_fk(Qsol[:, :, -1])[:, fe]
-        err_pos = np.linalg.norm(Tf[:, :3, 3] - RT[:, :3, 3], axis=1)
-        cosang = (np.einsum("bij,bij->b", Tf[:, :3, :3], RT[:, :3, :3]) - 1.0) / 2.0
-        err_rot = np.degrees(np.arccos(np.clip(cosang, -1, 1)))
-        seed_cost, _ = h.plan_cost(0, np.clip(Q0, None, None), [0, 0, 0])
-        sol_cost, _ = h.plan_cost(0, Qsol, [0, 0, 0])
+    # ---- BASELINE configs[3]: many scenes x 8 grasps, instances grouped by scene onto ranks, solved through the
+    # host-pointer API, results all_gathered (RCCL); every instance of a call reads a different field
+    scene_sharded = None
+    if world > 1 or args.scene_sharded:
+        SG, SP = 8, args.scenes_per_gpu
+        n_sc = SP * world
+        sid_all = np.repeat(np.arange(n_sc, dtype=np.int32), SG)
+        owner = shard_by_scene(sid_all, world)
+        mine_sc = np.unique(sid_all[owner == rank])
+        hs_ = _capi.SolverHandle(desc, cfg["link_ee"], cfg["link_gripper"], opts, device=local_rank, n_gripper_points=100)
+        hs_.set_mode(mode)
+        rng_goal = {}
+        for s_ in mine_sc:
+            scs = syn.make_scene(100 + int(s_), n=args.grid, res=res, origin=origin, table_z=table_z)
+            hs_.set_scene(int(s_), scs.c_all, scs.c_obs, scs.shape, scs.origin, scs.res)
 
-        # roofline of the dominant kernel: algorithmic bytes (7 float32 gathers per
-        # surface point and free waypoint) / HIP-event time of its launches in the timed region
+            def cc(q, s_=int(s_)):
+                _, _, val, _ = hs_.eval_points(s_, q, [0.0, 0.0, 0.0], use_obs=True)
+                return (val * moving[None, :]).sum(axis=1)
+            rng_goal[int(s_)] = syn.make_goals(desc, hs_.eval_fk, cfg["link_ee"], SG, seed=7000 + int(s_), collision_cost=cc, zlim=zlim)
+        # every rank needs the arguments of the whole list only for its own shard: the others' rows are never read
+        nI = n_sc * SG
+        RTa, qga = np.tile(np.eye(4), (nI, 1, 1)), np.tile(np.array(cfg["default_pose"]), (nI, 1))
+        for s_, (r_, q_) in rng_goal.items():
+            RTa[s_ * SG:(s_ + 1) * SG], qga[s_ * SG:(s_ + 1) * SG] = r_, q_
+        qca = np.tile(np.array(cfg["default_pose"]), (nI, 1))
+        Q0a = np.stack([syn.make_seed(qca[i], qga[i], T, desc.param_index) for i in range(nI)])
+        Sa = syn.standoff_pose(-0.1, cfg["axis_standoff"])
+        sargs = (sid_all, qca, RTa.reshape(nI, 1, 16), 1, Sa, [0.0, 0.0, 0.0], Q0a)
+        solve_sharded(hs_.solve_batch, *sargs, rank=rank, world=world, assignment=owner)  # warm-up
+        barrier()
+        tss = time.perf_counter()
+        idx, Qa, _, ca, ia, sa = solve_sharded(hs_.solve_batch, *sargs, rank=rank, world=world, assignment=owner)
+        barrier()
+        els = torch.tensor([time.perf_counter() - tss], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(els, op=dist.ReduceOp.MAX)
+        oi_ = desc.opt_index
+        scene_sharded = {"workload": f"BASELINE configs[3]: {n_sc} scenes x {SG} grasps, grouped by scene onto {world} GPU(s) "
+                                     f"({SP} scenes, {SP * 0.148 * (args.grid / 128) ** 3:.1f} GB of fields per GPU), host-pointer API, results "
+                                     + ("all_gathered over RCCL" if world > 1 else "kept on the one rank"),
+                         "instances": int(nI), "trajectories_per_s": round(nI / float(els.item()), 1),
+                         "all_instances_returned": bool(len(idx) == nI), "iters_mean": round(float(ia.mean()), 2),
+                         "max_joint_limit_violation": float(np.maximum(desc.lower[oi_][None, :, None] - Qa[:, oi_], Qa[:, oi_] - desc.upper[oi_][None, :, None]).max())}
+        hs_.close()
+
+    rc = 0
+    if rank == 0:
+        quality = quality_block(desc, cfg, h, 0, Qsol, RT, Q0, iters, status, args.max_iter)
+        quality["f_mean"] = round(float(cost.mean()), 5)
+        # objective split of the instances that miss the goal thresholds: the velocity term outweighs the goal term there
+        fgo, _, fve, _ = h.eval_objective(0, RT.reshape(NB, 1, 16), 1, S[0].reshape(4, 4), [0.0, 0.0, 0.0], Qsol)
+        quality["f_goal_mean"], quality["f_vel_mean"] = round(float(fgo.mean()), 5), round(float(fve.mean()), 5)
+        gate_ok = quality["max_joint_limit_violation"] <= 1e-8 and quality["plan_cost_le_seed_frac"] >= 0.95
+        quality["gate"] = "pass" if gate_ok else "FAIL"
+        if not gate_ok:
+            rc = 3
+
+        # roofline of the dominant kernel.  SURVEY.md 8d prices the reference's work at 7 float32 (28 B) per surface point
+        # and free waypoint; the broad phase proves most of those gathers to be exact zeros and skips them, so only the
+        # points the kernel actually looked up (device counter) are priced: 28 algorithmic bytes each (the kernel reads one
+        # 32-B voxel record per point instead of seven floats) over the HIP-event time of the kernel's launches.
         P = desc.n_points
-        bytes_per_inst_launch = (T - 2) * P * 28
         per_batch_ev = (iters + 1).reshape(M, B).sum(axis=1)  # each instance is evaluated iters+1 times per solve
         evals = float(sum(per_batch_ev[:m].sum() for m in plan))
-        alg_bytes = evals * bytes_per_inst_launch
+        full_points = evals * (T - 2) * P
         avg_launch_us = 1e3 * kern_ms / max(kern_launches, 1)
-        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
-        traffic = args.traffic
+        achieved = gathered * 28 / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+        traffic = issue = None
         tj = os.path.join(ROOT, "profiles", "traffic.json")
-        if traffic is None and os.path.exists(tj):  # quoted only for the workload and launch size it was measured on
-            tr = json.load(open(tj))
-            if (args.robot, args.grid, B * max(plan), slots) == (tr.get("robot"), tr.get("grid"), tr.get("instances_per_call"), tr.get("slots")):
-                traffic = tr.get("k_obstacle_gram_hbm_bytes_per_launch")
-        roofline = {"bound": "hbm", "kernel": "k_obstacle_gram", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+        if os.path.exists(tj):  # PMC figures are quoted only for the workload, mode and call size they were measured on
+            for tr in json.load(open(tj)).get("entries", []):
+                if (args.robot, args.grid, B * max(plan), slots, args.mode) == (tr.get("robot"), tr.get("grid"), tr.get("instances_per_call"),
+                                                                                 tr.get("slots"), tr.get("mode", "rounds")):
+                    traffic = tr.get("hbm_bytes_per_launch")
+                    issue = tr.get("issue")
+        roofline = {"bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "alg_bytes_per_launch": round(alg_bytes / max(kern_launches, 1)),
+                    "bytes_per_unit": 28, "unit_of_work": "surface point looked up in a cost field (value + 6 neighbours, SURVEY.md 8d)",
+                    "points_gathered_per_launch": round(gathered / max(kern_launches, 1)),
+                    "alg_bytes_per_launch": round(gathered * 28 / max(kern_launches, 1)),
+                    "alg_bytes_skipped_frac": round(1.0 - gathered / max(full_points, 1.0), 4),
+                    "chunk_tests_per_launch": round(tested / max(kern_launches, 1)) if tested else None,
                     "avg_launch_us": round(avg_launch_us, 2), "launches": kern_launches,
                     "instances_per_call": B * max(plan), "slots": slots,
+                    "issue": issue,
                     "measured": "HIP events on the launch stream around every launch of the kernel while ONE lane repeats the timed "
-                                "region's solver calls right after it, so that launches of other lanes do not stretch the durations"}
+                                "region's solver calls right after it, so that launches of other lanes do not stretch the durations; "
+                                "points gathered: device counter of the same launches; traffic / issue: rocprofv3 PMC passes of the "
+                                "same call size (profiles/traffic.json)"}
 
         cpu_baseline = None
         if not args.no_cpu_baseline:
@@ -287,7 +436,7 @@ def main():
             # pilot on the batch itself, then repeat it so the timed sample is ~10-20 s of CPU work
             tc = time.perf_counter()
             cq, cr, cs_, cb, c0 = qc[:B], RT[:B].reshape(B, 1, 16), S[:B], base[:B], Q0[:B]  # the first batch
-            Qo, _, fo, ito, _ = o.solve_batch(0, cq, cr, 1, cs_, cb, c0, n_threads=cores)
+            Qo, _, fo, ito, sto = o.solve_batch(0, cq, cr, 1, cs_, cb, c0, n_threads=cores)
             t_pilot = time.perf_counter() - tc
             reps = int(min(max(np.ceil(args.cpu_seconds / max(t_pilot, 1e-3)), 1), 64))
             tile = lambda a: np.concatenate([a] * reps)
@@ -308,7 +457,11 @@ def main():
                             "single_core_value": round(ns / tcpu / cores, 4),
                             "single_thread": {"value": round(n1 / t1, 4), "sample": f"the first {n1} instances on one thread, {t1:.1f} s"},
                             "max_abs_dQ_vs_gpu": float(np.abs(Qo - Qsol[:B]).max()),
-                            "iters_equal_gpu": bool(np.array_equal(ito, iters[:B]))}
+                            "iters_equal_gpu": bool(np.array_equal(ito, iters[:B])),
+                            # the quality block of the CPU port on the same 64 instances, next to the GPU's on them: what the
+                            # goal misses are a property of (objective and weights) shows in both
+                            "quality": quality_block(desc, cfg, h, 0, Qo, RT[:B], Q0[:B], ito.astype(np.int64), sto, args.max_iter),
+                            "quality_gpu_same_instances": quality_block(desc, cfg, h, 0, Qsol[:B], RT[:B], Q0[:B], iters[:B], status[:B], args.max_iter)}
 
         out = {
             "metric": "grasp trajectories/sec", "value": round(value, 2), "unit": "trajectories/s",
@@ -319,34 +472,35 @@ def main():
                                     f"BASELINE configs[1]: Panda 7-DoF, 1 scene x {B} goal grasps per GPU, T={int(T)}, ") +
                                    f"{P} surface points, {args.grid}^3 f32 SDF cost field",
                        "batch_per_gpu": B, "T": int(T), "surface_points": int(P), "grid": args.grid,
-                       "max_iter": args.max_iter, "steps_per_call": M, "lanes": D,
+                       "max_iter": args.max_iter, "steps_per_call": M, "lanes": D, "solver_mode": args.mode,
                        "parallelism": f"instances sharded over {world} GPU(s), no collective"},
             "pipeline": {"lanes": D, "steps_per_call": M, "slots_per_lane": slots,
                          "calls_in_steps": sorted(set(plan)),
-                         "what": "per GPU: `lanes` solver handles (HIP stream + host thread each); every solver call of a lane gets "
-                                 "`steps_per_call` consecutive steps' batches (different grasp sets of the scene) and keeps at most "
+                         "what": "per GPU: `lanes` solver handles (HIP stream + host thread each, every lane its own grasp sets); every "
+                                 "solver call of a lane gets `steps_per_call` consecutive steps' batches and keeps at most "
                                  "`slots_per_lane` of their instances in flight, handing a finished instance's slot to the next",
                          "serial_ms_per_step": None if args.merged_launches_only else round(1e3 * serial_elapsed / args.steps, 3),
                          "serial_trajectories_per_s": None if args.merged_launches_only else round(B * args.steps / serial_elapsed, 2),
                          "host_cpu_cores_busy": round(host_cpu / elapsed, 2),
-                         "lanes_bit_identical": same, "merged_equals_single_batch_solves": merged_equals_single},
+                         "lane_results_reproducible_alone": lanes_reproducible, "merged_equals_single_batch_solves": merged_equals_single},
             "sqp_iters_per_s": round(iters_per_s, 1),
+            # SURVEY.md 8d's metric: gto_solve_batch with host pointers, H2D / D2H of the per-instance data inside the timing,
+            # through the same lanes and call sizes as the timed region; and one batch per call
+            "host_api_pipelined_trajectories_per_s": None if host_pipe_rate is None else round(world * host_pipe_rate, 2),
             "host_api_trajectories_per_s": None if host_rate is None else round(host_rate, 2),
             "iters_mean": round(float(iters.mean()), 2), "iters_max": int(iters.max()),
             "status_counts": {str(k): int((status == k).sum()) for k in np.unique(status)},
-            "quality": {"max_joint_limit_violation": viol, "goal_err_pos_max_m": round(float(err_pos.max()), 5),
-                        "goal_err_rot_max_deg": round(float(err_rot.max()), 3),
-                        "goal_ok_frac": round(float(((err_pos < 0.01) & (err_rot < 5)).mean()), 3),
-                        "plan_cost_le_seed_frac": round(float((sol_cost <= seed_cost + 1e-12).mean()), 3),
-                        "f_mean": round(float(cost.mean()), 5)},
+            "quality": quality,
             "reference_published": "0.098 trajectories/s (Panda tabletop, IPOPT on unknown CPU; BASELINE.md section 1)",
-            "roofline": roofline, "cpu_baseline": cpu_baseline,
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "scene_sharded": scene_sharded,
         }
         print(json.dumps(out))
     for ln in reversed(lanes):  # the owner of the shared scene goes last
         ln.h.close()
     if world > 1:
         dist.destroy_process_group()
+    if rc:
+        raise SystemExit(rc)
 
 
 if __name__ == "__main__":

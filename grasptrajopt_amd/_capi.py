@@ -134,6 +134,7 @@ def load_library(path: Optional[str] = None):
     lib.gto_solve_batch_device.argtypes = solve_args + [C.c_void_p]
     lib.gto_last_kernel_time.argtypes = [H, _pd, _pi]
     lib.gto_set_profiling.argtypes = [H, C.c_int32]
+    lib.gto_last_kernel_work.argtypes = [H, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.gto_set_stream.argtypes = [H, C.c_void_p]
     lib.gto_set_mode.argtypes = [H, C.c_int32]
     lib.gto_share_scene.argtypes = [H, C.c_int32, H, C.c_int32]
@@ -149,8 +150,8 @@ def load_library(path: Optional[str] = None):
     lib.gto_depth_sdf_cost.argtypes = [C.c_int, _pf, C.c_int32, C.c_int32, _pd, _pd, _pd, _pd, _pu8, C.c_double, _pd, C.c_int64,
                                        C.c_float, C.c_float, _pf, _pu8, _pf, _pd, _pu8]
     for fn in ("gto_create", "gto_set_opts", "gto_set_scene", "gto_drop_scene", "gto_solve_batch",
-               "gto_solve_batch_device", "gto_last_kernel_time", "gto_set_profiling", "gto_set_stream", "gto_set_mode", "gto_share_scene", "gto_eval_fk",
-               "gto_eval_points", "gto_eval_objective", "gto_eval_obstacle_normal_eq", "gto_plan_cost", "gto_solve_ik_batch",
+               "gto_solve_batch_device", "gto_last_kernel_time", "gto_last_kernel_work", "gto_set_profiling", "gto_set_stream", "gto_set_mode", "gto_share_scene",
+               "gto_eval_fk", "gto_eval_points", "gto_eval_objective", "gto_eval_obstacle_normal_eq", "gto_plan_cost", "gto_solve_ik_batch",
                "gto_solve_base_batch", "gto_eval_base_objective", "gto_depth_sdf_cost"):
         getattr(lib, fn).restype = C.c_int
     if path is None:
@@ -161,7 +162,8 @@ def load_library(path: Optional[str] = None):
 EXPORTED_SYMBOLS = (
     "gto_default_opts", "gto_version", "gto_create", "gto_destroy", "gto_last_error", "gto_set_opts",
     "gto_set_scene", "gto_drop_scene", "gto_solve_batch", "gto_solve_batch_device",
-    "gto_last_kernel_time", "gto_set_profiling", "gto_set_stream", "gto_set_mode", "gto_share_scene", "gto_eval_fk", "gto_eval_points",
+    "gto_last_kernel_time", "gto_last_kernel_work", "gto_set_profiling", "gto_set_stream", "gto_set_mode", "gto_share_scene", "gto_eval_fk",
+    "gto_eval_points",
     "gto_eval_objective", "gto_eval_obstacle_normal_eq", "gto_plan_cost", "gto_solve_ik_batch", "gto_solve_base_batch",
     "gto_eval_base_objective", "gto_depth_sdf_cost",
 )
@@ -298,6 +300,12 @@ class SolverHandle:
         n = C.c_int32()
         self._check(self.lib.gto_last_kernel_time(self._h, C.byref(ms), C.byref(n)), "gto_last_kernel_time")
         return ms.value, n.value
+
+    def last_kernel_work(self):
+        """(surface points gathered, chunk spheres tested) by the dominant kernel during the last profiled solve."""
+        a, b = C.c_uint64(), C.c_uint64()
+        self._check(self.lib.gto_last_kernel_work(self._h, C.byref(a), C.byref(b)), "gto_last_kernel_work")
+        return a.value, b.value
 
     # -------------------------------------------------------------- evaluation entry points
     def eval_fk(self, q):

@@ -637,6 +637,13 @@ int gto_set_stream(gto_handle* h, void* stream) {
   return GTO_OK;
 }
 
+int gto_last_kernel_work(gto_handle* h, uint64_t* points_gathered, uint64_t* chunk_tests) {
+  if (!h) return GTO_ERR_INVALID_ARG;
+  if (points_gathered) *points_gathered = h->last_counters[0];
+  if (chunk_tests) *chunk_tests = h->last_counters[1];
+  return GTO_OK;
+}
+
 int gto_set_profiling(gto_handle* h, int32_t enabled) {
   if (!h) return GTO_ERR_INVALID_ARG;
   h->profiling = enabled != 0;
@@ -719,6 +726,7 @@ static BatchPtrs make_ptrs(gto_handle* h, const int32_t* scene_id, const double*
   bp.qref = (double*)h->qref.p;
   bp.margin = (int32_t*)h->margin.p;
   bp.dbg = h->dbg;
+  bp.work = nullptr;
   return bp;
 }
 
@@ -783,7 +791,7 @@ static int launch_traj(gto_handle* h, hipStream_t st, TrajArgs a, const SolvePar
   const RobotDev& rb = h->rb;
   int rc;
   if ((rc = ensure(h, h->trajws, (size_t)a.B * 2 * sp.T * BLK_STRIDE * sizeof(double)))) return rc;
-  if ((rc = ensure(h, h->counters, 128))) return rc;
+  if ((rc = ensure(h, h->counters, 64 * sizeof(unsigned long long)))) return rc;
   a.blocks = (double*)h->trajws.p;
   a.counters = (unsigned long long*)h->counters.p;
   a.dbg = h->dbg;
@@ -886,6 +894,11 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
   bp.n_total = B;
   const size_t ndof = h->rb.ndof;
   HIPCHK(h, hipMemsetAsync(bp.n_done, 0, sizeof(int32_t), st));
+  if (h->profiling) {
+    if ((rc = ensure(h, h->counters, 64 * sizeof(unsigned long long)))) return rc;
+    bp.work = (unsigned long long*)h->counters.p;
+    HIPCHK(h, hipMemsetAsync(bp.work, 0, 64 * sizeof(unsigned long long), st));
+  }
   hipLaunchKernelGGL(k_lm_init, dim3(B), dim3(256), 0, st, h->d_rb, bp, sp, B, 0);
   if ((rc = launch_obstacle(h, st, bp, sp, B, 0, 4, 1, false))) return rc;
   // one round = evaluate the trial trajectories of the slots (obstacle kernel) + accept/solve/new trial (step
@@ -947,6 +960,10 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
       tot += ms;
     }
     h->last_ms = tot;
+    unsigned long long cells[64];
+    HIPCHK(h, hipMemcpy(cells, bp.work, sizeof cells, hipMemcpyDeviceToHost));
+    h->last_counters[0] = h->last_counters[1] = 0;
+    for (unsigned long long c : cells) h->last_counters[0] += c;
   }
   return GTO_OK;
 }

@@ -73,6 +73,7 @@ struct BatchPtrs {
   int32_t cap, n_total;
   int32_t* margin;   // [B][T] voxels of clearance left at qref when the whole waypoint was in free space, else -1
   long long* dbg;    // optional: phase timestamps of instance 0's step kernel (GTO_DEBUG_TIMING)
+  unsigned long long* work;  // [64] or null: surface points gathered (one voxel record or field value each), in 64 cells by blockIdx
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -931,6 +932,7 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
   gto_v4f64 gD = {0.0, 0.0, 0.0, 0.0};
   double ss = 0.0;  // sum of c^2 over this lane's points of the current waypoint
   int cnt = 0, cur_key = -1;
+  unsigned n_gathered = 0;  // surface points this wave looked up (wave-uniform)
 
 #define GTO_DRAIN()                                                                          \
   do {                                                                                       \
@@ -1043,6 +1045,7 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
       }
       cur_key = cur.key;
     }
+    n_gathered += cur.count;
     {
       const bool valid = lane < cur.count;
       if (!need_grad) {
@@ -1080,6 +1083,9 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
   }
 #undef GTO_FLUSH
 #undef GTO_DRAIN
+  // work counter of a profiled solve (bench.py prices the roofline on it): 64 cells so that the few thousand waves of a
+  // launch that gathered anything do not queue up on one address
+  if (bp.work && !fixed_mode && lane == 0 && n_gathered) atomicAdd(bp.work + (bid & 63), (unsigned long long)n_gathered);
   if (dbg_wg && tid == 0) bp.dbg[13] = clock64();
   if (sp.dbg_cut == 3) return;
   __syncthreads();

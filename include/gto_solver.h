@@ -246,6 +246,10 @@ int gto_set_stream(gto_handle* h, void* stream);
 /* Time spent inside the dominant kernel (gto_obstacle_gram) during the most recent solve,
  * measured with HIP events on the launch stream: total milliseconds and launch count. */
 int gto_last_kernel_time(gto_handle* h, double* total_ms, int32_t* launches);
+/* Work the dominant kernel did during the most recent solve (profiling enabled): surface points it looked up in
+ * a field (one 32-B voxel record or one float each; the broad phase skips the rest, which would read exact
+ * zeros) and chunk bounding spheres it tested.  bench.py prices the kernel's roofline on the points gathered. */
+int gto_last_kernel_work(gto_handle* h, uint64_t* points_gathered, uint64_t* chunk_tests);
 /* Enable/disable per-launch event timing of the dominant kernel (off by default). */
 int gto_set_profiling(gto_handle* h, int32_t enabled);
 
