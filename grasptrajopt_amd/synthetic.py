@@ -46,13 +46,25 @@ def _sphere_sdf(p, c, r):
 
 
 def make_scene(seed: int, n: int = 128, res: float = 0.0175,
-               origin=(-0.4, -1.12, -0.4), table_z: float = -0.03) -> Scene:
-    """Table slab below ``table_z`` + K in [3,8] random boxes/spheres standing on it."""
+               origin=(-0.4, -1.12, -0.4), table_z: float = -0.03, shelf: bool = False) -> Scene:
+    """Table slab below ``table_z`` + K in [3,8] random boxes/spheres standing on it.  ``shelf``: the objects stand in a
+    shelf compartment instead (SceneReplica shelf scenes): the lower board is the support at ``table_z`` (2 cm thick, no
+    slab below it), an upper board 0.40 m above it, a back wall and two side walls around x in [0.35, 0.95],
+    y in [-0.6, 0.6]; the compartment is open towards the robot."""
     rng = np.random.default_rng(1000 + seed)
     origin = np.asarray(origin, dtype=np.float64)
     ax = [origin[a] + res * np.arange(n) for a in range(3)]
     k = int(rng.integers(3, 9))
     objects = []
+    boards = []
+    if shelf:
+        x0, x1, y0, y1, hgt, th = 0.35, 0.95, -0.6, 0.6, 0.40, 0.01
+        xc, xh, yc, yh = (x0 + x1) / 2, (x1 - x0) / 2, (y0 + y1) / 2, (y1 - y0) / 2
+        boards = [(np.array([xc, yc, table_z - th]), np.array([xh, yh, th])),                    # lower board (support)
+                  (np.array([xc, yc, table_z + hgt + th]), np.array([xh, yh, th])),             # upper board
+                  (np.array([x1 + th, yc, table_z + hgt / 2]), np.array([th, yh, hgt / 2 + 2 * th])),  # back wall
+                  (np.array([xc, y0 - th, table_z + hgt / 2]), np.array([xh, th, hgt / 2 + 2 * th])),  # side walls
+                  (np.array([xc, y1 + th, table_z + hgt / 2]), np.array([xh, th, hgt / 2 + 2 * th]))]
     for i in range(k):
         cx, cy = rng.uniform(0.3, 0.8), rng.uniform(-0.5, 0.5)
         if rng.random() < 0.6:
@@ -68,7 +80,12 @@ def make_scene(seed: int, n: int = 128, res: float = 0.0175,
         Y, Z = np.meshgrid(ax[1], ax[2], indexing="ij")
         for ix in range(n):  # one x-slab at a time keeps memory small
             p = np.stack([np.full_like(Y, ax[0][ix]), Y, Z], axis=-1)
-            d = p[..., 2] - table_z  # half-space z < table_z
+            if shelf:
+                d = np.full(Y.shape, np.inf)
+                for c_, h_ in boards:
+                    d = np.minimum(d, _box_sdf(p, c_, h_))
+            else:
+                d = p[..., 2] - table_z  # half-space z < table_z
             for j, (kind, c, s) in enumerate(objects):
                 if j == skip:
                     continue
@@ -80,7 +97,7 @@ def make_scene(seed: int, n: int = 128, res: float = 0.0175,
     c_obs = sdf_cost_map(field(target)).reshape(-1)
     return Scene(c_all=c_all, c_obs=c_obs, shape=(n, n, n), origin=origin, res=res,
                  objects=[(kd, c.tolist(), (s.tolist() if kd == "box" else float(s))) for kd, c, s in objects]
-                 + [("target", target)])
+                 + [("target", target)] + ([("shelf", [[c_.tolist(), h_.tolist()] for c_, h_ in boards])] if shelf else []))
 
 
 def standoff_pose(offset: float, axis: str) -> np.ndarray:
