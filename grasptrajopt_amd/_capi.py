@@ -16,7 +16,7 @@ from .robot_desc import RobotDesc
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GTO_HIP_LIB", os.path.join(_HERE, "csrc", "libgto_hip.so"))  # override: A/B builds
 
-GTO_MAX_FRAMES, GTO_MAX_LINKS, GTO_MAX_OPT, GTO_MAX_DOF = 32, 32, 8, 32
+GTO_MAX_FRAMES, GTO_MAX_LINKS, GTO_MAX_OPT, GTO_MAX_DOF = 32, 32, 16, 32
 GRAD_CENTRAL_DIFF, GRAD_ZERO = 0, 1
 STATUS_CONVERGED, STATUS_MAX_ITER, STATUS_NUMERICAL = 0, 1, 2
 

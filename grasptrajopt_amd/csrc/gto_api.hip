@@ -64,6 +64,8 @@ struct gto_handle {
   double last_ms = 0.0;
   int last_launches = 0;
   size_t lm_lds = 0;
+  int np = GTO_NB;     // block width of the normal equations: 8 (up to eight optimised joints) or 16
+  DevBuf zws;          // k_lm_step_wide: block inverses [slots][T-2][np*np]
   int base_lds_set = 0;
   int slots = 384;  // instances in flight inside one solve call (GTO_SLOTS); a finished instance hands its slot to the next one
   bool ik_attr_set = false;
@@ -139,7 +141,7 @@ int gto_create(const gto_robot_desc* d, const gto_solver_opts* opts, int device,
   if (!validate_opts(opts, why)) return fail(nullptr, GTO_ERR_INVALID_ARG, why);
   if (d->n_frames < 1 || d->n_frames > GTO_MAX_FRAMES) return fail(nullptr, GTO_ERR_UNSUPPORTED, "n_frames out of range (max 32)");
   if (d->n_links < 1 || d->n_links > GTO_MAX_LINKS) return fail(nullptr, GTO_ERR_UNSUPPORTED, "n_links out of range (max 32)");
-  if (d->n_opt < 1 || d->n_opt > GTO_MAX_OPT) return fail(nullptr, GTO_ERR_UNSUPPORTED, "n_opt out of range (max 8)");
+  if (d->n_opt < 1 || d->n_opt > GTO_MAX_OPT) return fail(nullptr, GTO_ERR_UNSUPPORTED, "n_opt out of range (max 16)");
   if (d->ndof < d->n_opt || d->ndof > GTO_MAX_DOF) return fail(nullptr, GTO_ERR_UNSUPPORTED, "ndof out of range (max 32)");
   if (d->n_points < 1) return fail(nullptr, GTO_ERR_INVALID_ARG, "robot has no surface points");
   if (d->n_gripper_points < 1) return fail(nullptr, GTO_ERR_INVALID_ARG, "robot has no gripper points");
@@ -409,22 +411,33 @@ int gto_create(const gto_robot_desc* d, const gto_solver_opts* opts, int device,
             up((void**)&h->d_plink, plink.data(), P * sizeof(int32_t)) && up((void**)&h->d_perm, perm.data(), P * sizeof(int32_t)) &&
             up((void**)&h->d_chunks, chunks.data(), chunks.size() * sizeof(Chunk));
   if (!ok) { gto_destroy(h); return fail(nullptr, GTO_ERR_ALLOC, "device allocation failed in gto_create"); }
-  h->lm_lds = lm_lds_bytes(opts->T);
+  h->np = rb.n_opt <= GTO_NB ? GTO_NB : 16;
+  h->lm_lds = h->np == GTO_NB ? lm_lds_bytes(opts->T) : lm_wide_lds_bytes(opts->T, 16);
   if (const char* e = getenv("GTO_DEBUG_STEP_EXTRA_LDS")) h->lm_lds += (size_t)atoi(e);  // occupancy experiments
   if (h->lm_lds > 160 * 1024) { gto_destroy(h); return fail(nullptr, GTO_ERR_UNSUPPORTED, "T too large for the step kernel's LDS"); }
   {
-    const ObsLds lay(GTO_MAX_TG, rb.n_frames, rb.n_links, GTO_MAX_TG * rb.n_chunks);
-    const size_t lds = (size_t)lay.total_doubles * sizeof(double);
-    if (lds > 150 * 1024) { gto_destroy(h); return fail(nullptr, GTO_ERR_UNSUPPORTED, "robot too large for the obstacle kernel's LDS"); }
-    if (hipFuncSetAttribute((const void*)k_obstacle_gram, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)std::min<size_t>(lds + h->dbg_extra_lds, 160 * 1024)) != hipSuccess) {
-      gto_destroy(h);
-      return fail(nullptr, GTO_ERR_HIP, "hipFuncSetAttribute(k_obstacle_gram) failed");
+    // hipFuncSetAttribute is process-wide per kernel: track the largest request and only ever raise it
+    static size_t obs_attr[2] = {0, 0}, step_attr[2] = {0, 0};
+    const int w = h->np == GTO_NB ? 0 : 1;
+    const ObsLds lay(w ? 2 : GTO_MAX_TG, rb.n_frames, rb.n_links, (w ? 2 : GTO_MAX_TG) * rb.n_chunks, h->np);
+    const size_t lds = std::min<size_t>((size_t)lay.total_doubles * sizeof(double) + h->dbg_extra_lds, 160 * 1024);
+    if ((size_t)lay.total_doubles * sizeof(double) > 150 * 1024) { gto_destroy(h); return fail(nullptr, GTO_ERR_UNSUPPORTED, "robot too large for the obstacle kernel's LDS"); }
+    hipError_t e1 = hipSuccess, e2 = hipSuccess;
+    if (lds > obs_attr[w]) {
+      e1 = w ? hipFuncSetAttribute((const void*)k_obstacle_gram<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+             : hipFuncSetAttribute((const void*)k_obstacle_gram<GTO_NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      obs_attr[w] = lds;
     }
-  }
-  if (hipFuncSetAttribute((const void*)k_lm_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lm_lds) != hipSuccess) {
-    gto_destroy(h);
-    return fail(nullptr, GTO_ERR_HIP, "hipFuncSetAttribute(k_lm_step) failed");
+    if (h->lm_lds > step_attr[w]) {
+      e2 = w ? hipFuncSetAttribute((const void*)k_lm_step_wide<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lm_lds)
+             : hipFuncSetAttribute((const void*)k_lm_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lm_lds);
+      step_attr[w] = h->lm_lds;
+    }
+    if (e1 != hipSuccess || e2 != hipSuccess) {
+      gto_destroy(h);
+      return fail(nullptr, GTO_ERR_HIP, "hipFuncSetAttribute failed");
+    }
+    if (w) h->obs_tg = h->obs_tg_few = std::min(h->obs_tg, 2);  // wider blocks: two waypoints per workgroup keep its LDS small
   }
   *out = h;
   return GTO_OK;
@@ -452,7 +465,7 @@ void gto_destroy(gto_handle* h) {
   (void)hipFree(h->d_plink);
   (void)hipFree(h->d_perm);
   (void)hipFree(h->d_chunks);
-  DevBuf* bufs[] = {&h->trajws, &h->evterms, &h->evblocks, &h->counters, &h->state, &h->Qcur, &h->Qtry, &h->vis, &h->screw, &h->blocks, &h->goalblk, &h->ssfixed, &h->ndone, &h->qref, &h->margin, &h->qf, &h->slotbuf, &h->qfs};
+  DevBuf* bufs[] = {&h->zws, &h->trajws, &h->evterms, &h->evblocks, &h->counters, &h->state, &h->Qcur, &h->Qtry, &h->vis, &h->screw, &h->blocks, &h->goalblk, &h->ssfixed, &h->ndone, &h->qref, &h->margin, &h->qf, &h->slotbuf, &h->qfs};
   if (h->h_ndone) (void)hipHostFree(h->h_ndone);
   for (int p = 0; p < 2; ++p)
     if (h->ev_chk[p]) (void)hipEventDestroy(h->ev_chk[p]);
@@ -685,8 +698,10 @@ static int ensure_workspace(gto_handle* h, int B) {
   if ((rc = ensure(h, h->state, (size_t)B * sizeof(InstState)))) return rc;
   if ((rc = ensure(h, h->Qcur, (size_t)B * n * T * sizeof(double)))) return rc;
   if ((rc = ensure(h, h->Qtry, (size_t)B * n * T * sizeof(double)))) return rc;
-  if ((rc = ensure(h, h->blocks, (size_t)2 * B * T * BLK_STRIDE * sizeof(double)))) return rc;
-  if ((rc = ensure(h, h->goalblk, (size_t)2 * B * 2 * BLK_STRIDE * sizeof(double)))) return rc;
+  const size_t bstride = (size_t)h->np * h->np + h->np + 8;
+  if ((rc = ensure(h, h->blocks, (size_t)2 * B * T * bstride * sizeof(double)))) return rc;
+  if ((rc = ensure(h, h->goalblk, (size_t)2 * B * 2 * bstride * sizeof(double)))) return rc;
+  if (h->np != GTO_NB && (rc = ensure(h, h->zws, (size_t)std::min(B, h->slots) * (T - 2) * h->np * h->np * sizeof(double)))) return rc;
   if ((rc = ensure(h, h->ssfixed, (size_t)B * 4 * sizeof(double)))) return rc;
   if ((rc = ensure(h, h->ndone, 64))) return rc;
   if ((rc = ensure(h, h->qf, (size_t)B * T * rb.n_frames * sizeof(double)))) return rc;
@@ -752,10 +767,15 @@ static int launch_obstacle(gto_handle* h, hipStream_t st, const BatchPtrs& bp, c
   const int nb = n_slots > 0 ? n_slots : B;  // workgroups are laid out for the slots in flight; B stays the batch (strides)
   const int n_regular = obstacle_grid(nb, nG);
   const int cap_active = TG * h->rb.n_chunks;
-  const ObsLds lay(TG, h->rb.n_frames, h->rb.n_links, cap_active);
+  const ObsLds lay(TG, h->rb.n_frames, h->rb.n_links, cap_active, h->np);
   const size_t lds = (size_t)lay.total_doubles * sizeof(double) + h->dbg_extra_lds;
-  hipLaunchKernelGGL(k_obstacle_gram, dim3(n_regular + (with_goal_terms ? (nb + 3) / 4 : 0)), dim3(256), lds, st, h->d_rb, h->d_px, h->d_py,
-                     h->d_pz, h->d_chunks, h->d_scenes, bp, sp, B, t_begin, nT, fixed_mode, n_regular, TG, cap_active);
+  const dim3 grid(n_regular + (with_goal_terms ? (nb + 3) / 4 : 0));
+  if (h->np == GTO_NB)
+    hipLaunchKernelGGL(k_obstacle_gram<GTO_NB>, grid, dim3(256), lds, st, h->d_rb, h->d_px, h->d_py, h->d_pz, h->d_chunks, h->d_scenes, bp, sp,
+                       B, t_begin, nT, fixed_mode, n_regular, TG, cap_active);
+  else
+    hipLaunchKernelGGL(k_obstacle_gram<16>, grid, dim3(256), lds, st, h->d_rb, h->d_px, h->d_py, h->d_pz, h->d_chunks, h->d_scenes, bp, sp, B,
+                       t_begin, nT, fixed_mode, n_regular, TG, cap_active);
   if (timed) {
     HIPCHK(h, hipEventRecord(e1, st));
     h->last_launches++;
@@ -868,6 +888,7 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
   HIPCHK(h, hipSetDevice(h->device));
   hipStream_t st = stream ? (hipStream_t)stream : h->stream;
   if (h->mode == GTO_MODE_SINGLE_LAUNCH) {
+    if (h->np != GTO_NB) return fail(h, GTO_ERR_UNSUPPORTED, "GTO_MODE_SINGLE_LAUNCH handles up to eight optimised joints");
     TrajArgs a = {};
     a.scene_id = scene_id, a.qc = qc, a.goals = goals, a.n_goals = n_goals, a.standoff = standoff, a.base_pos = base_pos, a.Q0 = Q0;
     a.Q_out = Q_out, a.dQ_out = dQ_out, a.cost_out = cost_out, a.iters_out = iters_out, a.status_out = status_out;
@@ -899,7 +920,8 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
     bp.work = (unsigned long long*)h->counters.p;
     HIPCHK(h, hipMemsetAsync(bp.work, 0, 64 * sizeof(unsigned long long), st));
   }
-  hipLaunchKernelGGL(k_lm_init, dim3(B), dim3(256), 0, st, h->d_rb, bp, sp, B, 0);
+  if (h->np == GTO_NB) hipLaunchKernelGGL(k_lm_init<GTO_NB>, dim3(B), dim3(256), 0, st, h->d_rb, bp, sp, B, 0);
+  else hipLaunchKernelGGL(k_lm_init<16>, dim3(B), dim3(256), 0, st, h->d_rb, bp, sp, B, 0);
   if ((rc = launch_obstacle(h, st, bp, sp, B, 0, 4, 1, false))) return rc;
   // one round = evaluate the trial trajectories of the slots (obstacle kernel) + accept/solve/new trial (step
   // kernel).  An instance may start late: enough rounds for every slot to serve its share one after the other.
@@ -912,7 +934,8 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
     const int in_flight = std::min(W, B - known_done);
     const int tg = in_flight <= h->few_instances ? h->obs_tg_few : h->obs_tg;
     if ((rc = launch_obstacle(h, st, bp, sp, B, 2, T - 2, 0, h->profiling, true, W, tg))) return rc;
-    hipLaunchKernelGGL(k_lm_step, dim3(W), dim3(256), h->lm_lds, st, h->d_rb, bp, sp, B);
+    if (h->np == GTO_NB) hipLaunchKernelGGL(k_lm_step, dim3(W), dim3(256), h->lm_lds, st, h->d_rb, bp, sp, B);
+    else hipLaunchKernelGGL(k_lm_step_wide<16>, dim3(W), dim3(256), h->lm_lds, st, h->d_rb, bp, sp, B, (double*)h->zws.p);
     // Early exit.  Every few rounds the finished-instance counter is copied back (4 bytes) and an event is
     // recorded, but the host only LOOKS at the copy of the previous check: by then the GPU has long passed that
     // point, so the host never waits on the GPU's critical path and the queue never drains (a blocking
@@ -999,6 +1022,7 @@ int gto_solve_ik_batch(gto_handle* h, int32_t B, const int32_t* scene_id, const 
   if (B < 0 || max_iter < 0) return fail(h, GTO_ERR_INVALID_ARG, "B and max_iter must be >= 0");
   if (B == 0) return GTO_OK;
   if (!q0 || !goals || !q_out) return fail(h, GTO_ERR_INVALID_ARG, "null input array");
+  if (h->np != GTO_NB) return fail(h, GTO_ERR_UNSUPPORTED, "gto_solve_ik_batch handles up to eight optimised joints");
   int rc;
   if (scene_id && (rc = check_scene_ids_host(h, scene_id, B))) return rc;
   HIPCHK(h, hipSetDevice(h->device));
@@ -1044,6 +1068,7 @@ int gto_solve_base_batch(gto_handle* h, int32_t B, int32_t n_max, const int32_t*
   if (!h) return GTO_ERR_INVALID_ARG;
   if (B < 0 || max_iter < 0) return fail(h, GTO_ERR_INVALID_ARG, "B and max_iter must be >= 0");
   if (n_max < 1 || n_max > GTO_MAX_BASE_GOALS) return fail(h, GTO_ERR_UNSUPPORTED, "n_max must be in [1, 32]");
+  if (h->np != GTO_NB) return fail(h, GTO_ERR_UNSUPPORTED, "gto_solve_base_batch handles up to eight optimised joints");
   if (B == 0) return GTO_OK;
   if (!n_goals || !qc || !goals || !y_out || !q_out) return fail(h, GTO_ERR_INVALID_ARG, "null input array");
   for (int b = 0; b < B; ++b)
@@ -1252,7 +1277,8 @@ static int eval_common(gto_handle* h, int B, int n_max, const int32_t* scene_id,
   BatchPtrs bp = make_ptrs(h, (const int32_t*)d_sid, (const double*)d_qc, (const double*)d_goals, (const int32_t*)d_ng,
                            (const double*)d_so, (const double*)d_base, (const double*)d_Q0);
   HIPCHK(h, hipMemsetAsync(bp.n_done, 0, sizeof(int32_t), h->stream));
-  hipLaunchKernelGGL(k_lm_init, dim3(B), dim3(256), 0, h->stream, h->d_rb, bp, sp, B, 1 /* raw: evaluate Q as given */);
+  if (h->np == GTO_NB) hipLaunchKernelGGL(k_lm_init<GTO_NB>, dim3(B), dim3(256), 0, h->stream, h->d_rb, bp, sp, B, 1 /* raw: evaluate Q as given */);
+  else hipLaunchKernelGGL(k_lm_init<16>, dim3(B), dim3(256), 0, h->stream, h->d_rb, bp, sp, B, 1);
   if ((rc = launch_obstacle(h, h->stream, bp, sp, B, 0, 4, 1, false))) return rc;
   h->last_launches = 0;
   if ((rc = launch_obstacle(h, h->stream, bp, sp, B, 2, (int)T - 2, 0, h->profiling))) return rc;
@@ -1263,11 +1289,12 @@ static int eval_common(gto_handle* h, int B, int n_max, const int32_t* scene_id,
     h->last_ms = ms;
   }
   states.resize(B);
-  blocks.resize((size_t)B * T * BLK_STRIDE);
+  const size_t bstride = (size_t)h->np * h->np + h->np + 8;
+  blocks.resize((size_t)B * T * bstride);
   ssfixed.resize((size_t)B * 4);
   HIPCHK(h, hipMemcpyAsync(states.data(), h->state.p, B * sizeof(InstState), hipMemcpyDeviceToHost, h->stream));
   // trial slot is 1 right after init (slot = 0)
-  HIPCHK(h, hipMemcpyAsync(blocks.data(), (double*)h->blocks.p + (size_t)1 * B * T * BLK_STRIDE,
+  HIPCHK(h, hipMemcpyAsync(blocks.data(), (double*)h->blocks.p + (size_t)1 * B * T * bstride,
                            blocks.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipMemcpyAsync(ssfixed.data(), h->ssfixed.p, ssfixed.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1288,7 +1315,8 @@ int gto_eval_objective(gto_handle* h, int32_t B, int32_t n_max, const int32_t* s
   const int T = h->opts.T;
   for (int b = 0; b < B; ++b) {
     double so = ssf[4 * b] + ssf[4 * b + 1];
-    for (int t = 2; t < T; ++t) so += blocks[((size_t)b * T + t) * BLK_STRIDE + BLK_SS];
+    const size_t bstride = (size_t)h->np * h->np + h->np + 8, bss = (size_t)h->np * h->np + h->np;
+    for (int t = 2; t < T; ++t) so += blocks[((size_t)b * T + t) * bstride + bss];
     if (f_goal) f_goal[b] = st[b].fgoal_try;
     if (f_obs) f_obs[b] = h->opts.w_obstacle * so;
     if (f_vel) f_vel[b] = st[b].fvel_try;
@@ -1309,13 +1337,14 @@ int gto_eval_obstacle_normal_eq(gto_handle* h, int32_t B, const int32_t* scene_i
   const int T = h->opts.T, n = h->rb.n_opt;
   for (int b = 0; b < B; ++b)
     for (int t = 0; t < T; ++t) {
-      const double* blk = &blocks[((size_t)b * T + t) * BLK_STRIDE];
+      const int np = h->np;
+      const double* blk = &blocks[((size_t)b * T + t) * ((size_t)np * np + np + 8)];
       for (int i = 0; i < n; ++i) {
         for (int j = 0; j < n; ++j)
-          if (JtJ) JtJ[(((size_t)b * T + t) * n + i) * n + j] = (t < 2) ? 0.0 : blk[BLK_JTJ + 8 * i + j];
-        if (Jtr) Jtr[((size_t)b * T + t) * n + i] = (t < 2) ? 0.0 : blk[BLK_JTR + i];
+          if (JtJ) JtJ[(((size_t)b * T + t) * n + i) * n + j] = (t < 2) ? 0.0 : blk[np * i + j];
+        if (Jtr) Jtr[((size_t)b * T + t) * n + i] = (t < 2) ? 0.0 : blk[np * np + i];
       }
-      if (sumsq) sumsq[(size_t)b * T + t] = (t < 2) ? ssf[4 * b + t] : blk[BLK_SS];
+      if (sumsq) sumsq[(size_t)b * T + t] = (t < 2) ? ssf[4 * b + t] : blk[np * np + np];
     }
   return GTO_OK;
 }

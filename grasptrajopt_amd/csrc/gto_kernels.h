@@ -20,10 +20,16 @@
 #pragma once
 #include "gto_device.h"
 
+// doubles per (instance, waypoint) block: NP x NP J^T J (row-major), NP J^T r, sum c^2, pad.  NP = 8 for robots with up
+// to eight optimised joints (Panda, Fetch arm: the tuned path), 16 beyond that (mobile manipulators)
+template <int NP>
+struct Blk {
+  static constexpr int JTJ = 0, JTR = NP * NP, SS = NP * NP + NP, STRIDE = NP * NP + NP + 8;
+};
 #define BLK_JTJ 0
 #define BLK_JTR 64
 #define BLK_SS 72
-#define BLK_STRIDE 80  // doubles per (instance, waypoint) block: 8x8 J^T J, 8 J^T r, sum c^2, pad
+#define BLK_STRIDE 80  // = Blk<8>: the kernels that only exist for NP = 8 (k_lm_step, k_ik_solve, k_base_solve, k_traj_solve)
 #define GTO_MAX_ACTIVE 256   // chunks per robot (16 K surface points)
 #define GTO_MAX_TG 8         // waypoints per workgroup of the obstacle kernel
 #define GTO_MAX_T 96         // waypoints the step kernel's register-resident phases are unrolled for (and its LDS holds)
@@ -442,10 +448,10 @@ __host__ __device__ inline int fk_scratch_doubles(int F, int ng = 1) { return ng
 __device__ __forceinline__ void fk_mfma_tree(const RobotDev* __restrict__ rb, const double* __restrict__ s_tab, int ng,
                                     const double* __restrict__ s_sc, double* __restrict__ s_X, int* __restrict__ s_anc,
                                     int tid, double* __restrict__ s_vis, double* __restrict__ s_screw,
-                                    long long* dbgp = nullptr) {
+                                    long long* dbgp = nullptr, int scr_np = GTO_NB) {
   // `ng` configurations are advanced together, stage by stage, so that they share the barriers:
   // s_sc [ng][F][2], s_X [ng][2][F][16] then a dummy store target [64], s_anc [2][GTO_MAX_FRAMES] (the
-  // ancestors do not depend on the configuration), s_vis [ng][L][12], s_screw [ng][GTO_MAX_OPT][6]
+  // ancestors do not depend on the configuration), s_vis [ng][L][12], s_screw [ng][scr_np][6]
   const int F = rb->n_frames, L = rb->n_links, n = rb->n_opt;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: the compiler must see it as wave-uniform
   const int ra = lane >> 4, rc = lane & 3, blk = (lane >> 2) & 3;
@@ -531,7 +537,7 @@ __device__ __forceinline__ void fk_mfma_tree(const RobotDev* __restrict__ rb, co
         const double a1 = quad_perm<1, 2, 0, 3>(av), a2 = quad_perm<2, 0, 1, 3>(av);
         const double o1 = quad_perm<1, 2, 0, 3>(ov), o2 = quad_perm<2, 0, 1, 3>(ov);
         const double cr = o1 * a2 - o2 * a1;
-        double* sv = s_screw + (kq * GTO_MAX_OPT + j) * 6;
+        double* sv = s_screw + (kq * scr_np + j) * 6;
         *(w ? sv + rc : s_dummy + lane) = prism ? 0.0 : av;
         *(w ? sv + 3 + rc : s_dummy + lane) = prism ? av : cr;
       }
@@ -656,29 +662,31 @@ __global__ void k_dist_relax(const uint8_t* __restrict__ in, uint8_t* __restrict
 //             list of chunks that can touch a non-zero voxel
 //   main loop one link-uniform chunk of 64 Morton-sorted surface points per wave step (sparse wrench lists)
 //   epilogue  per-link 6x6 wrench Grams -> J^T J (n x n), J^T r (n), sum c^2 per waypoint
-#define GTO_GOAL_SCRATCH (2 * GTO_MAX_FRAMES * 12 + 2 * GTO_MAX_DOF + 48 + 2 * GTO_MAX_OPT * 6)  // doubles per goal wavefront
+#define GTO_GOAL_SCRATCH(NP) (2 * GTO_MAX_FRAMES * 12 + 2 * GTO_MAX_DOF + 48 + 2 * (NP) * 6)  // doubles per goal wavefront
 struct ObsLds {  // dynamic LDS layout (offsets in doubles), computed identically on host and device
   int vis, screw, uni, gram, list, out, active, total_doubles;
-  __host__ __device__ ObsLds(int TG, int F, int L, int cap_active) {
+  __host__ __device__ ObsLds(int TG, int F, int L, int cap_active, int NP = GTO_NB) {
+    const int stride = NP * NP + NP + 8;
     int o = 0;
     vis = o;    o += TG * L * 12;
-    screw = o;  o += TG * GTO_MAX_OPT * 6;
+    screw = o;  o += TG * NP * 6;
     // One region, two tenants.  Prologue: operand table, sin/cos [TG][F][2] and scratch of fk_mfma_tree (in the
     // goal workgroups: their scratch).  After the kinematics: Gram accumulators, wrench lists, surviving chunks.
     uni = o;
-    const int fk = fk_tab_doubles(F, L, GTO_MAX_OPT) + TG * F * 2 + fk_scratch_doubles(F, TG);
+    const int fk = fk_tab_doubles(F, L, NP) + TG * F * 2 + fk_scratch_doubles(F, TG);
     gram = o;   o += TG * L * GTO_GRAM;  // every (waypoint, link) is folded by exactly one wave
-    // wrench lists in the loop; in the epilogue s_u [TG][L][GTO_MAX_OPT][6] and behind it the output blocks
-    const int lst = 4 * GTO_LIST_CAP * 8, epi = TG * L * GTO_MAX_OPT * 6 + TG * BLK_STRIDE;
+    // wrench lists in the loop; in the epilogue s_u [TG][L][NP][6] and behind it the output blocks
+    const int lst = 4 * GTO_LIST_CAP * 8, epi = TG * L * NP * 6 + TG * stride;
     list = o;   o += lst > epi ? lst : epi;
-    out = list + TG * L * GTO_MAX_OPT * 6;
+    out = list + TG * L * NP * 6;
     active = o; o += cap_active;  // int2 per entry
     total_doubles = (o - uni > fk ? o : uni + fk);
-    if (total_doubles < 4 * GTO_GOAL_SCRATCH) total_doubles = 4 * GTO_GOAL_SCRATCH;  // the goal workgroups: four wavefronts
+    if (total_doubles < 4 * GTO_GOAL_SCRATCH(NP)) total_doubles = 4 * GTO_GOAL_SCRATCH(NP);  // the goal workgroups: four wavefronts
   }
 };
 
 struct InstState;
+template <int NP>
 __device__ __forceinline__ void trial_goal_terms_wave(const RobotDev* rb, const BatchPtrs& bp, const SolveParams& sp, int B,
                                              int b, int lane, int trial, InstState* st, double* s_q, double* s_fr,
                                              double* s_gaff, double* s_gscr);
@@ -686,6 +694,7 @@ __device__ __forceinline__ void trial_goal_terms_wave(const RobotDev* rb, const 
 #ifndef GTO_OBS_MIN_WAVES
 #define GTO_OBS_MIN_WAVES 5  // waves per SIMD the register allocator must leave room for: five workgroups per CU (31 KB of LDS each at three waypoints per workgroup)
 #endif
+template <int NP>
 __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const RobotDev* __restrict__ rb, const double* __restrict__ px,
                                                        const double* __restrict__ py, const double* __restrict__ pz,
                                                        const Chunk* __restrict__ chunks, const SceneDev* __restrict__ scenes,
@@ -698,7 +707,8 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
 
   const int bid = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int L = rb->n_links, n = rb->n_opt, T = sp.T, ndof = rb->ndof, F = rb->n_frames;
-  const ObsLds lay(TG, F, L, cap_active);
+  typedef Blk<NP> BK;
+  const ObsLds lay(TG, F, L, cap_active, NP);
   double* s_vis = smem_obs + lay.vis;
   double* s_screw = smem_obs + lay.screw;
   double* s_gram = smem_obs + lay.gram;
@@ -707,7 +717,7 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
   double* s_ktab = smem_obs + lay.uni;          // prologue only
   double* s_sc = s_ktab + fk_tab_doubles(F, L, n);  // prologue only
   int2* s_active = reinterpret_cast<int2*>(smem_obs + lay.active);  // (link | waypoint << 16, start | count << 16)
-  double* s_u = s_list;    // [TG][L][GTO_MAX_OPT][6] in the epilogue
+  double* s_u = s_list;    // [TG][L][NP][6] in the epilogue
 
   // Extra workgroups (blockIdx >= n_regular), one per instance: goal-set terms and velocity term of the
   // trial trajectory.  The step kernel only needs them at its NEXT launch, so they ride in the shadow
@@ -723,11 +733,11 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
     if (bg < 0) return;  // empty slot
     // a fresh instance evaluates its seed, whose goal terms k_lm_init already produced
     if (bp.state[bg].done || (listed && bp.state[bg].first)) return;
-    double* s_fr2 = smem_obs + wave * GTO_GOAL_SCRATCH;  // [2][GTO_MAX_FRAMES*12]
+    double* s_fr2 = smem_obs + wave * GTO_GOAL_SCRATCH(NP);  // [2][GTO_MAX_FRAMES*12]
     double* s_q2 = s_fr2 + 2 * GTO_MAX_FRAMES * 12;      // [2][GTO_MAX_DOF]
     double* s_ga = s_q2 + 2 * GTO_MAX_DOF;               // [48]
-    double* s_gs = s_ga + 48;                            // [2][GTO_MAX_OPT*6]
-    trial_goal_terms_wave(rb, bp, sp, B, bg, lane, 1 - bp.state[bg].slot, bp.state + bg, s_q2, s_fr2, s_ga, s_gs);
+    double* s_gs = s_ga + 48;                            // [2][NP*6]
+    trial_goal_terms_wave<NP>(rb, bp, sp, B, bg, lane, 1 - bp.state[bg].slot, bp.state + bg, s_q2, s_fr2, s_ga, s_gs);
     return;
   }
   // blockIdx -> (instance, waypoint group), bijective, with b % 8 == blockIdx % 8
@@ -785,8 +795,8 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
     __syncthreads();
     if (bp.dbg && tid == 0) atomicAdd((unsigned long long*)(bp.dbg + (s_nactive ? 41 : 42)), 1ull);
     if (s_nactive) {
-      double* out = bp.blocks + (((size_t)(1 - slot_cur) * B + b) * T + t0w) * BLK_STRIDE;
-      if (tid < BLK_STRIDE) out[tid] = (tid == BLK_SS) ? bp.ss_fixed[4 * b + (t0w < sp.ts ? 2 : 3)] : 0.0;
+      double* out = bp.blocks + (((size_t)(1 - slot_cur) * B + b) * T + t0w) * BK::STRIDE;
+      for (int i_ = tid; i_ < BK::STRIDE; i_ += 256) out[i_] = (i_ == BK::SS) ? bp.ss_fixed[4 * b + (t0w < sp.ts ? 2 : 3)] : 0.0;
       return;
     }
     __syncthreads();
@@ -817,7 +827,7 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
   {
     double* s_X = s_sc + 2 * ng * F;
     fk_mfma_tree(rb, s_ktab, ng, s_sc, s_X, reinterpret_cast<int*>(s_X + ng * 32 * F + 64), tid, s_vis, s_screw,
-                 dbg_wg ? bp.dbg + 20 : nullptr);
+                 dbg_wg ? bp.dbg + 20 : nullptr, NP);
   }
   __syncthreads();
   // the kinematics scratch is dead: its region now holds the Gram accumulators (the barriers of the broad
@@ -1090,25 +1100,25 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
   if (sp.dbg_cut == 3) return;
   __syncthreads();
   // the wrench lists are dead: their region now holds s_u and, behind it, the output blocks
-  for (int i = tid; i < ng * BLK_STRIDE; i += 256) s_out[i] = 0.0;
+  for (int i = tid; i < ng * BK::STRIDE; i += 256) s_out[i] = 0.0;
   __syncthreads();
   // sum of c^2 per waypoint: its keys in link order
   if (tid < ng) {
     double v = 0.0;
     for (int l = 0; l < L; ++l) v += s_gram[(tid * L + l) * GTO_GRAM + 27];
-    s_out[tid * BLK_STRIDE + BLK_SS] = v;
+    s_out[tid * BK::STRIDE + BK::SS] = v;
   }
   __syncthreads();
 
   // projection of the per-link wrench Grams onto the joint screws, over the links that were touched:
   //   JtJ[i][j] = sum_l [i,j in anc(l)] s_i^T W_l s_j ,  Jtr[i] = sum_l [i in anc(l)] s_i . v_l
   if (!fixed_mode) {
-    // all waypoints of the group at once: s_u [ng][L][GTO_MAX_OPT][6] in the dead list region
+    // all waypoints of the group at once: s_u [ng][L][NP][6] in the dead list region
     for (int idx = tid; idx < ng * L * n; idx += 256) {
       const int kq = idx / (L * n), r_ = idx - kq * L * n, l = r_ / n, j = r_ - l * n;
       if (!((s_touched[kq] >> l) & 1u)) continue;
       const double* W = s_gram + (kq * L + l) * GTO_GRAM;
-      const double* sj = s_screw + kq * GTO_MAX_OPT * 6 + 6 * j;
+      const double* sj = s_screw + kq * NP * 6 + 6 * j;
       const bool on = (rb->link_anc[l] >> j) & 1u;
 #pragma unroll
       for (int r = 0; r < 6; ++r) {
@@ -1117,32 +1127,33 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
 #pragma unroll
           for (int c = 0; c < 6; ++c) u += W[sym6(r, c)] * sj[c];
         }
-        s_u[((kq * L + l) * GTO_MAX_OPT + j) * 6 + r] = u;
+        s_u[((kq * L + l) * NP + j) * 6 + r] = u;
       }
     }
     __syncthreads();
     // one thread per output entry, links summed in order (deterministic, no atomics)
-    for (int idx = tid; idx < ng * 72; idx += 256) {
-      const int kq = idx / 72, e = idx - kq * 72;
+    constexpr int NE = NP * NP + NP;  // entries of J^T J, then of J^T r
+    for (int idx = tid; idx < ng * NE; idx += 256) {
+      const int kq = idx / NE, e = idx - kq * NE;
       const unsigned touched = s_touched[kq];
       if (!touched) continue;  // the block stays zero
-      const double* screw = s_screw + kq * GTO_MAX_OPT * 6;
-      if (e < 64) {
-        const int i = e >> 3, j = e & 7;
+      const double* screw = s_screw + kq * NP * 6;
+      if (e < NP * NP) {
+        const int i = e / NP, j = e % NP;
         double v = 0.0;
         if (i < n && j < n) {
           const double* si = screw + 6 * i;
           for (int l = 0; l < L; ++l) {
             const uint32_t anc = rb->link_anc[l];
             if (((touched >> l) & 1u) && ((anc >> i) & 1u) && ((anc >> j) & 1u)) {
-              const double* u = s_u + ((kq * L + l) * GTO_MAX_OPT + j) * 6;
+              const double* u = s_u + ((kq * L + l) * NP + j) * 6;
               v += si[0] * u[0] + si[1] * u[1] + si[2] * u[2] + si[3] * u[3] + si[4] * u[4] + si[5] * u[5];
             }
           }
         }
-        s_out[kq * BLK_STRIDE + BLK_JTJ + e] = v;
+        s_out[kq * BK::STRIDE + BK::JTJ + e] = v;
       } else {
-        const int i = e - 64;
+        const int i = e - NP * NP;
         double v = 0.0;
         if (i < n) {
           const double* si = screw + 6 * i;
@@ -1152,7 +1163,7 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
               v += si[0] * vv[0] + si[1] * vv[1] + si[2] * vv[2] + si[3] * vv[3] + si[4] * vv[4] + si[5] * vv[5];
             }
         }
-        s_out[kq * BLK_STRIDE + BLK_JTR + i] = v;
+        s_out[kq * BK::STRIDE + BK::JTR + i] = v;
       }
     }
   }
@@ -1162,13 +1173,13 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
     bp.dbg[15] = NA;
   }
   if (fixed_mode) {
-    if (tid < ng) bp.ss_fixed[4 * b + t0v + tid] = s_out[tid * BLK_STRIDE + BLK_SS];
+    if (tid < ng) bp.ss_fixed[4 * b + t0v + tid] = s_out[tid * BK::STRIDE + BK::SS];
   } else {
     // add the constant contribution of the static links (measured once at init)
-    if (tid < ng) s_out[tid * BLK_STRIDE + BLK_SS] += bp.ss_fixed[4 * b + ((t0w + tid) < sp.ts ? 2 : 3)];
+    if (tid < ng) s_out[tid * BK::STRIDE + BK::SS] += bp.ss_fixed[4 * b + ((t0w + tid) < sp.ts ? 2 : 3)];
     __syncthreads();
-    double* out = bp.blocks + (((size_t)(1 - slot_cur) * B + b) * T + t0w) * BLK_STRIDE;
-    for (int i = tid; i < ng * BLK_STRIDE; i += 256) out[i] = s_out[i];
+    double* out = bp.blocks + (((size_t)(1 - slot_cur) * B + b) * T + t0w) * BK::STRIDE;
+    for (int i = tid; i < ng * BK::STRIDE; i += 256) out[i] = s_out[i];
   }
 }
 
@@ -1273,7 +1284,8 @@ __device__ __forceinline__ void goal_gram_moments(const RobotDev* rb, const doub
   v6[5] = Dmu[2] + K * d[2];
 }
 
-// One wavefront.  s_gaff [2][24], s_gscr [2][GTO_MAX_OPT*6] in LDS.  goalblk_out: [2][BLK_STRIDE] or null.
+// One wavefront.  s_gaff [2][24], s_gscr [2][NP*6] in LDS.  goalblk_out: [2][Blk<NP>::STRIDE] or null.
+template <int NP = GTO_NB>
 __device__ __forceinline__ GoalOut goal_terms_wave(const RobotDev* rb, const SolveParams& sp, const double* goals, int n_goals,
                                           const double* standoff, const double* s_gaff, const double* s_gscr,
                                           double* goalblk_out, int lane) {
@@ -1311,17 +1323,18 @@ __device__ __forceinline__ GoalOut goal_terms_wave(const RobotDev* rb, const Sol
     const int n = rb->n_opt;
     const uint32_t anc = rb->frame_anc[rb->frame_gripper];
     const int which = lane >> 5, l = lane & 31;
-    double* blk = goalblk_out + which * BLK_STRIDE;
+    typedef Blk<NP> BK;
+    double* blk = goalblk_out + which * BK::STRIDE;
     if (which == 1 && !sp.use_standoff) {
-      for (int i = l; i < BLK_STRIDE; i += 32) blk[i] = 0.0;
+      for (int i = l; i < BK::STRIDE; i += 32) blk[i] = 0.0;
     } else {
       double Y[12], W21[21], v6[6];
       goal_target(s_gaff + 24 * which, goals + 16 * besti, which ? standoff : nullptr, Y);
       goal_gram_moments(rb, s_gaff + 24 * which, Y, W21, v6);
-      const double* S = s_gscr + which * GTO_MAX_OPT * 6;
+      const double* S = s_gscr + which * NP * 6;
 #pragma unroll
-      for (int h2 = 0; h2 < 2; ++h2) {
-        const int e = l + 32 * h2, i = e >> 3, j = e & 7;
+      for (int h2 = 0; h2 < NP * NP / 32; ++h2) {
+        const int e = l + 32 * h2, i = e / NP, j = e % NP;
         double v = 0.0;
         if (i < n && j < n && ((anc >> i) & 1u) && ((anc >> j) & 1u)) {
 #pragma unroll
@@ -1332,15 +1345,15 @@ __device__ __forceinline__ GoalOut goal_terms_wave(const RobotDev* rb, const Sol
             v += S[6 * i + r] * u;
           }
         }
-        blk[BLK_JTJ + e] = v;
+        blk[BK::JTJ + e] = v;
       }
-      if (l < 8) {
+      if (l < NP) {
         double g = 0.0;
         if (l < n && ((anc >> l) & 1u)) {
 #pragma unroll
           for (int r = 0; r < 6; ++r) g += S[6 * l + r] * v6[r];
         }
-        blk[BLK_JTR + l] = g;
+        blk[BK::JTR + l] = g;
       }
     }
   }
@@ -1349,7 +1362,8 @@ __device__ __forceinline__ GoalOut goal_terms_wave(const RobotDev* rb, const Sol
 
 // Goal terms + velocity term of the trial trajectory; one wavefront per instance.  Forward kinematics
 // is needed at two waypoints only (final and standoff); the obstacle kernel does its own.
-// s_q [GTO_MAX_DOF], s_fr [GTO_MAX_FRAMES*12], s_gaff [48], s_gscr [2*GTO_MAX_OPT*6] are LDS scratch.
+// s_q [GTO_MAX_DOF], s_fr [GTO_MAX_FRAMES*12], s_gaff [48], s_gscr [2*NP*6] are LDS scratch.
+template <int NP>
 __device__ __forceinline__ void trial_goal_terms_wave(const RobotDev* rb, const BatchPtrs& bp, const SolveParams& sp, int B,
                                              int b, int lane, int trial, InstState* st, double* s_q, double* s_fr,
                                              double* s_gaff, double* s_gscr) {
@@ -1373,12 +1387,12 @@ __device__ __forceinline__ void trial_goal_terms_wave(const RobotDev* rb, const 
     if (l >= 12 && l < 12 + n) {  // screw of optimised joint j = l - 12
       const int j = l - 12;
       for (int i = 0; i < rb->n_frames; ++i)
-        if (rb->opt_of_frame[i] == j) screw_of_frame(rb, i, fr + 12 * i, s_gscr + which * GTO_MAX_OPT * 6 + 6 * j);
+        if (rb->opt_of_frame[i] == j) screw_of_frame(rb, i, fr + 12 * i, s_gscr + which * NP * 6 + 6 * j);
     }
     wave_sync();
   }
-  double* gblk = bp.goalblk + ((size_t)trial * B + b) * 2 * BLK_STRIDE;
-  GoalOut go = goal_terms_wave(rb, sp, bp.goals + (size_t)b * sp.n_max * 16, bp.n_goals[b],
+  double* gblk = bp.goalblk + ((size_t)trial * B + b) * 2 * Blk<NP>::STRIDE;
+  GoalOut go = goal_terms_wave<NP>(rb, sp, bp.goals + (size_t)b * sp.n_max * 16, bp.n_goals[b],
                                bp.standoff ? bp.standoff + (size_t)b * 16 : nullptr, s_gaff, s_gscr, gblk, lane);
   // velocity term with eliminated velocities (gto/gto_planner.py:133-135)
   double fv = 0.0;
@@ -1396,10 +1410,11 @@ __device__ __forceinline__ void trial_goal_terms_wave(const RobotDev* rb, const 
 }
 
 // raw != 0: take Q0's optimised rows as they are (evaluation entry points); otherwise build the seed.
+template <int NP>
 __global__ __launch_bounds__(256) void k_lm_init(const RobotDev* __restrict__ rb, BatchPtrs bp, SolveParams sp, int B, int raw) {
   const int b = blockIdx.x, tid = threadIdx.x;
   __shared__ double s_gaff[48];
-  __shared__ double s_gscr[2 * GTO_MAX_OPT * 6];
+  __shared__ double s_gscr[2 * NP * 6];
   __shared__ double s_q[2 * GTO_MAX_DOF];
   __shared__ double s_fr[2 * GTO_MAX_FRAMES * 12];
   const int T = sp.T, n = rb->n_opt;
@@ -1450,7 +1465,7 @@ __global__ __launch_bounds__(256) void k_lm_init(const RobotDev* __restrict__ rb
       if (bp.slot_inst && b < bp.cap) bp.qfs[(size_t)b * T * F + idx] = v;  // slot b starts with instance b
     }
   }
-  if (tid < 64) trial_goal_terms_wave(rb, bp, sp, B, b, tid, 1, st, s_q, s_fr, s_gaff, s_gscr);
+  if (tid < 64) trial_goal_terms_wave<NP>(rb, bp, sp, B, b, tid, 1, st, s_q, s_fr, s_gaff, s_gscr);
 }
 
 // 1/x to full double precision: hardware seed + two Newton steps (no IEEE division sequence)
@@ -1943,7 +1958,7 @@ __global__ __launch_bounds__(256) void k_lm_step(const RobotDev* __restrict__ rb
 // wrenches (y x w, w), folded per wave and then in wave order (bit-reproducible); the collision term is
 // the PLAIN sum of the cost and enters the gradient only: b = J^T r + (w/2) sum_l sum_{j in anc(l)} s_j . v_l.
 __host__ __device__ inline int ik_lds_doubles(int F, int L, int n) {
-  return fk_tab_doubles(F, L, n) + 2 * F + fk_scratch_doubles(F) + L * 12 + GTO_MAX_OPT * 6 + 24 + 2 * BLK_STRIDE + 4 * L * 8 +
+  return fk_tab_doubles(F, L, n) + 2 * F + fk_scratch_doubles(F) + L * 12 + GTO_NB * 6 + 24 + 2 * BLK_STRIDE + 4 * L * 8 +
          2 * 64 + 2 * 8 + 8 + 8 + 8 + GTO_MAX_DOF + 16;
 }
 
@@ -1966,7 +1981,7 @@ __global__ __launch_bounds__(256, GTO_IK_MIN_WAVES) void k_ik_solve(const RobotD
   double* s_X = s_sc + 2 * F;
   double* s_vis = s_X + fk_scratch_doubles(F);
   double* s_screw = s_vis + L * 12;
-  double* s_gaff = s_screw + GTO_MAX_OPT * 6;  // gripper and ee affines
+  double* s_gaff = s_screw + GTO_NB * 6;  // gripper and ee affines
   double* s_gblk = s_gaff + 24;                // pose-term blocks (BLK_JTJ, BLK_JTR); goal_terms_wave clears a second one
   double* s_acc = s_gblk + 2 * BLK_STRIDE;     // [4 waves][L][8]: wrench sum (6), cost sum, -
   double* s_A = s_acc + 4 * L * 8;             // [2][64]
@@ -2208,7 +2223,7 @@ __global__ __launch_bounds__(256, GTO_IK_MIN_WAVES) void k_ik_solve(const RobotD
 #define GTO_MAX_BASE_GOALS 32
 #define GTO_BASE_SYS 112  // per goal: D 8x8 | C 8x3 | S 3x3 | g 3+8 | f
 __host__ __device__ inline int base_lds_doubles(int n_max) {
-  return GTO_MAX_DOF + 8 * GTO_MAX_DOF + 8 * GTO_MAX_FRAMES * 12 + 8 * 24 + 8 * GTO_MAX_OPT * 6 + 2 * n_max * GTO_BASE_SYS +
+  return GTO_MAX_DOF + 8 * GTO_MAX_DOF + 8 * GTO_MAX_FRAMES * 12 + 8 * 24 + 8 * GTO_NB * 6 + 2 * n_max * GTO_BASE_SYS +
          3 * (8 + 8 * n_max) + n_max * (24 + 8 + 16) + 32;
 }
 
@@ -2266,8 +2281,8 @@ __global__ __launch_bounds__(256) void k_base_solve(const RobotDev* __restrict__
   double* s_q = s_qc + GTO_MAX_DOF;             // [8][GTO_MAX_DOF]
   double* s_fr = s_q + 8 * GTO_MAX_DOF;         // [8][GTO_MAX_FRAMES*12]
   double* s_gaff = s_fr + 8 * GTO_MAX_FRAMES * 12;  // [8][24] gripper and ee affines
-  double* s_scr = s_gaff + 8 * 24;              // [8][GTO_MAX_OPT*6] joint screws
-  double* s_sys = s_scr + 8 * GTO_MAX_OPT * 6;  // [2][n_max][GTO_BASE_SYS]
+  double* s_scr = s_gaff + 8 * 24;              // [8][GTO_NB*6] joint screws
+  double* s_sys = s_scr + 8 * GTO_NB * 6;  // [2][n_max][GTO_BASE_SYS]
   double* s_x = s_sys + 2 * n_max * GTO_BASE_SYS;  // [8 + 8 n_max]: base pose in 0..2, goal i's joints at 8 + 8 i
   double* s_xt = s_x + NV;
   double* s_st = s_xt + NV;                     // projected step
@@ -2319,12 +2334,12 @@ __global__ __launch_bounds__(256) void k_base_solve(const RobotDev* __restrict__
       if (l >= 12 && l < 12 + n) {
         const int j = l - 12;
         for (int i = 0; i < F; ++i)
-          if (rb->opt_of_frame[i] == j) screw_of_frame(rb, i, fr + 12 * i, s_scr + slot8 * GTO_MAX_OPT * 6 + 6 * j);
+          if (rb->opt_of_frame[i] == j) screw_of_frame(rb, i, fr + 12 * i, s_scr + slot8 * GTO_NB * 6 + 6 * j);
       }
       wave_sync();
       if (valid) {
         const double* ga = s_gaff + 24 * slot8;
-        const double* scr = s_scr + slot8 * GTO_MAX_OPT * 6;
+        const double* scr = s_scr + slot8 * GTO_NB * 6;
         double Y0[12], Y[12];
         goal_target(ga, goals + ((size_t)b * n_max + gi) * 16, nullptr, Y0);
         // target pose seen from the current base: B RT G, B = rt2tr(rotz(theta), [x, y, 0])
@@ -2620,6 +2635,281 @@ __global__ __launch_bounds__(256) void k_base_solve(const RobotDev* __restrict__
     if (iters_out) iters_out[b] = k;
     if (status_out) status_out[b] = status;
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Step kernel for robots with 9..16 optimised joints (mobile manipulators: BASELINE configs[4]): the same accept / reject,
+// active set, block-tridiagonal solve, projected step and predicted decrease as k_lm_step, written for width, not for
+// latency.  One workgroup of 256 threads per slot; thread (r, c) = (tid >> 4, tid & 15) owns entry (r, c) of the 16x16
+// blocks (a 16-lane DPP row is a matrix row: mat-vec products reduce with row_sum16).  The block recursion runs forward
+// over all waypoints (Gauss-Jordan without pivoting on the SPD blocks, pivot row / column exchanged through LDS), the
+// inverses Z_s go to a workspace in HBM (L2) and come back for the back substitution.
+//   dynamic LDS (doubles): Q [NP][T] | b, y, x [m][NP] each | e [m][NP] | S [2][NP*NP] | red [32] ; int act [m]
+__host__ __device__ inline size_t lm_wide_lds_bytes(int T, int NP) {
+  const size_t m = (size_t)T - 2;
+  return ((size_t)NP * T + 4 * m * NP + 2 * NP * NP + 32) * sizeof(double) + (m + 8) * sizeof(int);
+}
+
+template <int NP>
+__global__ __launch_bounds__(256) void k_lm_step_wide(const RobotDev* __restrict__ rb, BatchPtrs bp, SolveParams sp, int B,
+                                                      double* __restrict__ Zws /* [slots][T-2][NP*NP] */) {
+  static_assert(NP == 16, "one thread per entry of a 16x16 block");
+  typedef Blk<NP> BK;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const bool listed = bp.slot_inst != nullptr;
+  const int slot_id = blockIdx.x;
+  const int b = listed ? bp.slot_inst[slot_id] : slot_id;
+  if (b < 0) return;  // empty slot
+  __shared__ int s_nid;
+  InstState* st = bp.state + b;
+  if (st->done) return;
+  extern __shared__ __attribute__((aligned(16))) double smem_w[];
+  const int T = sp.T, n = rb->n_opt, m = T - 2, nF = rb->n_frames;
+  double* s_Q = smem_w;                      // [NP][T]
+  double* s_b = s_Q + NP * T;                // [m][NP]
+  double* s_y = s_b + m * NP;
+  double* s_x = s_y + m * NP;
+  double* s_e = s_x + m * NP;
+  double* s_S = s_e + m * NP;                // [2][NP*NP] pivot exchange
+  double* s_red = s_S + 2 * NP * NP;         // [32]
+  int* s_act = reinterpret_cast<int*>(s_red + 32);  // [m] frozen-joint bit masks
+  const int r = tid >> 4, c = tid & 15;
+  const int trial = 1 - st->slot;
+  double* __restrict__ qfb = listed ? bp.qfs + (size_t)slot_id * T * nF : bp.qf + (size_t)b * T * nF;
+  double* __restrict__ Zb = Zws + (size_t)slot_id * m * NP * NP;
+
+  // ---- P0: objective of the trial point
+  double fo = 0.0;
+  {
+    const double* blk = bp.blocks + ((size_t)trial * B + b) * T * BK::STRIDE;
+    for (int t = 2 + lane; t < T; t += 64) fo += blk[(size_t)t * BK::STRIDE + BK::SS];
+    fo = wave_sum(fo);
+    fo += bp.ss_fixed[4 * b] + bp.ss_fixed[4 * b + 1];
+  }
+  const double f_try = st->fgoal_try + sp.w_obstacle * fo + st->fvel_try;
+  // ---- P1: accept / reject (uniform over the workgroup)
+  double f = st->f, lambda = st->lambda, nu = st->nu;
+  int slot = st->slot, done = 0, status = st->status;
+  const int k = st->evals;
+  const int argmin_try = st->argmin_try, argmin_cur0 = st->argmin_cur;
+  const double pred0 = st->pred;
+  bool accept = false;
+  if (st->first) {
+    accept = true;
+  } else if (f_try < f && pred0 > 0.0) {
+    accept = true;
+    const double df = f - f_try, rho = df / pred0;
+    const double sg = 2.0 * rho - 1.0;
+    double fac = 1.0 - sg * sg * sg;
+    fac = fmax(fac, 1.0 / 3.0);
+    lambda = fmax(lambda * fac, 1e-12);
+    nu = 2.0;
+    if (df <= sp.tol_rel_f * (1.0 + f_try)) {
+      status = GTO_STATUS_CONVERGED;
+      done = 1;
+    }
+  } else {
+    lambda *= nu;
+    nu *= 2.0;
+    if (lambda > 1e15) {
+      status = GTO_STATUS_CONVERGED;
+      done = 1;
+    }
+  }
+  double* __restrict__ Qc = bp.Qcur + (size_t)b * n * T;
+  double* __restrict__ Qt = bp.Qtry + (size_t)b * n * T;
+  if (accept) {
+    f = f_try;
+    slot = trial;
+  }
+  const int argmin_cur = accept ? argmin_try : argmin_cur0;
+  for (int idx = tid; idx < NP * T; idx += 256) {
+    const double v = idx < n * T ? (accept ? Qt : Qc)[idx] : 0.0;
+    s_Q[idx] = v;
+    if (accept && idx < n * T) Qc[idx] = v;
+  }
+  if (!done && k >= sp.max_iter) {
+    status = GTO_STATUS_MAX_ITER;
+    done = 1;
+  }
+#define GTO_FINISH_W(STATUS)                      \
+  do {                                            \
+    if (tid == 0) {                               \
+      st->f = f;                                  \
+      st->lambda = lambda;                        \
+      st->nu = nu;                                \
+      st->slot = slot;                            \
+      st->first = 0;                              \
+      st->done = 1;                               \
+      st->status = (STATUS);                      \
+      st->argmin_cur = argmin_cur;                \
+      atomicAdd(bp.n_done, 1);                    \
+      if (listed) {                               \
+        const int nid = atomicAdd(bp.next, 1);    \
+        s_nid = nid < bp.n_total ? nid : -1;      \
+        bp.slot_inst[slot_id] = s_nid;            \
+      }                                           \
+    }                                             \
+    if (listed) {                                 \
+      __syncthreads();                            \
+      const int nid = s_nid;                      \
+      if (nid >= 0)                               \
+        for (int i_ = tid; i_ < sp.T * nF; i_ += 256)     \
+          bp.qfs[(size_t)slot_id * sp.T * nF + i_] = bp.qf[(size_t)nid * sp.T * nF + i_]; \
+    }                                             \
+    return;                                       \
+  } while (0)
+  __syncthreads();
+  if (done) GTO_FINISH_W(status);
+
+  // ---- P2: gradient b = J^T r at the current iterate, active set, right-hand side
+  const double* __restrict__ oblk = bp.blocks + ((size_t)slot * B + b) * T * BK::STRIDE;
+  const double* __restrict__ gblk = bp.goalblk + ((size_t)slot * B + b) * 2 * BK::STRIDE;
+  const double alpha = sp.alpha;
+  for (int s = tid; s < m; s += 256) s_act[s] = 0;
+  __syncthreads();
+  for (int idx = tid; idx < m * NP; idx += 256) {
+    const int sI = idx / NP, i = idx % NP, t = sI + 2;
+    double bv = 0.0;
+    int act = 1;  // padded rows count as frozen
+    if (i < n) {
+      bv = sp.w_obstacle * oblk[(size_t)t * BK::STRIDE + BK::JTR + i];
+      if (t == T - 1) bv += gblk[BK::JTR + i];
+      if (sp.use_standoff && t == sp.ts) bv += gblk[BK::STRIDE + BK::JTR + i];
+      const double qt = s_Q[i * T + t], qm = s_Q[i * T + t - 1];
+      bv += alpha * (qt - qm);
+      if (t < T - 1) bv -= alpha * (s_Q[i * T + t + 1] - qt);
+      act = (qt <= rb->lower[i] && bv > 0.0) || (qt >= rb->upper[i] && bv < 0.0);
+    }
+    s_b[idx] = bv;
+    if (act) atomicOr(&s_act[sI], 1 << i);
+  }
+  __syncthreads();
+  for (int idx = tid; idx < m * NP; idx += 256) {
+    const int sI = idx / NP, i = idx % NP;
+    const int a0 = (s_act[sI] >> i) & 1;
+    const int a1 = (sI < m - 1) ? (s_act[sI + 1] >> i) & 1 : 1;
+    s_e[idx] = (a0 || a1) ? 0.0 : -alpha;
+    s_y[idx] = a0 ? 0.0 : -s_b[idx];
+  }
+  __syncthreads();
+  // undamped block entry (r, c) of waypoint s: obstacle + goal + velocity terms
+  const bool inb = r < n && c < n;
+  auto a_entry = [&](int s) {
+    const int t = s + 2;
+    double a = inb ? sp.w_obstacle * oblk[(size_t)t * BK::STRIDE + BK::JTJ + tid] : 0.0;
+    if (inb && r == c) a += (t == T - 1) ? alpha : 2.0 * alpha;
+    if (inb && t == T - 1) a += gblk[BK::JTJ + tid];
+    if (inb && sp.use_standoff && t == sp.ts) a += gblk[BK::STRIDE + BK::JTJ + tid];
+    return a;
+  };
+  // ---- P3: forward block recursion S_s = D_s - E Z_{s-1} E, Z_s = S_s^-1, y_s = Z_s (rhs_s - E y_{s-1})
+  int bad = 0;
+  {
+    double Zprev = 0.0;
+    double a_next = a_entry(0);
+    for (int s = 0; s < m; ++s) {
+      const double a = a_next;
+      if (s + 1 < m) a_next = a_entry(s + 1);  // the next block's loads fly during this block's inversion
+      const int am = s_act[s];
+      const bool frozen = ((am >> r) & 1) || ((am >> c) & 1);
+      double S = frozen ? (r == c ? 1.0 : 0.0) : (r == c ? a * (1.0 + lambda) : a);
+      double zc = s_y[s * NP + c];
+      if (s > 0) {
+        const double er = s_e[(s - 1) * NP + r], ec = s_e[(s - 1) * NP + c];
+        S -= er * ec * Zprev;
+        zc -= ec * s_x[(s - 1) * NP + c];  // s_x holds y during the forward sweep
+      }
+      // Gauss-Jordan, no pivoting (SPD): the pivot row and column go through LDS, two buffers, one barrier per pivot
+#pragma unroll 1
+      for (int j = 0; j < NP; ++j) {
+        double* buf = s_S + (j & 1) * NP * NP;
+        buf[tid] = S;
+        __syncthreads();
+        const double pjj = buf[j * NP + j], prj = buf[r * NP + j], pjc = buf[j * NP + c];
+        if (!(pjj > 0.0)) bad = 1;
+        const double piv = 1.0 / pjj;
+        const double tcol = -prj * piv;
+        const double in_row = (c == j) ? piv : pjc * piv;
+        const double off_row = (c == j) ? tcol : fma(tcol, pjc, S);
+        S = (r == j) ? in_row : off_row;
+      }
+      Zb[(size_t)s * NP * NP + tid] = S;
+      Zprev = S;
+      const double yr = row_sum16(S * zc);
+      __syncthreads();  // every thread has read y_{s-1} before it is needed no more... and the pivot buffers are free
+      if (c == 0) s_x[s * NP + r] = yr;
+      __syncthreads();
+    }
+  }
+  if (tid == 0) s_red[0] = 0.0;
+  __syncthreads();
+  if (bad) s_red[0] = 1.0;
+  __syncthreads();
+  if (s_red[0] != 0.0) GTO_FINISH_W(GTO_STATUS_NUMERICAL);
+  // ---- back substitution x_s = y_s - Z_s E_s x_{s+1}
+  {
+    double zn = m >= 2 ? Zb[(size_t)(m - 2) * NP * NP + tid] : 0.0;
+    for (int s = m - 2; s >= 0; --s) {
+      const double Z = zn;
+      if (s > 0) zn = Zb[(size_t)(s - 1) * NP * NP + tid];
+      const double pr = row_sum16(Z * (s_e[s * NP + c] * s_x[(s + 1) * NP + c]));
+      __syncthreads();
+      if (c == 0) s_x[s * NP + r] -= pr;
+      __syncthreads();
+    }
+  }
+  // ---- P4: projected trial point; s_x becomes the projected step
+  double maxstep = 0.0;
+  for (int idx = tid; idx < m * NP; idx += 256) {
+    const int sI = idx / NP, i = idx % NP, t = sI + 2;
+    double sv = 0.0;
+    if (i < n) {
+      const double q0 = s_Q[i * T + t];
+      double v = q0 + s_x[idx];
+      v = fmin(fmax(v, rb->lower[i]), rb->upper[i]);
+      Qt[(size_t)i * T + t] = v;
+      qfb[(size_t)t * nF + rb->opt_frame[i]] = v;  // the obstacle kernel reads joint values by frame
+      sv = v - q0;
+    }
+    s_x[idx] = sv;
+    maxstep = fmax(maxstep, fabs(sv));
+  }
+  if (tid < n * 2) Qt[(size_t)(tid >> 1) * T + (tid & 1)] = s_Q[(tid >> 1) * T + (tid & 1)];
+  maxstep = wave_max(maxstep);
+  if (lane == 0) s_red[1 + (tid >> 6)] = maxstep;
+  __syncthreads();
+  maxstep = fmax(fmax(s_red[1], s_red[2]), fmax(s_red[3], s_red[4]));
+  if (maxstep < sp.tol_step) GTO_FINISH_W(GTO_STATUS_CONVERGED);
+  // ---- P5: predicted decrease of the undamped model: -(2 b.s + s^T A s)
+  {
+    double part = 0.0;
+    for (int s = 0; s < m; ++s) {
+      const double sr = s_x[s * NP + r], scv = s_x[s * NP + c];
+      double v = a_entry(s) * sr * scv;
+      if (c == 0) {
+        const double xn = (s < m - 1) ? s_x[(s + 1) * NP + r] : 0.0;
+        v += 2.0 * sr * fma(-alpha, xn, s_b[s * NP + r]);
+      }
+      part += v;
+    }
+    part = wave_sum(part);
+    if (lane == 0) s_red[8 + (tid >> 6)] = part;
+  }
+  __syncthreads();
+  const double acc = (s_red[8] + s_red[9]) + (s_red[10] + s_red[11]);
+  if (tid == 0) {
+    st->f = f;
+    st->lambda = lambda;
+    st->nu = nu;
+    st->pred = -acc;
+    st->slot = slot;
+    st->first = 0;
+    st->status = status;
+    st->evals = k + 1;
+    st->argmin_cur = argmin_cur;
+  }
+#undef GTO_FINISH_W
 }
 
 __global__ __launch_bounds__(64) void k_lm_finalize(const RobotDev* __restrict__ rb, BatchPtrs bp, SolveParams sp, int B,

@@ -75,7 +75,7 @@ struct TrajLds {  // dynamic LDS layout in doubles, identical on host and device
     uni = o;
     int w = 0;
     oV = w;      w += G * L * 12;
-    oScr = w;    w += (G > 2 ? G : 2) * GTO_MAX_OPT * 6;  // the goal task uses two blocks whatever G is
+    oScr = w;    w += (G > 2 ? G : 2) * GTO_NB * 6;  // the goal task uses two blocks whatever G is
     oAli = w;    { const int fk = 4 * F * 2 + n_xst * 64, lst = TRAJ_LIST_CAP * 8; w += fk > lst ? fk : lst; }
     oGk = w;     w += 32;
     oSurv = w;   w += 64;
@@ -349,7 +349,7 @@ __global__ __launch_bounds__(64 * NW, 4) void k_traj_solve(
               const double o1 = quad_perm<1, 2, 0, 3>(ov), o2 = quad_perm<2, 0, 1, 3>(ov);
               const double cr = o1 * a2 - o2 * a1;
               if (bvalid && ra == 0 && rc < 3) {
-                double* sv = s_scr + (blk * GTO_MAX_OPT + j) * 6;
+                double* sv = s_scr + (blk * GTO_NB + j) * 6;
                 sv[rc] = prism ? 0.0 : av;
                 sv[3 + rc] = prism ? av : cr;
               }
@@ -426,8 +426,8 @@ __global__ __launch_bounds__(64 * NW, 4) void k_traj_solve(
             if (w1) s_gk[gk1] = gD[1];
             wave_sync();
             const uint32_t anc = __builtin_amdgcn_readlane(ldesc, fl);
-            const double* sr = s_scr + (fb * GTO_MAX_OPT + r) * 6;
-            const double* scc = s_scr + (fb * GTO_MAX_OPT + c) * 6;
+            const double* sr = s_scr + (fb * GTO_NB + r) * 6;
+            const double* scc = s_scr + (fb * GTO_NB + c) * 6;
             if (r < n && c < n && ((anc >> r) & 1u) && ((anc >> c) & 1u)) {
               double v = 0.0;
 #pragma unroll
@@ -440,7 +440,7 @@ __global__ __launch_bounds__(64 * NW, 4) void k_traj_solve(
               jtj += v;
             }
             if (lane < n && ((anc >> lane) & 1u)) {
-              const double* si = s_scr + (fb * GTO_MAX_OPT + lane) * 6;
+              const double* si = s_scr + (fb * GTO_NB + lane) * 6;
               jtr += si[0] * s_gk[21] + si[1] * s_gk[22] + si[2] * s_gk[23] + si[3] * s_gk[24] + si[4] * s_gk[25] + si[5] * s_gk[26];
             }
             acc_touched = true;

@@ -38,7 +38,8 @@ extern "C" {
 /* compile-time capacity of the kernels */
 #define GTO_MAX_FRAMES 32 /* kinematic frames after pruning            */
 #define GTO_MAX_LINKS 32  /* collision links carrying surface points   */
-#define GTO_MAX_OPT 8     /* optimised joints (Panda/Fetch arm: 7)      */
+#define GTO_MAX_OPT 16    /* optimised joints (Panda/Fetch arm: 7, mobile Fetch: 10); IK / base placement /
+                             GTO_MODE_SINGLE_LAUNCH: up to 8 */
 #define GTO_MAX_DOF 32    /* actuated joints (Panda 9, Fetch 15)        */
 
 /* joint types (optas/models.py:850-866) */
