@@ -105,6 +105,8 @@ def main():
     ap.add_argument("--max-iter", type=int, default=100, help="iteration cap (reference IPOPT cap: 100)")
     ap.add_argument("--robot", default="panda_5k")
     ap.add_argument("--grid", type=int, default=128)
+    ap.add_argument("--T", type=int, default=50, help="waypoints (reference: 50); the standoff waypoint stays a fifth of them from the end")
+    ap.add_argument("--shelf", action="store_true", help="shelf scene (boards and walls around the objects) instead of a table top")
     ap.add_argument("--mode", choices=["rounds", "single"], default="rounds", help="solver mode (include/gto_solver.h GTO_MODE_*)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--merged-launches-only", action="store_true",
@@ -150,7 +152,11 @@ def main():
     desc = load_builtin(args.robot)
     opts = _capi.default_opts()
     opts.max_iter = args.max_iter
+    opts.T = args.T
+    opts.standoff_offset = -max(2, args.T // 5)  # reference: T = 50, offset -10 (gto/gto_planner.py:22,25)
     T, ndof, B = opts.T, desc.ndof, args.batch
+    mobile = args.robot.endswith("_mobile")      # BASELINE configs[4]: --robot fetch_mobile --T 80 --grid 256 --shelf
+    default_pose = np.concatenate([np.zeros(ndof - len(cfg["default_pose"])), np.array(cfg["default_pose"], dtype=np.float64)])
     D, M = max(1, args.pipeline), max(1, args.merge)
     slots = int(os.environ.get("GTO_SLOTS", "384"))  # instances a solver call keeps in flight (gto_api.hip)
     mode = _capi.SolverHandle.MODE_SINGLE_LAUNCH if args.mode == "single" else _capi.SolverHandle.MODE_ROUNDS
@@ -163,7 +169,12 @@ def main():
     res = 2.24 / args.grid  # covers the 2.24 m reach box (0.0175 m at 128^3)
     origin = (-0.3, -1.12, 0.0) if fetch else (-0.4, -1.12, -0.4)
     table_z = 0.45 if fetch else -0.03
-    sc = syn.make_scene(scene_seed, n=args.grid, res=res, origin=origin, table_z=table_z)
+    if args.shelf:
+        table_z = 0.75
+    if mobile:  # the base roams +-1 m: a 4.48 m box around it
+        res, origin = 4.48 / args.grid, (-1.6, -2.24, -0.2)
+    make_scene = lambda seed: syn.make_scene(seed, n=args.grid, res=res, origin=origin, table_z=table_z, shelf=args.shelf)
+    sc = make_scene(scene_seed)
 
     # D pipeline lanes: each one solver handle bound to ONE stream of its own, with its own M batches (M consecutive
     # steps, grasp sets of its own) in HBM and its own outputs; a call solves m <= M of them at once
@@ -212,8 +223,10 @@ def main():
         return (val * moving[None, :]).sum(axis=1)
 
     zlim = (0.55, 1.2) if fetch else (0.08, 0.7)
+    if args.shelf:
+        zlim = (table_z + 0.07, table_z + 0.33)
     NB = M * B
-    qc = np.tile(np.array(cfg["default_pose"]), (NB, 1))
+    qc = np.tile(default_pose, (NB, 1))
     S = np.tile(syn.standoff_pose(-0.1, cfg["axis_standoff"]).reshape(1, 16), (NB, 1))
     base = np.zeros((NB, 3))
     lane_data = []
@@ -348,7 +361,7 @@ def main():
         hs_.set_mode(mode)
         rng_goal = {}
         for s_ in mine_sc:
-            scs = syn.make_scene(100 + int(s_), n=args.grid, res=res, origin=origin, table_z=table_z)
+            scs = make_scene(100 + int(s_))
             hs_.set_scene(int(s_), scs.c_all, scs.c_obs, scs.shape, scs.origin, scs.res)
 
             def cc(q, s_=int(s_)):
@@ -357,10 +370,10 @@ def main():
             rng_goal[int(s_)] = syn.make_goals(desc, hs_.eval_fk, cfg["link_ee"], SG, seed=7000 + int(s_), collision_cost=cc, zlim=zlim)
         # every rank needs the arguments of the whole list only for its own shard: the others' rows are never read
         nI = n_sc * SG
-        RTa, qga = np.tile(np.eye(4), (nI, 1, 1)), np.tile(np.array(cfg["default_pose"]), (nI, 1))
+        RTa, qga = np.tile(np.eye(4), (nI, 1, 1)), np.tile(default_pose, (nI, 1))
         for s_, (r_, q_) in rng_goal.items():
             RTa[s_ * SG:(s_ + 1) * SG], qga[s_ * SG:(s_ + 1) * SG] = r_, q_
-        qca = np.tile(np.array(cfg["default_pose"]), (nI, 1))
+        qca = np.tile(default_pose, (nI, 1))
         Q0a = np.stack([syn.make_seed(qca[i], qga[i], T, desc.param_index) for i in range(nI)])
         Sa = syn.standoff_pose(-0.1, cfg["axis_standoff"])
         sargs = (sid_all, qca, RTa.reshape(nI, 1, 16), 1, Sa, [0.0, 0.0, 0.0], Q0a)
@@ -468,7 +481,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": (f"BASELINE configs[2]-like: Fetch arm, 1 scene x {B} goal grasps per GPU, T={int(T)}, " if fetch else
+            "config": {"workload": (f"BASELINE configs[4]: Fetch on a planar base ({desc.n_opt} optimised joints), 1 scene x {B} goal grasps per GPU, T={int(T)}, " if mobile else
+                                    f"BASELINE configs[2]: Fetch arm, {'shelf' if args.shelf else 'table-top'} scene x {B} goal grasps per GPU, T={int(T)}, " if fetch else
                                     f"BASELINE configs[1]: Panda 7-DoF, 1 scene x {B} goal grasps per GPU, T={int(T)}, ") +
                                    f"{P} surface points, {args.grid}^3 f32 SDF cost field",
                        "batch_per_gpu": B, "T": int(T), "surface_points": int(P), "grid": args.grid,

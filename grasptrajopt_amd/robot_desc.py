@@ -204,12 +204,38 @@ class RobotDesc:
                    points=z["points"], normals=z["normals"].astype(np.float64), point_link=z["point_link"])
 
 
+def with_planar_base(desc: RobotDesc, xy_limit: float = 1.0, name: Optional[str] = None) -> RobotDesc:
+    """The same robot on a planar mobile base: three actuated joints (prismatic x, prismatic y, revolute about z) between a
+    fixed world frame and the old root, optimised together with the arm -- the mobile manipulator of
+    examples/pybullet_gto_planning_mobile.py with the base pose as part of the trajectory (BASELINE configs[4]: Fetch
+    arm 7 + base 3 = 10 optimised joints).  Joint order: the base joints first, then the robot's own."""
+    F0 = desc.n_frames
+    names = ["odom", "base_x", "base_y", "base_theta"] + list(desc.frame_names)
+    parent = np.concatenate([[-1, 0, 1, 2], np.where(desc.parent < 0, 3, desc.parent + 4)]).astype(np.int32)
+    jtype = np.concatenate([[JOINT_FIXED, JOINT_PRISMATIC, JOINT_PRISMATIC, JOINT_REVOLUTE], desc.joint_type]).astype(np.int32)
+    qidx = np.concatenate([[-1, 0, 1, 2], np.where(desc.q_index < 0, -1, desc.q_index + 3)]).astype(np.int32)
+    z3 = np.zeros((4, 3))
+    axis = np.concatenate([[[1.0, 0, 0], [1.0, 0, 0], [0, 1.0, 0], [0, 0, 1.0]], desc.axis])
+    out = RobotDesc(
+        name=name or desc.name + "_mobile", frame_names=names, parent=parent, joint_type=jtype, q_index=qidx,
+        origin_xyz=np.concatenate([z3, desc.origin_xyz]), origin_rpy=np.concatenate([z3, desc.origin_rpy]), axis=axis,
+        actuated_joint_names=["base_x", "base_y", "base_theta"] + list(desc.actuated_joint_names),
+        lower=np.concatenate([[-xy_limit, -xy_limit, -np.pi], desc.lower]), upper=np.concatenate([[xy_limit, xy_limit, np.pi], desc.upper]),
+        opt_index=np.concatenate([[0, 1, 2], desc.opt_index + 3]).astype(np.int32), param_index=(desc.param_index + 3).astype(np.int32),
+        link_names=list(desc.link_names), link_frame=(desc.link_frame + 4).astype(np.int32), visual_xyz=desc.visual_xyz.copy(),
+        visual_rpy=desc.visual_rpy.copy(), points=desc.points.copy(), normals=desc.normals.copy(), point_link=desc.point_link.copy())
+    assert out.n_frames == F0 + 4
+    return out
+
+
 _DATA_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
 
 
 def load_builtin(name: str) -> RobotDesc:
     """Distilled fixtures shipped with the package (tools/distill_robot.py): 'panda', 'fetch',
     'panda_5k' (12 x 417 points, the benchmark's ~5k-point robot)."""
+    if name.endswith("_mobile"):  # 'fetch_mobile': the Fetch arm on a planar base, 10 optimised joints
+        return with_planar_base(load_builtin(name[: -len("_mobile")]), name=name)
     prefix = os.path.join(_DATA_DIR, name)
     if not os.path.exists(prefix + ".npz"):
         raise FileNotFoundError(f"no built-in robot description '{name}' under {_DATA_DIR}")

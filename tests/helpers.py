@@ -19,7 +19,7 @@ class Problem:
     """A seeded batch of (scene, goal) instances for one robot."""
 
     def __init__(self, robot="panda", B=4, scene_seed=1, n=48, res=0.0467, n_goals=1, T=50, base=(0, 0, 0),
-                 use_standoff=True, fk=None):
+                 use_standoff=True, fk=None, shelf=False, scene_origin=None, table_z=None):
         self.robot = robot
         self.cfg = cfg_of(robot)
         self.desc = load_builtin(robot)
@@ -27,10 +27,12 @@ class Problem:
         origin = (-0.4, -1.12, -0.4)
         if robot.startswith("fetch"):
             origin = (-0.3, -1.12, 0.0)
-        self.scene = syn.make_scene(scene_seed, n=n, res=res, origin=origin,
-                                    table_z=0.45 if robot.startswith("fetch") else -0.03)
+        self.scene = syn.make_scene(scene_seed, n=n, res=res, origin=origin if scene_origin is None else scene_origin,
+                                    table_z=(0.45 if robot.startswith("fetch") else -0.03) if table_z is None else table_z, shelf=shelf)
         self.base = np.tile(np.asarray(base, dtype=np.float64), (B, 1))
-        self.qc = np.tile(np.array(self.cfg["default_pose"], dtype=np.float64), (B, 1))
+        pose = np.array(self.cfg["default_pose"], dtype=np.float64)
+        pose = np.concatenate([np.zeros(self.desc.ndof - len(pose)), pose])  # a planar base in front (robot_desc.with_planar_base)
+        self.qc = np.tile(pose, (B, 1))
         self.S = syn.standoff_pose(-0.1, self.cfg["axis_standoff"]) if use_standoff else None
         self._fk = fk
 

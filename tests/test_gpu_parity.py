@@ -679,3 +679,69 @@ def test_device_entry_point_on_caller_stream(capi, oracle_mod, mode):
     stream.synchronize()
     np.testing.assert_array_equal(ref[0], out[0].cpu().numpy())
     h.close()
+
+
+# ------------------------------------------------------------------------------------------ more than eight optimised joints
+@pytest.mark.parametrize("T,off,n_goals,grad", [(50, -10, 1, 0), (50, -10, 3, 0), (80, -16, 2, 0), (50, -10, 1, 1)])
+def test_mobile_fetch_ten_joints_matches_oracle(capi, oracle_mod, T, off, n_goals, grad):
+    """Fetch arm on a planar base (robot_desc.with_planar_base): 3 base + 7 arm = 10 optimised joints, the 16-wide blocks
+    (k_obstacle_gram<16>, k_lm_step_wide).  Objective terms, normal equations and the solve against the oracle."""
+    prob = Problem("fetch_mobile", B=6, scene_seed=5, n_goals=n_goals, T=T, shelf=True, table_z=0.75)
+    assert prob.desc.n_opt == 10
+    opts = oracle_mod.reference_opts(T=T, standoff_offset=off, grad_mode=grad, max_iter=40)
+    h = capi.SolverHandle(prob.desc, prob.cfg["link_ee"], prob.cfg["link_gripper"], opts, device=0)
+    o = oracle_mod.Oracle(prob.desc, prob.cfg["link_ee"], prob.cfg["link_gripper"], opts)
+    prob.finish(h.eval_fk)
+    h.set_scene(*prob.scene_args())
+    o.set_scene(*prob.scene_args())
+    np.testing.assert_allclose(h.eval_fk(prob.qgoal[:, 0]), o.eval_fk(prob.qgoal[:, 0]), rtol=0, atol=1e-12)
+    eg = h.eval_objective(0, prob.goals, n_goals, prob.S, prob.base, prob.Q0)
+    eo = o.eval_objective(0, prob.goals, n_goals, prob.S, prob.base, prob.Q0)
+    for a, b in zip(eg[:3], eo[:3]):
+        np.testing.assert_allclose(a, b, rtol=1e-10)
+    np.testing.assert_array_equal(eg[3], eo[3])
+    Jg, jg, sg = h.eval_obstacle_normal_eq(0, prob.base, prob.Q0)
+    Jo, jo, so = o.eval_obstacle_normal_eq(0, prob.base, prob.Q0)
+    sc = max(np.abs(Jo).max(), 1e-30)
+    np.testing.assert_allclose(Jg, Jo, rtol=0, atol=1e-10 * sc)
+    np.testing.assert_allclose(jg, jo, rtol=0, atol=1e-10 * max(np.abs(jo).max(), 1e-30))
+    np.testing.assert_allclose(sg, so, rtol=1e-10, atol=1e-300)
+    Qg, dQg, fg, itg, stg = h.solve_batch(*prob.solve_args())
+    Qo, dQo, fo, ito, sto = o.solve_batch(*prob.solve_args())
+    np.testing.assert_array_equal(itg, ito)
+    np.testing.assert_array_equal(stg, sto)
+    np.testing.assert_allclose(Qg, Qo, rtol=0, atol=1e-6)
+    np.testing.assert_allclose(fg, fo, rtol=1e-7)
+    _invariants(prob.desc, prob.qc, prob.Q0, Qg, dQg)
+    # the entry points that only exist for up to eight optimised joints say so
+    with pytest.raises(capi.GTOError, match="eight"):
+        h.solve_ik_batch(None, prob.qc, prob.goals[:, 0], None, 5)
+    h.set_mode(1)
+    with pytest.raises(capi.GTOError, match="eight"):
+        h.solve_batch(*prob.solve_args())
+    h.close()
+
+
+def test_mobile_fetch_baseline_config4_size(capi, oracle_mod):
+    """BASELINE configs[4]: mobile Fetch, 10 optimised joints, T = 80 waypoints, 256^3 cost field (1.2 GB resident with its
+    voxel records and distance fields), shelf scene.  Oracle on a sample, invariants and objective consistency on all."""
+    from grasptrajopt_amd import synthetic as syn
+    T, B = 80, 16
+    prob = Problem("fetch_mobile", B=B, scene_seed=8, n=256, res=0.0175, T=T, shelf=True, table_z=0.75, scene_origin=(-1.6, -2.24, -0.2))
+    assert prob.scene.shape == (256, 256, 256)
+    opts = oracle_mod.reference_opts(T=T, standoff_offset=-16, max_iter=30)
+    h = capi.SolverHandle(prob.desc, prob.cfg["link_ee"], prob.cfg["link_gripper"], opts, device=0)
+    prob.finish(h.eval_fk)
+    h.set_scene(*prob.scene_args())
+    Q, dQ, f, it, st = h.solve_batch(*prob.solve_args())
+    _invariants(prob.desc, prob.qc, prob.Q0, Q, dQ)
+    fg, fo, fv, _ = h.eval_objective(0, prob.goals, 1, prob.S, prob.base, Q)
+    np.testing.assert_allclose(fg + fo + fv, f, rtol=1e-10)
+    o = oracle_mod.Oracle(prob.desc, prob.cfg["link_ee"], prob.cfg["link_gripper"], opts)
+    o.set_scene(*prob.scene_args())
+    sel = [0, 7, 15]
+    Qo, _, fo_, ito, sto = o.solve_batch(0, prob.qc[sel], prob.goals[sel], 1, prob.S, prob.base[sel], prob.Q0[sel])
+    np.testing.assert_array_equal(it[sel], ito)
+    np.testing.assert_array_equal(st[sel], sto)
+    np.testing.assert_allclose(Q[sel], Qo, rtol=0, atol=1e-6)
+    h.close()
