@@ -235,6 +235,11 @@ def main():
                                collision_cost=goal_collision_cost, zlim=zlim) for m in range(M)]
         RT_, qg_ = np.concatenate([x[0] for x in sets]), np.concatenate([x[1] for x in sets])
         Q0_ = np.stack([syn.make_seed(qc[b], qg_[b], T, desc.param_index) for b in range(NB)])
+        if args.shelf:  # shelf scenes are planned with interpolate=False (examples/pybullet_gto_planning.py:98-109,
+            # gto/gto_planner.py:216-219): hold qc, jump to the IK solution at the standoff waypoint
+            hold = np.repeat(qc[:, :, None], T, axis=2)
+            hold[:, :, T + opts.standoff_offset:] = Q0_[:, :, -1:]
+            Q0_ = hold
         ln.upload(qc, RT_, S, base, Q0_)
         lane_data.append((RT_, Q0_))
     RT, Q0 = lane_data[0]
@@ -401,7 +406,18 @@ def main():
         # objective split of the instances that miss the goal thresholds: the velocity term outweighs the goal term there
         fgo, _, fve, _ = h.eval_objective(0, RT.reshape(NB, 1, 16), 1, S[0].reshape(4, 4), [0.0, 0.0, 0.0], Qsol)
         quality["f_goal_mean"], quality["f_vel_mean"] = round(float(fgo.mean()), 5), round(float(fve.mean()), 5)
-        gate_ok = quality["max_joint_limit_violation"] <= 1e-8 and quality["plan_cost_le_seed_frac"] >= 0.95
+        # solver invariant: the objective at the returned trajectory is never above the (clipped, pinned) seed's
+        seedc = Q0.copy()
+        oi_g = desc.opt_index
+        seedc[:, oi_g] = np.clip(seedc[:, oi_g], desc.lower[oi_g][None, :, None], desc.upper[oi_g][None, :, None])
+        seedc[:, :, :2] = qc[:, :, None]
+        sg_, so_, sv_, _ = h.eval_objective(0, RT.reshape(NB, 1, 16), 1, S[0].reshape(4, 4), [0.0, 0.0, 0.0], seedc)
+        quality["objective_le_seed_frac"] = round(float((cost <= (sg_ + so_ + sv_) * (1 + 1e-12)).mean()), 4)
+        # gate: joint limits and the objective invariant always; compute_plan_cost against the seed's where the seed is a
+        # collision-scored trajectory (interpolated seeds; the hold-and-jump seeds of shelf scenes cost nothing by construction)
+        gate_ok = quality["max_joint_limit_violation"] <= 1e-8 and quality["objective_le_seed_frac"] == 1.0
+        if not args.shelf:
+            gate_ok = gate_ok and quality["plan_cost_le_seed_frac"] >= 0.95
         quality["gate"] = "pass" if gate_ok else "FAIL"
         if not gate_ok:
             rc = 3
