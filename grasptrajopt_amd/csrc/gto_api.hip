@@ -39,7 +39,7 @@ struct gto_handle {
   SceneDev* d_scenes = nullptr;
   size_t d_scenes_cap = 0;
   // solve workspace (grown on demand)
-  DevBuf state, Qcur, Qtry, vis, screw, blocks, goalblk, ssfixed, ndone, qref, margin, qf, slotbuf, qfs;
+  DevBuf state, Qcur, Qtry, vis, screw, blocks, goalblk, ssfixed, ndone, qf, slotbuf, qfs;
   DevBuf trajws, evterms, evblocks, counters;  // k_traj_solve: block workspace, evaluation outputs, work counters
   int traj_nw = 8;        // wavefronts per workgroup (instance) of k_traj_solve: 4, 8 or 16 (GTO_TRAJ_NW)
   int traj_nw_few = 16;   // ... when a call has few instances (latency matters more than occupancy)
@@ -164,6 +164,8 @@ int gto_create(const gto_robot_desc* d, const gto_solver_opts* opts, int device,
   if (const char* e = getenv("GTO_CHECK_EVERY")) h->check_every = atoi(e);
   if (const char* e = getenv("GTO_DEBUG_CUT")) h->dbg_cut = atoi(e);
   if (const char* e = getenv("GTO_DEBUG_EXTRA_LDS")) h->dbg_extra_lds = (size_t)atoi(e);
+  if (h->dbg_cut) fprintf(stderr, "[gto] WARNING: GTO_DEBUG_CUT=%d cuts the obstacle kernel short: timing experiments only, RESULTS ARE GARBAGE\n", h->dbg_cut);
+  if (h->dbg_extra_lds || getenv("GTO_DEBUG_STEP_EXTRA_LDS")) fprintf(stderr, "[gto] WARNING: GTO_DEBUG_*EXTRA_LDS pads the kernels' LDS (occupancy experiments): slower, results unchanged\n");
   if (const char* e = getenv("GTO_SLOTS")) h->slots = std::max(1, atoi(e));
   if (const char* e = getenv("GTO_OBS_TG")) h->obs_tg = h->obs_tg_few = std::max(1, std::min(GTO_MAX_TG, atoi(e)));
   if (const char* e = getenv("GTO_OBS_TG_FEW")) h->obs_tg_few = std::max(1, std::min(GTO_MAX_TG, atoi(e)));
@@ -465,7 +467,7 @@ void gto_destroy(gto_handle* h) {
   (void)hipFree(h->d_plink);
   (void)hipFree(h->d_perm);
   (void)hipFree(h->d_chunks);
-  DevBuf* bufs[] = {&h->zws, &h->trajws, &h->evterms, &h->evblocks, &h->counters, &h->state, &h->Qcur, &h->Qtry, &h->vis, &h->screw, &h->blocks, &h->goalblk, &h->ssfixed, &h->ndone, &h->qref, &h->margin, &h->qf, &h->slotbuf, &h->qfs};
+  DevBuf* bufs[] = {&h->zws, &h->trajws, &h->evterms, &h->evblocks, &h->counters, &h->state, &h->Qcur, &h->Qtry, &h->vis, &h->screw, &h->blocks, &h->goalblk, &h->ssfixed, &h->ndone, &h->qf, &h->slotbuf, &h->qfs};
   if (h->h_ndone) (void)hipHostFree(h->h_ndone);
   for (int p = 0; p < 2; ++p)
     if (h->ev_chk[p]) (void)hipEventDestroy(h->ev_chk[p]);
@@ -543,6 +545,65 @@ int gto_set_scene(gto_handle* h, int32_t id, const float* c_all, const float* c_
   if (nvox >= ((size_t)1 << 31)) return fail(h, GTO_ERR_UNSUPPORTED, "field larger than 2^31 voxels");
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipStreamSynchronize(h->stream));
+  // Build the new scene completely first (fields, voxel records, distance fields), then swap it in and free the old one:
+  // a failure half-way leaves the table and the previous scene of this id untouched and frees what was allocated.
+  std::vector<void*> owned;
+  auto fail_free = [&](hipError_t e, const char* what) {
+    for (void* p : owned) (void)hipFree(p);
+    h->err = std::string(what) + ": " + hipGetErrorString(e);
+    return GTO_ERR_HIP;
+  };
+#define SCN(call)                                      \
+  do {                                                 \
+    hipError_t e_ = (call);                            \
+    if (e_ != hipSuccess) return fail_free(e_, #call); \
+  } while (0)
+  auto dalloc = [&](void** p, size_t bytes) {
+    hipError_t e = hipMalloc(p, bytes);
+    if (e == hipSuccess) owned.push_back(*p);
+    return e;
+  };
+  float *da = nullptr, *dob = nullptr;
+  SCN(dalloc((void**)&da, nvox * sizeof(float)));
+  SCN(hipMemcpy(da, c_all, nvox * sizeof(float), hipMemcpyHostToDevice));
+  if (c_obs && c_obs != c_all) {
+    SCN(dalloc((void**)&dob, nvox * sizeof(float)));
+    SCN(hipMemcpy(dob, c_obs, nvox * sizeof(float), hipMemcpyHostToDevice));
+  } else {
+    dob = da;
+  }
+  // gather-friendly voxel records (one-time, outside the timed solve)
+  VoxelRec *ra = nullptr, *rob = nullptr;
+  SCN(dalloc((void**)&ra, nvox * sizeof(VoxelRec)));
+  const unsigned nblk = (unsigned)((nvox + 255) / 256);
+  hipLaunchKernelGGL(k_build_records, dim3(nblk), dim3(256), 0, h->stream, da, ra, shape[0], shape[1], shape[2]);
+  if (dob != da) {
+    SCN(dalloc((void**)&rob, nvox * sizeof(VoxelRec)));
+    hipLaunchKernelGGL(k_build_records, dim3(nblk), dim3(256), 0, h->stream, dob, rob, shape[0], shape[1], shape[2]);
+  } else {
+    rob = ra;
+  }
+  // broad-phase distance fields: ping-pong relaxation, the scratch half is freed again
+  uint8_t *dista = nullptr, *distb = nullptr, *scratch = nullptr;
+  SCN(dalloc((void**)&scratch, nvox));
+  for (int which = 0; which < (rob != ra ? 2 : 1); ++which) {
+    uint8_t* d0 = nullptr;
+    SCN(dalloc((void**)&d0, nvox));
+    uint8_t* d1 = scratch;
+    hipLaunchKernelGGL(k_dist_init, dim3(nblk), dim3(256), 0, h->stream, which ? rob : ra, d0, (long)nvox);
+    for (int it = 0; it < GTO_DIST_CAP; ++it) {
+      hipLaunchKernelGGL(k_dist_relax, dim3(nblk), dim3(256), 0, h->stream, d0, d1, shape[0], shape[1], shape[2]);
+      std::swap(d0, d1);
+    }
+    // GTO_DIST_CAP is even: the result is back in the buffer allocated for it, `scratch` is scratch again
+    static_assert(GTO_DIST_CAP % 2 == 0, "ping-pong parity");
+    (which ? distb : dista) = d0;
+  }
+  if (rob == ra) distb = dista;
+  SCN(hipStreamSynchronize(h->stream));
+  SCN(hipGetLastError());
+  (void)hipFree(scratch);
+#undef SCN
   if ((size_t)id >= h->scenes.size()) {
     SceneDev z;
     memset(&z, 0, sizeof z);
@@ -551,51 +612,6 @@ int gto_set_scene(gto_handle* h, int32_t id, const float* c_all, const float* c_
   SceneDev& s = h->scenes[id];
   int rcf = free_scene(h, s);
   if (rcf) return rcf;
-  float *da = nullptr, *dob = nullptr;
-  HIPCHK(h, hipMalloc((void**)&da, nvox * sizeof(float)));
-  HIPCHK(h, hipMemcpy(da, c_all, nvox * sizeof(float), hipMemcpyHostToDevice));
-  if (c_obs && c_obs != c_all) {
-    HIPCHK(h, hipMalloc((void**)&dob, nvox * sizeof(float)));
-    HIPCHK(h, hipMemcpy(dob, c_obs, nvox * sizeof(float), hipMemcpyHostToDevice));
-  } else {
-    dob = da;
-  }
-  // gather-friendly voxel records (one-time, outside the timed solve)
-  VoxelRec *ra = nullptr, *rob = nullptr;
-  HIPCHK(h, hipMalloc((void**)&ra, nvox * sizeof(VoxelRec)));
-  const unsigned nblk = (unsigned)((nvox + 255) / 256);
-  hipLaunchKernelGGL(k_build_records, dim3(nblk), dim3(256), 0, h->stream, da, ra, shape[0], shape[1], shape[2]);
-  if (dob != da) {
-    HIPCHK(h, hipMalloc((void**)&rob, nvox * sizeof(VoxelRec)));
-    hipLaunchKernelGGL(k_build_records, dim3(nblk), dim3(256), 0, h->stream, dob, rob, shape[0], shape[1], shape[2]);
-  } else {
-    rob = ra;
-  }
-  // broad-phase distance fields
-  auto build_dist = [&](const VoxelRec* rec, uint8_t** out) -> int {
-    uint8_t *d0 = nullptr, *d1 = nullptr;
-    HIPCHK(h, hipMalloc((void**)&d0, nvox));
-    HIPCHK(h, hipMalloc((void**)&d1, nvox));
-    hipLaunchKernelGGL(k_dist_init, dim3(nblk), dim3(256), 0, h->stream, rec, d0, (long)nvox);
-    for (int it = 0; it < GTO_DIST_CAP; ++it) {
-      hipLaunchKernelGGL(k_dist_relax, dim3(nblk), dim3(256), 0, h->stream, d0, d1, shape[0], shape[1], shape[2]);
-      std::swap(d0, d1);
-    }
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    HIPCHK(h, hipFree(d1));
-    *out = d0;
-    return GTO_OK;
-  };
-  uint8_t *dista = nullptr, *distb = nullptr;
-  int rcd = build_dist(ra, &dista);
-  if (rcd) return rcd;
-  if (rob != ra) {
-    if ((rcd = build_dist(rob, &distb))) return rcd;
-  } else {
-    distb = dista;
-  }
-  HIPCHK(h, hipStreamSynchronize(h->stream));
-  HIPCHK(h, hipGetLastError());
   s.c_all = da;
   s.c_obs = dob;
   s.r_all = ra;
@@ -707,8 +723,6 @@ static int ensure_workspace(gto_handle* h, int B) {
   if ((rc = ensure(h, h->qf, (size_t)B * T * rb.n_frames * sizeof(double)))) return rc;
   if ((rc = ensure(h, h->slotbuf, ((size_t)std::min(B, h->slots) + 16) * sizeof(int32_t)))) return rc;
   if ((rc = ensure(h, h->qfs, (size_t)std::min(B, h->slots) * T * rb.n_frames * sizeof(double)))) return rc;
-  if ((rc = ensure(h, h->qref, (size_t)B * T * GTO_MAX_OPT * sizeof(double)))) return rc;
-  if ((rc = ensure(h, h->margin, (size_t)B * T * sizeof(int32_t)))) return rc;
   if (!h->h_ndone) HIPCHK(h, hipHostMalloc((void**)&h->h_ndone, 64));
   for (int p = 0; p < 2; ++p)
     if (!h->ev_chk[p]) HIPCHK(h, hipEventCreateWithFlags(&h->ev_chk[p], hipEventDisableTiming));
@@ -738,8 +752,6 @@ static BatchPtrs make_ptrs(gto_handle* h, const int32_t* scene_id, const double*
   bp.qfs = nullptr;
   bp.cap = 0;
   bp.n_total = 0;
-  bp.qref = (double*)h->qref.p;
-  bp.margin = (int32_t*)h->margin.p;
   bp.dbg = h->dbg;
   bp.work = nullptr;
   return bp;
@@ -969,7 +981,6 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
     fprintf(stderr, "[gto dbg] step-kernel phases (cycles) P0+P1 %lld | P2 %lld | diag %lld | dense %lld | back %lld | P4 %lld | P5 %lld | s_dense %lld\n",
             t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3], t[5] - t[4], t[6] - t[5], t[7] - t[6], t[9]);
     fprintf(stderr, "[gto dbg] P2 split (cycles): loads+barrier %lld | b-vector+masks %lld | blocks %lld | e,y+barrier %lld\n", t[28] - t[1], t[29] - t[28], t[30] - t[29], t[2] - t[30]);
-    fprintf(stderr, "[gto dbg] obstacle workgroups of active instances: %lld, with a margin %lld, culled %lld (over the whole solve)\n", t[40], t[41] + t[42], t[41]);
     fprintf(stderr, "[gto dbg] fk_mfma_tree (cycles): local %lld | rounds %lld %lld %lld %lld | outputs %lld\n", t[21] - t[20], t[22] - t[21], t[23] - t[22], t[24] - t[23], t[25] - t[24], t[27] - t[25]);
     fprintf(stderr, "[gto dbg] obstacle WG (b=0,t=T-1) cycles: prologue %lld | broad %lld | loop %lld | epilogue %lld | active chunks %lld | prologue up to the chain %lld\n",
             t[11] - t[10], t[12] - t[11], t[13] - t[12], t[14] - t[13], t[15], t[16] - t[10]);

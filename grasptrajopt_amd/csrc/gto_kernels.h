@@ -67,7 +67,6 @@ struct BatchPtrs {
   double* ss_fixed;  // [B][4]  sum c^2 of the two pinned waypoints; of the static links under c_all / c_obs
   int32_t* n_done;   // [1]     instances that have finished
   double* qf;        // [B][T][F] joint value of every frame of the trial trajectory (0 for fixed joints)
-  double* qref;      // [B][T][GTO_MAX_OPT] configuration at which `margin` was measured
   // slots: the solve loop keeps at most `cap` instances in flight.  slot_inst[i] is the instance slot i works on
   // (-1: none left); the step kernel of a slot whose instance finishes puts the next instance that has not
   // started into it (*next = id of that instance, n_total ids in all).  The joint values of the slot's trial
@@ -77,7 +76,6 @@ struct BatchPtrs {
   int32_t* next;       // [1]
   double* qfs;         // [cap][T][F]
   int32_t cap, n_total;
-  int32_t* margin;   // [B][T] voxels of clearance left at qref when the whole waypoint was in free space, else -1
   long long* dbg;    // optional: phase timestamps of instance 0's step kernel (GTO_DEBUG_TIMING)
   unsigned long long* work;  // [64] or null: surface points gathered (one voxel record or field value each), in 64 cells by blockIdx
 };
@@ -760,17 +758,10 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
   if (dbg_wg && tid == 0) bp.dbg[10] = clock64();
 
   // ---- prologue.  Every global load it needs is issued here, before the first branch that depends on one
-  // of them: ONE memory round trip for the instance state, the culling inputs, the joint values of the
+  // of them: ONE memory round trip for the instance state, the joint values of the
   // frames (bp.qf, written by the step kernel) and the operand table of fk_mfma_tree.
   if (sp.dbg_cut == 6) return;
   const int done = listed ? 0 : st->done, slot_cur = st->slot;  // a slot never holds a finished instance
-  const bool cull_try = TG == 1 && !fixed_mode;
-  const int mg = cull_try ? bp.margin[(size_t)b * T + t0w] : -1;
-  double dq_try = 0.0, dq_ref = 0.0;
-  if (cull_try && tid < n) {
-    dq_try = bp.Qtry[((size_t)b * n + tid) * T + t0w];
-    dq_ref = bp.qref[((size_t)b * T + t0w) * GTO_MAX_OPT + tid];
-  }
   // joint values of the group's waypoints: by slot in the solve loop (no dependence on the instance id)
   const double* __restrict__ qfp = listed ? bp.qfs + ((size_t)bi * T + t0w) * F : bp.qf + ((size_t)b * T + t0w) * F;
   const double qfv = tid < ng * F ? qfp[tid] : 0.0;
@@ -784,23 +775,6 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
   for (int u = 0; u < 6; ++u)
     if (tid + 256 * u < nt) s_ktab[tid + 256 * u] = tabv[u];
   for (int k = tid + 256 * 6; k < nt; k += 256) s_ktab[k] = rb->fk_tab[k];  // very large robots
-  // Temporal culling (exact): if at configuration qref every chunk of this waypoint was at least
-  // `margin` voxels clear of any non-zero voxel, and no surface point can have moved further than that
-  // since (|dx| <= sum_j |dq_j| reach_j), the waypoint still contributes exact zeros: write them and leave.
-  if (bp.dbg && tid == 0 && !fixed_mode) atomicAdd((unsigned long long*)(bp.dbg + 40), 1ull);
-  if (mg >= 0) {  // block-uniform
-    double dsum = tid < n ? fabs(dq_try - dq_ref) * rb->reach[tid] : 0.0;
-    if (tid < 64) dsum = wave_sum(dsum);
-    if (tid == 0) s_nactive = (rb->reach[0] >= 0.0 && (int)ceil(dsum * scenes[bp.scene_id[b]].rinv) <= mg) ? 1 : 0;
-    __syncthreads();
-    if (bp.dbg && tid == 0) atomicAdd((unsigned long long*)(bp.dbg + (s_nactive ? 41 : 42)), 1ull);
-    if (s_nactive) {
-      double* out = bp.blocks + (((size_t)(1 - slot_cur) * B + b) * T + t0w) * BK::STRIDE;
-      for (int i_ = tid; i_ < BK::STRIDE; i_ += 256) out[i_] = (i_ == BK::SS) ? bp.ss_fixed[4 * b + (t0w < sp.ts ? 2 : 3)] : 0.0;
-      return;
-    }
-    __syncthreads();
-  }
   if (sp.dbg_cut == 7) return;
   // sin/cos of every (waypoint, joint), one lane each
   if (tid < ng * F) {
@@ -848,7 +822,6 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
   // skipped.  Survivors keep (waypoint, link) order (ballot prefix): a wave still sees few key changes.
   auto use_all = [&](int kq_) { return static_only ? (t0v == 2) : ((t0w + kq_) < sp.ts); };
   const int C = rb->n_chunks;
-  int my_slack = 1 << 20;  // min over this thread's chunks of (distance - radius), voxels
   for (int base_c = 0; base_c < ng * C; base_c += 256) {
     const int gi = base_c + tid;
     bool keep = false;
@@ -873,14 +846,6 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
         const uint8_t* __restrict__ dist = use_all(kq) ? sc.d_all : sc.d_obs;
         const int dd = (int)dist[k2 + nz * (k1 + sc.ny * k0)];
         keep = dd <= R;
-        // clearance that also survives a move of the sphere: stay inside the grid and below the cap
-        int sl = dd - R;
-        sl = min(sl, min(min(k0, k1), k2) - R);
-        sl = min(sl, min(min(sc.nx - 1 - k0, sc.ny - 1 - k1), sc.nz - 1 - k2) - R);
-        sl = min(sl, GTO_DIST_CAP - 1 - R);
-        my_slack = min(my_slack, sl);
-      } else {
-        my_slack = -1000;
       }
     }
     const unsigned long long bm = __ballot(keep);
@@ -897,17 +862,6 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
     __syncthreads();
   }
   const int NA = s_nactive;
-  if (TG == 1 && !fixed_mode) {
-    // remember how much room this waypoint had (only if the whole waypoint was culled)
-    const int ms = wave_min_i32(my_slack);
-    if (lane == 0) s_wcount[wave] = ms;
-    __syncthreads();
-    if (tid < n) bp.qref[((size_t)b * T + t0w) * GTO_MAX_OPT + tid] = dq_try;
-    if (tid == 0) {
-      const int mall = min(min(s_wcount[0], s_wcount[1]), min(s_wcount[2], s_wcount[3]));
-      bp.margin[(size_t)b * T + t0w] = (NA == 0 && mall >= 2) ? mall - 2 : -1;
-    }
-  }
   // Contiguous range of surviving chunks per wave, cut at key changes only: a (waypoint, link) key is then
   // folded by exactly ONE wave, so a single Gram copy needs neither atomics nor per-wave copies, the result
   // is bit-reproducible, and the 15 KB of LDS saved buy a fourth workgroup per CU.  (A link has a handful
@@ -1315,6 +1269,7 @@ __device__ __forceinline__ GoalOut goal_terms_wave(const RobotDev* rb, const Sol
       besti = oi;
     }
   }
+  if (besti == 0x7fffffff) besti = 0;  // an empty or all-NaN goal set (the device entry point does not check its inputs)
   GoalOut out;
   out.f_goal = best;
   out.argmin = besti;
@@ -1431,7 +1386,6 @@ __global__ __launch_bounds__(256) void k_lm_init(const RobotDev* __restrict__ rb
     st->evals = 0;
     st->argmin_cur = 0;
   }
-  for (int t = tid; t < T; t += 256) bp.margin[(size_t)b * T + t] = -1;
   if (bp.slot_inst && tid == 0) {  // the first `cap` instances take the slots; the rest wait for one to free up
     if (b < bp.cap) bp.slot_inst[b] = b;
     if (b == 0) *bp.next = bp.cap;
