@@ -985,10 +985,10 @@ __global__ __launch_bounds__(64 * NW, 4) void k_traj_solve(
       status = GTO_STATUS_CONVERGED;
       break;
     }
-    // ---- P5: predicted decrease of the undamped model: -(2 b.s + s^T A s)
+    // ---- P5: predicted decrease of the undamped model: -(2 b.s + s^T A s), one partial sum per waypoint, the waypoints
+    // added up in a fixed order: the value does not depend on how many waves share the waypoints
     {
       const double c0 = (c == 0) ? 2.0 : 0.0;
-      double part = 0.0;
 #pragma unroll
       for (int kk = 0; kk < KMAX; ++kk) {
         const int s = wave + NW * kk;
@@ -996,23 +996,16 @@ __global__ __launch_bounds__(64 * NW, 4) void k_traj_solve(
           const double sr = s_x[s * 8 + r], scv = s_x[s * 8 + c];
           const double xn = (s < m - 1) ? s_x[(s + 1) * 8 + r] : 0.0;
           const double lin = c0 * fma(-alpha, xn, s_b[s * 8 + r]);
-          part = fma(sr, fma(av[kk], scv, lin), part);
+          const double pw = wave_sum(sr * fma(av[kk], scv, lin));
+          if (lane == 0) s_y[s] = pw;  // s_y is dead after the back-substitution
         }
       }
-      part = wave_sum(part);
-      __syncthreads();  // every wave has read s_red[4..] above
-      if (lane == 0) s_red[4 + wave] = part;
     }
     __syncthreads();
     {
-      // same association as four waves summing (s0 + s1) + (s2 + s3) when NW == 4; pairwise in general
       double acc = 0.0;
-      if (NW == 4) acc = (s_red[4] + s_red[5]) + (s_red[6] + s_red[7]);
-      else {
-#pragma unroll
-        for (int w = 0; w < NW; ++w) acc += s_red[4 + w];
-      }
-      pred = -acc;
+      for (int sI = lane; sI < m; sI += 64) acc += s_y[sI];
+      pred = -wave_sum(acc);
     }
     ++k;
     __syncthreads();  // the S-phase arrays are dead: the union region goes back to the waves
