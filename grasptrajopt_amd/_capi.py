@@ -106,6 +106,24 @@ def pack_robot_desc(desc: RobotDesc, link_ee: str, link_gripper: str,
 _lib = None
 
 
+def _preload_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so with the SONAME of the system
+    copy (libamdhip64.so.7) but link it by file name: if libgto_hip.so pulls in /opt/rocm's copy first and torch is
+    imported afterwards, a second runtime is mapped next to it and finds no devices ("No HIP GPUs are available").
+    Mapping torch's copy first (when there is a torch) makes every later lookup, by SONAME or by file, land on it."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    for loc in (spec.submodule_search_locations if spec and spec.submodule_search_locations else []):
+        cand = os.path.join(loc, "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+            return cand
+    return None
+
+
 def load_library(path: Optional[str] = None):
     """Load libgto_hip.so (built by __graft_entry__.build()). Raises if it is not there."""
     global _lib
@@ -116,6 +134,7 @@ def load_library(path: Optional[str] = None):
         raise RuntimeError(
             f"HIP library not found at {p}: run `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback for the GTO solve path.")
+    _preload_hip_runtime()
     lib = C.CDLL(p)
     H = C.c_void_p
     lib.gto_default_opts.argtypes = [C.POINTER(CSolverOpts)]

@@ -45,6 +45,7 @@ struct InstState {
 
 struct SolveParams {
   int32_t T, ts, use_standoff, n_max, max_iter, grad_mode;
+  int32_t interleave;  // obstacle kernel: waypoints of a group nG apart (1) instead of consecutive (0); same results
   int32_t dbg_cut;  // debug: leave the obstacle kernel after phase k (1 prologue, 2 broad phase, 3 loop); 0 = off
   double dt, alpha, w_obstacle, w_vel, tol_step, tol_rel_f, lambda0;
 };
@@ -753,7 +754,12 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
   const int t0v = t_begin + grp_id * TG;                 // first (virtual) waypoint of this group
   const bool static_only = fixed_mode && t0v >= 2;
   const int t0w = static_only ? 0 : t0v;                 // waypoint whose configuration is used
-  const int ng = static_only ? 1 : min(TG, (fixed_mode ? 2 : t_begin + nT) - t0v);  // waypoints in this group
+  // Waypoints of the group: consecutive, or (solve loop, sp.interleave) nG apart, so that the few waypoints next to the
+  // obstacles, which are neighbours in time, land in different workgroups.  The results do not depend on the grouping.
+  const bool inter = sp.interleave && !fixed_mode;
+  const int wstep = inter ? nG : 1, w0 = inter ? t_begin + grp_id : t0w;
+  const int ng = static_only ? 1 : (inter ? (nT - grp_id + nG - 1) / nG : min(TG, (fixed_mode ? 2 : t_begin + nT) - t0v));  // waypoints in this group
+  auto wp = [&](int kq_) { return w0 + kq_ * wstep; };    // waypoint of the group's kq-th member
   const bool dbg_wg = bp.dbg && b == 0 && grp_id == nG - 1;
   if (dbg_wg && tid == 0) bp.dbg[10] = clock64();
 
@@ -763,8 +769,9 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
   if (sp.dbg_cut == 6) return;
   const int done = listed ? 0 : st->done, slot_cur = st->slot;  // a slot never holds a finished instance
   // joint values of the group's waypoints: by slot in the solve loop (no dependence on the instance id)
-  const double* __restrict__ qfp = listed ? bp.qfs + ((size_t)bi * T + t0w) * F : bp.qf + ((size_t)b * T + t0w) * F;
-  const double qfv = tid < ng * F ? qfp[tid] : 0.0;
+  const double* __restrict__ qfp = listed ? bp.qfs + ((size_t)bi * T + w0) * F : bp.qf + ((size_t)b * T + w0) * F;
+  const int qstride = (wstep - 1) * F;  // extra offset per group member
+  const double qfv = tid < ng * F ? qfp[tid + (inter ? (tid / F) * qstride : 0)] : 0.0;
   const int jtv = tid < ng * F ? rb->joint_type[tid % F] : GTO_JOINT_FIXED;
   const int nt = fk_tab_doubles(F, L, n);  // rb->fk_tab is packed for exactly this (F, L, n)
   double tabv[6];
@@ -786,7 +793,7 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
   }
   for (int idx = tid + 256; idx < ng * F; idx += 256) {  // waypoint groups of very large robots
     const int jt = rb->joint_type[idx % F];
-    const double qv = qfp[idx];
+    const double qv = qfp[idx + (idx / F) * qstride];
     double a = 0.0, c = 1.0;
     if (jt == GTO_JOINT_REVOLUTE) sincos(qv, &a, &c);
     else if (jt == GTO_JOINT_PRISMATIC) a = qv;
@@ -820,7 +827,7 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
   // looks up the Chebyshev distance to the nearest non-zero voxel; a chunk whose sphere (radius R voxels,
   // +2 for the floor of the centre and index rounding) cannot reach one contributes exact zeros and is
   // skipped.  Survivors keep (waypoint, link) order (ballot prefix): a wave still sees few key changes.
-  auto use_all = [&](int kq_) { return static_only ? (t0v == 2) : ((t0w + kq_) < sp.ts); };
+  auto use_all = [&](int kq_) { return static_only ? (t0v == 2) : (wp(kq_) < sp.ts); };
   const int C = rb->n_chunks;
   for (int base_c = 0; base_c < ng * C; base_c += 256) {
     const int gi = base_c + tid;
@@ -1130,10 +1137,11 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
     if (tid < ng) bp.ss_fixed[4 * b + t0v + tid] = s_out[tid * BK::STRIDE + BK::SS];
   } else {
     // add the constant contribution of the static links (measured once at init)
-    if (tid < ng) s_out[tid * BK::STRIDE + BK::SS] += bp.ss_fixed[4 * b + ((t0w + tid) < sp.ts ? 2 : 3)];
+    if (tid < ng) s_out[tid * BK::STRIDE + BK::SS] += bp.ss_fixed[4 * b + (wp(tid) < sp.ts ? 2 : 3)];
     __syncthreads();
-    double* out = bp.blocks + (((size_t)(1 - slot_cur) * B + b) * T + t0w) * BK::STRIDE;
-    for (int i = tid; i < ng * BK::STRIDE; i += 256) out[i] = s_out[i];
+    double* out = bp.blocks + (((size_t)(1 - slot_cur) * B + b) * T + w0) * BK::STRIDE;
+    const int ostride = (wstep - 1) * BK::STRIDE;
+    for (int i = tid; i < ng * BK::STRIDE; i += 256) out[i + (i / BK::STRIDE) * ostride] = s_out[i];
   }
 }
 
