@@ -48,6 +48,9 @@ struct gto_handle {
   int mode = GTO_MODE_ROUNDS;  // gto_set_mode / GTO_MODE: rounds of two launches over slots, or one launch per call (gto_traj.h)
   unsigned long long last_counters[4] = {0, 0, 0, 0};
   int32_t* h_ndone = nullptr;  // pinned
+  unsigned long long* h_progress = nullptr;  // pinned, device-visible: (call tag << 32 | finished) written by the step kernel
+  unsigned long long* d_progress = nullptr;  // its device address
+  unsigned progress_tag = 0;
   int check_every = 4;
   hipEvent_t ev_chk[2] = {nullptr, nullptr};
   int dbg_cut = 0;
@@ -474,6 +477,7 @@ void gto_destroy(gto_handle* h) {
   (void)hipFree(h->d_chunks);
   DevBuf* bufs[] = {&h->zws, &h->trajws, &h->evterms, &h->evblocks, &h->counters, &h->state, &h->Qcur, &h->Qtry, &h->vis, &h->screw, &h->blocks, &h->goalblk, &h->ssfixed, &h->ndone, &h->qf, &h->slotbuf, &h->qfs};
   if (h->h_ndone) (void)hipHostFree(h->h_ndone);
+  if (h->h_progress) (void)hipHostFree(h->h_progress);
   for (int p = 0; p < 2; ++p)
     if (h->ev_chk[p]) (void)hipEventDestroy(h->ev_chk[p]);
   for (DevBuf* b : bufs) (void)hipFree(b->p);
@@ -730,6 +734,11 @@ static int ensure_workspace(gto_handle* h, int B) {
   if ((rc = ensure(h, h->slotbuf, ((size_t)std::min(B, h->slots) + 16) * sizeof(int32_t)))) return rc;
   if ((rc = ensure(h, h->qfs, (size_t)std::min(B, h->slots) * T * rb.n_frames * sizeof(double)))) return rc;
   if (!h->h_ndone) HIPCHK(h, hipHostMalloc((void**)&h->h_ndone, 64));
+  if (!h->h_progress) {
+    HIPCHK(h, hipHostMalloc((void**)&h->h_progress, 64, hipHostMallocMapped));
+    *h->h_progress = 0ull;
+    HIPCHK(h, hipHostGetDevicePointer((void**)&h->d_progress, h->h_progress, 0));
+  }
   for (int p = 0; p < 2; ++p)
     if (!h->ev_chk[p]) HIPCHK(h, hipEventCreateWithFlags(&h->ev_chk[p], hipEventDisableTiming));
   return GTO_OK;
@@ -737,7 +746,7 @@ static int ensure_workspace(gto_handle* h, int B) {
 
 static BatchPtrs make_ptrs(gto_handle* h, const int32_t* scene_id, const double* qc, const double* goals,
                            const int32_t* n_goals, const double* standoff, const double* base_pos, const double* Q0) {
-  BatchPtrs bp;
+  BatchPtrs bp = {};
   bp.scene_id = scene_id;
   bp.qc = qc;
   bp.goals = goals;
@@ -933,6 +942,11 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
   bp.n_total = B;
   const size_t ndof = h->rb.ndof;
   HIPCHK(h, hipMemsetAsync(bp.n_done, 0, sizeof(int32_t), st));
+  // the finished-counter reaches the host through a word in pinned memory that the step kernel writes; the tag tells
+  // this call's values from what the last launches of the previous call may still be writing
+  h->progress_tag = h->progress_tag + 1 ? h->progress_tag + 1 : 1;
+  bp.progress = h->d_progress;
+  bp.progress_tag = (unsigned long long)h->progress_tag << 32;
   if (h->profiling) {
     if ((rc = ensure(h, h->counters, 64 * sizeof(unsigned long long)))) return rc;
     bp.work = (unsigned long long*)h->counters.p;
@@ -962,21 +976,23 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
     // read-back every 8 rounds cost 25-30 us of idle GPU each).  The price is a few rounds of empty launches
     // after the last instance finishes.
     if (h->check_every > 0 && (k % h->check_every) == h->check_every - 1 && k < max_rounds) {
+      // throttle: never more than two check intervals ahead of the GPU (an event, no copy: the counter itself arrives
+      // through the progress word)
       const int p = n_checks & 1;
-      HIPCHK(h, hipMemcpyAsync(h->h_ndone + p, bp.n_done, sizeof(int32_t), hipMemcpyDeviceToHost, st));
       HIPCHK(h, hipEventRecord(h->ev_chk[p], st));
       if (n_checks > 0) {
         // sleep-poll instead of hipEventSynchronize: the runtime spins there, one host core per lane, and a node
-        // with 8 GPUs x 4 lanes may not have 32 cores to burn; the check is four rounds old, 50 us do not matter
+        // with 8 GPUs x 4 lanes may not have 32 cores to burn; 50 us do not matter
         for (;;) {
           const hipError_t qe = hipEventQuery(h->ev_chk[1 - p]);
           if (qe == hipSuccess) break;
           if (qe != hipErrorNotReady) HIPCHK(h, qe);
           std::this_thread::sleep_for(std::chrono::microseconds(50));
         }
-        known_done = h->h_ndone[1 - p];
-        if (known_done >= B) live = false;
       }
+      const unsigned long long pv = *(volatile unsigned long long*)h->h_progress;
+      if ((unsigned)(pv >> 32) == h->progress_tag) known_done = std::max(known_done, (int)(pv & 0xffffffffull));
+      if (known_done >= B) live = false;
       ++n_checks;
     }
   }

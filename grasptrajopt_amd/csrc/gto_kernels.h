@@ -78,6 +78,10 @@ struct BatchPtrs {
   double* qfs;         // [cap][T][F]
   int32_t cap, n_total;
   long long* dbg;    // optional: phase timestamps of instance 0's step kernel (GTO_DEBUG_TIMING)
+  // progress word in pinned host memory (or null): the first workgroup of every step launch publishes
+  // (call tag << 32 | instances finished so far); the host polls it instead of copying n_done back through the stream
+  unsigned long long* progress;
+  unsigned long long progress_tag;
   unsigned long long* work;  // [64] or null: surface points gathered (one voxel record or field value each), in 64 cells by blockIdx
 };
 
@@ -1473,6 +1477,10 @@ __device__ __forceinline__ double matvec8(double Z, double zc) {
 // spread over the four waves by waypoint, the serial block recursion runs on wave 0.
 __global__ __launch_bounds__(256) void k_lm_step(const RobotDev* __restrict__ rb, BatchPtrs bp, SolveParams sp, int B) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (blockIdx.x == 0 && threadIdx.x == 0 && bp.progress) {  // lagged by design: what had finished when this launch started
+    const int nd = __hip_atomic_load(bp.n_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(bp.progress, bp.progress_tag | (unsigned long long)(unsigned)nd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
   const bool listed = bp.slot_inst != nullptr;  // solve loop: one workgroup per slot
   const int slot_id = blockIdx.x;
   const int b = listed ? bp.slot_inst[slot_id] : slot_id;
@@ -2618,6 +2626,10 @@ __global__ __launch_bounds__(256) void k_lm_step_wide(const RobotDev* __restrict
   static_assert(NP == 16, "one thread per entry of a 16x16 block");
   typedef Blk<NP> BK;
   const int tid = threadIdx.x, lane = tid & 63;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && bp.progress) {  // lagged by design: what had finished when this launch started
+    const int nd = __hip_atomic_load(bp.n_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(bp.progress, bp.progress_tag | (unsigned long long)(unsigned)nd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
   const bool listed = bp.slot_inst != nullptr;
   const int slot_id = blockIdx.x;
   const int b = listed ? bp.slot_inst[slot_id] : slot_id;
