@@ -1399,7 +1399,16 @@ int gto_plan_cost(gto_handle* h, int32_t scene_id, int32_t n, const double* plan
   if ((rc = stage_in(h, 1, base_pos, 3 * sizeof(double), &dbase))) return rc;
   std::vector<double> part((size_t)n * T);
   if ((rc = stage_out(h, 0, part.data(), part.size() * sizeof(double), &dpart))) return rc;
-  hipLaunchKernelGGL(k_plan_cost, dim3((unsigned)T, n), dim3(256), 0, h->stream, h->d_rb, h->d_px, h->d_py, h->d_pz, h->d_plink,
+  const size_t pc_lds = sizeof(double) * plan_cost_lds_doubles(h->rb.n_frames, h->rb.n_links, h->rb.n_opt);
+  if (pc_lds > 150 * 1024) return fail(h, GTO_ERR_UNSUPPORTED, "robot too large for the plan-cost kernel's LDS");
+  {
+    static size_t pc_attr = 48 * 1024;  // process-wide per kernel: only ever raised
+    if (pc_lds > pc_attr) {
+      HIPCHK(h, hipFuncSetAttribute((const void*)k_plan_cost, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pc_lds));
+      pc_attr = pc_lds;
+    }
+  }
+  hipLaunchKernelGGL(k_plan_cost, dim3((unsigned)((T + GTO_PLAN_TG - 1) / GTO_PLAN_TG), n), dim3(256), pc_lds, h->stream, h->d_rb, h->d_px, h->d_py, h->d_pz, h->d_plink,
                      h->d_scenes + scene_id, (int)T, (const double*)dplans, (const double*)dbase, (double*)dpart);
   if ((rc = fetch_out(h, 0, part.data(), part.size() * sizeof(double)))) return rc;
   HIPCHK(h, hipStreamSynchronize(h->stream));

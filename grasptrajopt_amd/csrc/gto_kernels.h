@@ -2978,34 +2978,72 @@ __global__ void k_eval_points(const RobotDev* __restrict__ rb, const double* __r
 }
 
 // compute_plan_cost (gto/gto_models.py:204-215): block per (plan, waypoint), plain sum of c_obs
+#define GTO_PLAN_TG 4  // waypoints per workgroup of k_plan_cost
+__host__ __device__ inline int plan_cost_lds_doubles(int F, int L, int n) {
+  return fk_tab_doubles(F, L, n) + GTO_PLAN_TG * F * 2 + fk_scratch_doubles(F, GTO_PLAN_TG) + GTO_PLAN_TG * L * 12 + GTO_PLAN_TG * GTO_NB * 6 + 4 * GTO_PLAN_TG;
+}
+// One workgroup per (plan, group of four waypoints): kinematics of the four configurations on the matrix cores
+// (fk_mfma_tree, as in the obstacle kernel), then every thread walks its surface points once for all four waypoints.
+// The per-waypoint sums are formed in the order thread-strided partial sums -> wave -> waves 0..3.
 __global__ __launch_bounds__(256) void k_plan_cost(const RobotDev* __restrict__ rb, const double* __restrict__ px,
                                                    const double* __restrict__ py, const double* __restrict__ pz,
                                                    const int32_t* __restrict__ plink, const SceneDev* __restrict__ scene,
                                                    int T, const double* __restrict__ plans, const double* __restrict__ base,
                                                    double* __restrict__ partial /*[n][T]*/) {
-  const int t = blockIdx.x, i = blockIdx.y, tid = threadIdx.x;
-  __shared__ double s_vis[GTO_MAX_LINKS * 12];
-  __shared__ double s_red[4];
-  if (tid == 0) {
-    double q[GTO_MAX_DOF];
-    for (int j = 0; j < rb->ndof; ++j) q[j] = plans[((size_t)i * rb->ndof + j) * T + t];
-    kin_eval(rb, q, s_vis, nullptr, nullptr);
+  constexpr int TG = GTO_PLAN_TG;
+  const int t0 = blockIdx.x * TG, i = blockIdx.y, tid = threadIdx.x;
+  const int F = rb->n_frames, L = rb->n_links, n = rb->n_opt, ndof = rb->ndof;
+  const int ng = min(TG, T - t0);
+  extern __shared__ __attribute__((aligned(16))) double smem_pc[];
+  double* s_tab = smem_pc;
+  double* s_sc = s_tab + fk_tab_doubles(F, L, n);  // [TG][F][2]
+  double* s_X = s_sc + TG * F * 2;
+  double* s_vis = s_X + fk_scratch_doubles(F, TG);  // [TG][L][12]
+  double* s_screw = s_vis + TG * L * 12;            // [TG][GTO_NB][6] (by-product of the kinematics, unused here)
+  double* s_red = s_screw + TG * GTO_NB * 6;        // [4][TG]
+  const int nt = fk_tab_doubles(F, L, n);
+  for (int k = tid; k < nt; k += 256) s_tab[k] = rb->fk_tab[k];
+  for (int idx = tid; idx < ng * F; idx += 256) {
+    const int kq = idx / F, f = idx - kq * F;
+    const int jt = rb->joint_type[f], dq = rb->q_index[f];
+    double a = 0.0, cs = 1.0;
+    if (dq >= 0) {
+      const double qv = plans[((size_t)i * ndof + dq) * T + t0 + kq];
+      if (jt == GTO_JOINT_REVOLUTE) sincos(qv, &a, &cs);
+      else if (jt == GTO_JOINT_PRISMATIC) a = qv;
+    }
+    s_sc[2 * idx] = a;
+    s_sc[2 * idx + 1] = cs;
   }
+  __syncthreads();
+  fk_mfma_tree(rb, s_tab, ng, s_sc, s_X, reinterpret_cast<int*>(s_X + ng * 32 * F + 64), tid, s_vis, s_screw);
   __syncthreads();
   const SceneDev sc = *scene;
-  double acc = 0.0;
+  const double b0 = base[0], b1 = base[1], b2 = base[2];
+  double acc[TG];
+#pragma unroll
+  for (int g = 0; g < TG; ++g) acc[g] = 0.0;
   for (int p = tid; p < rb->n_points; p += 256) {
-    const double* V = s_vis + 12 * plink[p];
     const double x0 = px[p], x1 = py[p], x2 = pz[p];
-    const int ix = voxel_axis(V[0] * x0 + V[1] * x1 + V[2] * x2 + V[3] + base[0], sc.ox, sc.res, sc.rinv, sc.nx);
-    const int iy = voxel_axis(V[4] * x0 + V[5] * x1 + V[6] * x2 + V[7] + base[1], sc.oy, sc.res, sc.rinv, sc.ny);
-    const int iz = voxel_axis(V[8] * x0 + V[9] * x1 + V[10] * x2 + V[11] + base[2], sc.oz, sc.res, sc.rinv, sc.nz);
-    acc += (double)sc.c_obs[iz + sc.nz * (iy + sc.ny * ix)];
+    const int l = plink[p];
+#pragma unroll
+    for (int g = 0; g < TG; ++g) {
+      if (g < ng) {
+        const double* V = s_vis + (g * L + l) * 12;
+        const int ix = voxel_axis(V[0] * x0 + V[1] * x1 + V[2] * x2 + V[3] + b0, sc.ox, sc.res, sc.rinv, sc.nx);
+        const int iy = voxel_axis(V[4] * x0 + V[5] * x1 + V[6] * x2 + V[7] + b1, sc.oy, sc.res, sc.rinv, sc.ny);
+        const int iz = voxel_axis(V[8] * x0 + V[9] * x1 + V[10] * x2 + V[11] + b2, sc.oz, sc.res, sc.rinv, sc.nz);
+        acc[g] += (double)sc.c_obs[iz + sc.nz * (iy + sc.ny * ix)];
+      }
+    }
   }
-  acc = wave_sum(acc);
-  if ((tid & 63) == 0) s_red[tid >> 6] = acc;
+#pragma unroll
+  for (int g = 0; g < TG; ++g) {
+    const double v = wave_sum(acc[g]);
+    if ((tid & 63) == 0) s_red[(tid >> 6) * TG + g] = v;
+  }
   __syncthreads();
-  if (tid == 0) partial[(size_t)i * T + t] = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+  if (tid < ng) partial[(size_t)i * T + t0 + tid] = ((s_red[tid] + s_red[TG + tid]) + s_red[2 * TG + tid]) + s_red[3 * TG + tid];
 }
 
 // ------------------------------------------------------------------------------------------------
