@@ -257,6 +257,27 @@ def test_slots_hand_over_to_waiting_instances(capi, oracle_mod, monkeypatch, slo
     h.close()
 
 
+@pytest.mark.parametrize("knob,value", [("GTO_OBS_TG", "1"), ("GTO_OBS_TG", "2"), ("GTO_OBS_TG", "4"), ("GTO_OBS_INTERLEAVE", "0"),
+                                        ("GTO_OBS_INTERLEAVE", "1"), ("GTO_CHECK_EVERY", "1"), ("GTO_CHECK_EVERY", "7")])
+def test_launch_geometry_does_not_change_results(capi, oracle_mod, monkeypatch, knob, value):
+    """How the waypoints are dealt to the workgroups of the obstacle kernel (group size, consecutive or interleaved) and
+    how often the host looks at the progress word are scheduling decisions: every instance gets bit-for-bit the same
+    trajectory, cost and iteration count (a (waypoint, link) key is folded by one wave in chunk order, the keys of a
+    waypoint are added up in link order)."""
+    prob = Problem("panda", B=24, scene_seed=5, n_goals=2)
+    h, o = make_pair(capi, oracle_mod, prob, max_iter=15)
+    ref = h.solve_batch(*prob.solve_args())
+    monkeypatch.setenv(knob, value)
+    h2 = capi.SolverHandle(prob.desc, prob.cfg["link_ee"], prob.cfg["link_gripper"], oracle_mod.reference_opts(max_iter=15), device=0)
+    h2.set_scene(*prob.scene_args())
+    for _ in range(2):
+        got = h2.solve_batch(*prob.solve_args())
+        for a, b in zip(ref, got):
+            np.testing.assert_array_equal(a, b)
+    h2.close()
+    h.close()
+
+
 def test_full_size_properties(capi, oracle_mod):
     """BASELINE.json configs[1] sizes (Panda, ~5k surface points, 128^3 field, 64 goals, T=50):
     too slow for the scalar oracle end-to-end, so checked through size-independent properties."""
