@@ -2236,7 +2236,10 @@ __device__ __forceinline__ void base_screw(int a, const double* scr, double tx, 
   }
 }
 
-__global__ __launch_bounds__(256) void k_base_solve(const RobotDev* __restrict__ rb, const double* __restrict__ qc,
+#ifndef GTO_BASE_MIN_WAVES
+#define GTO_BASE_MIN_WAVES 2  // measured (tools/ab_base.sh, Fetch, 10 goals per set; 64 / 1024 sets per call, w = 0 | 0.01): 1 wave/SIMD (256 VGPRs + 36 AGPRs) 39 k / 364 k | 17.5 k / 79 k sets/s; 2 (256 VGPRs, 108 B scratch) 38 k / 411 k | 17.0 k / 126 k; 3 (168, 464 B) 31 k / 333 k | 14.8 k / 99 k
+#endif
+__global__ __launch_bounds__(256, GTO_BASE_MIN_WAVES) void k_base_solve(const RobotDev* __restrict__ rb, const double* __restrict__ qc,
                                                     const double* __restrict__ goals, const int32_t* __restrict__ n_goals,
                                                     SolveParams sp, double w_effort, int n_max, double* __restrict__ y_out,
                                                     double* __restrict__ q_out, double* __restrict__ cost_out,
