@@ -278,6 +278,55 @@ def test_launch_geometry_does_not_change_results(capi, oracle_mod, monkeypatch, 
     h.close()
 
 
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("robot", ["panda", "fetch"])
+def test_hip_lm_ends_where_lbfgsb_ends(capi, oracle_mod, robot, mode):
+    """The solver iteration against a third-party optimiser (tests/independent.py): on the smooth problem IPOPT sees
+    gradient-wise (GTO_GRAD_ZERO, empty field), every HIP solution is a KKT point, and where SciPy's L-BFGS-B ends in
+    the same basin it ends at the same trajectory and the same objective value."""
+    from independent import check_against_lbfgsb
+    T = 12
+    prob = Problem(robot, B=4, scene_seed=1, T=T)
+    opts = oracle_mod.reference_opts(T=T, standoff_offset=-3, grad_mode=1, max_iter=300, tol_rel_f=1e-14)
+    h = capi.SolverHandle(prob.desc, prob.cfg["link_ee"], prob.cfg["link_gripper"], opts, device=0)
+    h.set_mode(mode)
+    o = oracle_mod.Oracle(prob.desc, prob.cfg["link_ee"], prob.cfg["link_gripper"], opts)
+    prob.finish(h.eval_fk)
+    zero = np.zeros_like(prob.scene.c_all)
+    for x in (h, o):
+        x.set_scene(0, zero, zero, prob.scene.shape, prob.scene.origin, prob.scene.res)
+    Q, _, f, it, st = h.solve_batch(*prob.solve_args())
+    check_against_lbfgsb(o, prob, opts, Q, f, st, min_same_basin=2)
+    h.close()
+
+
+@pytest.mark.parametrize("robot", ["panda", "fetch"])
+def test_hip_ik_ends_where_lbfgsb_ends(capi, oracle_mod, robot):
+    """gto_solve_ik_batch (no collision term) against SciPy's L-BFGS-B on the objective value (tests/independent.py)."""
+    from independent import check_ik_against_lbfgsb
+    prob = Problem(robot, B=8, scene_seed=5)
+    h, o = make_pair(capi, oracle_mod, prob, tol_rel_f=1e-14)
+    rng = np.random.default_rng(1)
+    oi = prob.desc.opt_index
+    q0 = prob.qc.copy()
+    q0[4:, oi] = prob.qgoal[4:, 0][:, oi] + rng.uniform(-0.3, 0.3, size=(4, len(oi)))
+    q, f, it, st = h.solve_ik_batch(None, q0, prob.goals[:, 0], prob.base, max_iter=200)
+    check_ik_against_lbfgsb(o, prob, q0, q, f, min_agree=6)
+    h.close()
+
+
+def test_hip_base_placement_ends_where_lbfgsb_ends(capi, oracle_mod):
+    """gto_solve_base_batch with a firm effort weight against SciPy's L-BFGS-B on the objective value."""
+    from independent import check_base_against_lbfgsb
+    from grasptrajopt_amd import synthetic as syn
+    prob = Problem("fetch", B=4, scene_seed=2)
+    h, o = make_pair(capi, oracle_mod, prob, tol_rel_f=1e-14)
+    goals, _ = syn.make_base_goal_sets(prob.desc, h.eval_fk, prob.cfg["link_ee"], prob.qc[0], 4, 3, 0)
+    y, q, f, it, st = h.solve_base_batch(prob.qc, goals, None, 1.0, max_iter=300)
+    check_base_against_lbfgsb(o, prob.desc, prob.qc, np.asarray(goals).reshape(4, 3, 16), 1.0, y, q, f, min_agree=3)
+    h.close()
+
+
 def test_full_size_properties(capi, oracle_mod):
     """BASELINE.json configs[1] sizes (Panda, ~5k surface points, 128^3 field, 64 goals, T=50):
     too slow for the scalar oracle end-to-end, so checked through size-independent properties."""
