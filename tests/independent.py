@@ -165,3 +165,34 @@ def check_base_against_lbfgsb(oracle_obj, desc, qc, goals, w, y_sol, q_sol, cost
         r2 = lbfgsb_fd(fbatch, xs, lo_x, hi_x)
         assert r2.fun >= cost[b] * (1 - 1e-7) - 1e-12
     assert agree >= min_agree, f"only {agree} of {B} base placements agree with L-BFGS-B"
+
+
+def check_obstacle_blocks_against_fd(obj, desc, T, ts, Q, base, h=1e-6):
+    """The obstacle term's Gauss-Newton blocks assembled point by point in numpy — cost value and field-gradient model
+    per surface point from eval_points (pinned against gto/sdf_callback.py), point Jacobians dx/dq by central differences
+    of the world points — against eval_obstacle_normal_eq (wrench Grams folded per link and projected onto the joint
+    screws).  `obj` is the oracle or the HIP handle: same surface.  Returns the number of waypoints with a non-zero block."""
+    oi = desc.opt_index
+    n = len(oi)
+    JtJ, Jtr, ss = obj.eval_obstacle_normal_eq(0, base, Q[None])
+    nonzero = 0
+    for t in range(T):
+        q = Q[:, t]
+        use_obs = t >= ts  # gto/gto_planner.py:117-131: sdf_cost_all before the standoff waypoint, sdf_cost_obstacle from it on
+        _, _, val, grad = obj.eval_points(0, q[None], base, use_obs=use_obs)
+        np.testing.assert_allclose(ss[0, t], (val[0] ** 2).sum(), rtol=1e-12, atol=1e-14)
+        if t < 2:
+            continue  # pinned waypoints: no unknowns
+        qs = np.repeat(q[None], 2 * n, 0)
+        for j in range(n):
+            qs[2 * j, oi[j]] += h
+            qs[2 * j + 1, oi[j]] -= h
+        xp = obj.eval_points(0, qs, base, use_obs=use_obs)[0]
+        dx = (xp[0::2] - xp[1::2]) / (2.0 * h)              # [n, P, 3]
+        J = np.einsum("pk,jpk->pj", grad[0], dx)            # [P, n] rows of the obstacle Jacobian
+        A, b = J.T @ J, J.T @ val[0]
+        scale = max(np.abs(A).max(), 1e-12)
+        np.testing.assert_allclose(JtJ[0, t], A, rtol=0, atol=2e-6 * scale)
+        np.testing.assert_allclose(Jtr[0, t], b, rtol=0, atol=2e-6 * max(np.abs(b).max(), 1e-12))
+        nonzero += int(np.abs(A).max() > 0)
+    return nonzero

@@ -327,6 +327,23 @@ def test_hip_base_placement_ends_where_lbfgsb_ends(capi, oracle_mod):
     h.close()
 
 
+@pytest.mark.parametrize("robot", ["panda", "fetch", "panda_5k"])
+def test_hip_obstacle_blocks_against_finite_difference_jacobians(capi, oracle_mod, robot):
+    """k_obstacle_gram's blocks (wrench Grams per link on the matrix core, projected onto the joint screws) against a
+    point-by-point numpy assembly with FINITE-DIFFERENCE point Jacobians (tests/independent.py): no analytic Jacobian
+    of anybody's is trusted."""
+    from independent import check_obstacle_blocks_against_fd
+    T = 16
+    prob = Problem(robot, B=2, scene_seed=3, T=T)
+    opts = oracle_mod.reference_opts(T=T, standoff_offset=-4)
+    h = capi.SolverHandle(prob.desc, prob.cfg["link_ee"], prob.cfg["link_gripper"], opts, device=0)
+    prob.finish(h.eval_fk)
+    h.set_scene(*prob.scene_args())
+    nz = sum(check_obstacle_blocks_against_fd(h, prob.desc, T, T - 4, prob.Q0[b], prob.base[b]) for b in range(prob.B))
+    assert nz >= 4
+    h.close()
+
+
 def test_full_size_properties(capi, oracle_mod):
     """BASELINE.json configs[1] sizes (Panda, ~5k surface points, 128^3 field, 64 goals, T=50):
     too slow for the scalar oracle end-to-end, so checked through size-independent properties."""

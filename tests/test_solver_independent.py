@@ -68,3 +68,16 @@ def test_oracle_base_placement_ends_where_lbfgsb_ends(oracle_mod):
     goals, _ = syn.make_base_goal_sets(prob.desc, o.eval_fk, prob.cfg["link_ee"], prob.qc[0], 4, 3, 0)
     y, q, f, it, st = o.solve_base_batch(prob.qc, goals, None, 1.0, max_iter=300)
     check_base_against_lbfgsb(o, prob.desc, prob.qc, np.asarray(goals).reshape(4, 3, 16), 1.0, y, q, f, min_agree=3)
+
+
+@pytest.mark.parametrize("robot,grad_mode", [("panda", 0), ("fetch", 0)])
+def test_oracle_obstacle_blocks_against_finite_difference_jacobians(oracle_mod, robot, grad_mode):
+    from independent import check_obstacle_blocks_against_fd
+    T = 16
+    prob = Problem(robot, B=2, scene_seed=3, T=T)
+    opts = oracle_mod.reference_opts(T=T, standoff_offset=-4, grad_mode=grad_mode)
+    o = oracle_mod.Oracle(prob.desc, prob.cfg["link_ee"], prob.cfg["link_gripper"], opts)
+    prob.finish(o.eval_fk)
+    o.set_scene(*prob.scene_args())
+    nz = sum(check_obstacle_blocks_against_fd(o, prob.desc, T, T - 4, prob.Q0[b], prob.base[b]) for b in range(prob.B))
+    assert nz >= 4  # the trajectories do pass through the cost band
