@@ -415,9 +415,22 @@ def main():
         seedc[:, :, :2] = qc[:, :, None]
         sg_, so_, sv_, _ = h.eval_objective(0, RT.reshape(NB, 1, 16), 1, S[0].reshape(4, 4), [0.0, 0.0, 0.0], seedc)
         quality["objective_le_seed_frac"] = round(float((cost <= (sg_ + so_ + sv_) * (1 + 1e-12)).mean()), 4)
+        # what the shipped stopping tolerance (tol_rel_f) leaves on the table: the first batch again with a tolerance five
+        # orders tighter and three times the iteration cap, objective against objective
+        tol0, it0 = opts.tol_rel_f, opts.max_iter
+        h.set_opts(tol_rel_f=tol0 * 1e-5, max_iter=3 * it0)
+        _, _, f_tight, it_tight, _ = h.solve_batch(0, qc[:B], RT[:B].reshape(B, 1, 16), 1, S[:B], base[:B], Q0[:B])
+        h.set_opts(tol_rel_f=tol0, max_iter=it0)
+        gap = (cost[:B] - f_tight) / np.maximum(f_tight, 1e-300)
+        quality["stopping_tolerance_check"] = {"tol_rel_f": tol0, "tight_tol_rel_f": tol0 * 1e-5, "tight_max_iter": 3 * it0,
+                                               "f_excess_rel_max": float(gap.max()), "f_excess_rel_mean": float(gap.mean()),
+                                               "f_excess_rel_max_converged": float(gap[status[:B] == 0].max()) if (status[:B] == 0).any() else None,
+                                               "iters_mean": round(float(iters[:B].mean()), 2), "iters_mean_tight": round(float(it_tight.mean()), 2)}
         # gate: joint limits and the objective invariant always; compute_plan_cost against the seed's where the seed is a
         # collision-scored trajectory (interpolated seeds; the hold-and-jump seeds of shelf scenes cost nothing by construction)
         gate_ok = quality["max_joint_limit_violation"] <= 1e-8 and quality["objective_le_seed_frac"] == 1.0
+        # ... and the stopping tolerance may not cost a converged instance more than 1e-4 of its objective
+        gate_ok = gate_ok and (quality["stopping_tolerance_check"]["f_excess_rel_max_converged"] or 0.0) <= 1e-4
         if not args.shelf:
             gate_ok = gate_ok and quality["plan_cost_le_seed_frac"] >= 0.95
         quality["gate"] = "pass" if gate_ok else "FAIL"
