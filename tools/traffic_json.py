@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""profiles/traffic.json from the PMC passes of tools/pmc_pass.sh: HBM traffic (FETCH_SIZE x 2 + WRITE_SIZE, KB -> bytes; the
+factor 2 is MI355X_MICROARCH.md's gfx950 correction: FETCH_SIZE counts 128-B requests at 64 B) and issue-side figures of
+the dominant kernel per launch, one entry per call size.
+usage: tools/traffic_json.py <gpurun_out/pmc_320> <gpurun_out/pmc_2048> ...   (directory name ends in the call size)"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+entries = []
+for d in sys.argv[1:]:
+    size = int(os.path.basename(d.rstrip("/")).split("_")[-1])
+    js = json.load(open(os.path.join(d, "pmc_summary.json")))
+    k = next(v for n, v in js.items() if "k_obstacle_gram" in n)
+    us = k["mean_us"]
+    simd_cycles = 1024 * us * 1e-6 * 2.4e9  # 256 CUs x 4 SIMDs at 2.4 GHz
+    entries.append({
+        "robot": "panda_5k", "grid": 128, "mode": "rounds", "instances_per_call": size, "slots": 384,
+        "source": f"profiles/r02_pmc_{size}.txt (tools/pmc_pass.sh: rocprofv3 --kernel-trace --pmc, separate passes, bench.py --pipeline 1 "
+                  f"--merged-launches-only with calls of {size} instances)",
+        "kernel": "k_obstacle_gram", "launches": k["launches"], "mean_launch_us_profiled": round(us, 2),
+        "FETCH_SIZE_KB_mean_per_launch": round(k["FETCH_SIZE"], 1), "WRITE_SIZE_KB_mean_per_launch": round(k["WRITE_SIZE"], 1),
+        "correction": "FETCH_SIZE doubled (gfx950 counts 128-B requests at 64 B, MI355X_MICROARCH.md); WRITE_SIZE uncalibrated, taken as is",
+        "hbm_bytes_per_launch": int(round((2 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024)),
+        "issue": {
+            "fp64_valu_busy_frac": round(4 * k["SQ_ACTIVE_INST_VALU"] / simd_cycles, 3),
+            "scalar_busy_frac": round(4 * k["SQ_ACTIVE_INST_SCA"] / simd_cycles, 3),
+            "waves_waiting_frac": round(k["SQ_WAIT_ANY"] / k["SQ_WAVE_CYCLES"], 3),
+            "l2_hit_rate": round(k["TCC_HIT_sum"] / max(k["TCC_REQ_sum"], 1.0), 3),
+            "valu_insts_per_launch": int(k["SQ_INSTS_VALU"]), "salu_insts_per_launch": int(k["SQ_INSTS_SALU"]),
+            "lds_bank_conflict_cycles_per_lds_inst": round(k["SQ_LDS_BANK_CONFLICT"] / max(k["SQ_INSTS_LDS"], 1.0), 2),
+            "how": "SQ_ACTIVE_INST_* x 4 (quad-cycles) / (1024 SIMDs x launch duration x 2.4 GHz); the kernel is bound by instruction "
+                   "issue and latency, not by HBM"}})
+out = {"note": "HBM traffic and issue-side figures of the dominant kernel per launch, by call size; bench.py quotes an entry only for the "
+               "workload, solver mode and call size it was measured on", "entries": entries}
+json.dump(out, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
+print(json.dumps(out, indent=1))
