@@ -61,6 +61,7 @@ struct gto_handle {
   size_t dbg_extra_lds = 0;  // GTO_DEBUG_EXTRA_LDS: occupancy experiments  // GTO_DEBUG_CUT: timing experiments only, results are garbage
   int obs_tg_few = 2;  // ... when few instances are in flight (one small batch, the tail of a call): lower latency per round; results do not depend on the group size
   int few_instances = 64;
+  int step_nw_few = 8;  // GTO_STEP_NW_FEW: wavefronts per workgroup of the step kernel in launches with few instances in flight (4 or 8)
   int obs_tg = 3;  // waypoints per workgroup of the obstacle kernel: they share the table staging, the FK barriers and the launch overhead
   long long* dbg = nullptr;
   // staging for the host-pointer entry points
@@ -137,7 +138,7 @@ static int validate_opts(const gto_solver_opts* o, std::string& why) {
 
 static size_t lm_lds_bytes(int T) {
   size_t m = (size_t)T - 2;
-  size_t dbl = m * 64 + 4 * m * 8 + 8 * (size_t)T + 16 + 16;
+  size_t dbl = m * 64 + 4 * m * 8 + 8 * (size_t)T + 16 + 32;
   return dbl * sizeof(double) + m * 8 * sizeof(int) + 64;
 }
 
@@ -178,6 +179,7 @@ int gto_create(const gto_robot_desc* d, const gto_solver_opts* opts, int device,
   if (const char* e = getenv("GTO_OBS_TG")) h->obs_tg = h->obs_tg_few = std::max(1, std::min(GTO_MAX_TG, atoi(e)));
   if (const char* e = getenv("GTO_OBS_TG_FEW")) h->obs_tg_few = std::max(1, std::min(GTO_MAX_TG, atoi(e)));
   if (const char* e = getenv("GTO_FEW_INSTANCES")) h->few_instances = atoi(e);
+  if (const char* e = getenv("GTO_STEP_NW_FEW")) h->step_nw_few = atoi(e) == 8 ? 8 : 4;
   if (const char* e = getenv("GTO_TRAJ_NW")) { int v = atoi(e); if (v == 4 || v == 8 || v == 16) h->traj_nw = h->traj_nw_few = v; }
   if (const char* e = getenv("GTO_TRAJ_NW_FEW")) { int v = atoi(e); if (v == 4 || v == 8 || v == 16) h->traj_nw_few = v; }
   if (const char* e = getenv("GTO_TRAJ_FEW")) h->traj_few = atoi(e);
@@ -440,7 +442,8 @@ int gto_create(const gto_robot_desc* d, const gto_solver_opts* opts, int device,
     }
     if (h->lm_lds > step_attr[w]) {
       e2 = w ? hipFuncSetAttribute((const void*)k_lm_step_wide<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lm_lds)
-             : hipFuncSetAttribute((const void*)k_lm_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lm_lds);
+             : hipFuncSetAttribute((const void*)k_lm_step<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lm_lds);
+      if (!w && e2 == hipSuccess) e2 = hipFuncSetAttribute((const void*)k_lm_step<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lm_lds);
       step_attr[w] = h->lm_lds;
     }
     if (e1 != hipSuccess || e2 != hipSuccess) {
@@ -968,7 +971,10 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
     const int tg = few ? h->obs_tg_few : h->obs_tg;
     sp.interleave = h->obs_interleave == 1 || (h->obs_interleave == 2 && few);
     if ((rc = launch_obstacle(h, st, bp, sp, B, 2, T - 2, 0, h->profiling, true, W, tg))) return rc;
-    if (h->np == GTO_NB) hipLaunchKernelGGL(k_lm_step, dim3(W), dim3(256), h->lm_lds, st, h->d_rb, bp, sp, B);
+    if (h->np == GTO_NB) {
+      if (few && h->step_nw_few == 8) hipLaunchKernelGGL(k_lm_step<8>, dim3(W), dim3(512), h->lm_lds, st, h->d_rb, bp, sp, B);
+      else hipLaunchKernelGGL(k_lm_step<4>, dim3(W), dim3(256), h->lm_lds, st, h->d_rb, bp, sp, B);
+    }
     else hipLaunchKernelGGL(k_lm_step_wide<16>, dim3(W), dim3(256), h->lm_lds, st, h->d_rb, bp, sp, B, (double*)h->zws.p);
     // Early exit.  Every few rounds the finished-instance counter is copied back (4 bytes) and an event is
     // recorded, but the host only LOOKS at the copy of the previous check: by then the GPU has long passed that

@@ -1475,7 +1475,13 @@ __device__ __forceinline__ double matvec8(double Z, double zc) {
 // One workgroup of four wavefronts per instance.  Lane (r,c) = (lane>>3, lane&7) of a wave owns entry
 // (r,c) of the 8x8 blocks; the data-parallel phases (assembly, projected step, predicted decrease) are
 // spread over the four waves by waypoint, the serial block recursion runs on wave 0.
-__global__ __launch_bounds__(256) void k_lm_step(const RobotDev* __restrict__ rb, BatchPtrs bp, SolveParams sp, int B) {
+// NW wavefronts per workgroup: 4, or 8 for launches with few instances in flight (the assembly, the projected step and the
+// predicted decrease are spread over the waves; the twisted factorisation uses two of them either way).  The results do
+// not depend on NW: the only cross-wave sum, the predicted decrease, is formed per waypoint class (s mod 8) in ascending
+// order and the eight classes are added in a fixed order.
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void k_lm_step(const RobotDev* __restrict__ rb, BatchPtrs bp, SolveParams sp, int B) {
+  constexpr int NT = 64 * NW;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   if (blockIdx.x == 0 && threadIdx.x == 0 && bp.progress) {  // lagged by design: what had finished when this launch started
     const int nd = __hip_atomic_load(bp.n_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1497,8 +1503,8 @@ __global__ __launch_bounds__(256) void k_lm_step(const RobotDev* __restrict__ rb
   double* s_x = s_b + m * 8;
   double* s_Q = s_x + m * 8;
   double* s_gaff = s_Q + 8 * T;
-  double* s_red = s_gaff + 16;  // [16] cross-wave scratch
-  int* s_actm = (int*)(s_red + 16);                // [m] frozen-joint bit masks (room for [m][8])
+  double* s_red = s_gaff + 16;  // [32] cross-wave scratch: [0] failure flag, [1..8] step maxima, [8] first dense block (int, early), [16..23] predicted decrease by class
+  int* s_actm = (int*)(s_red + 32);                // [m] frozen-joint bit masks (room for [m][8])
   int* s_first_dense = (int*)(s_red + 8);  // first waypoint block with an off-diagonal entry
 
   const int r = lane >> 3, c = lane & 7;
@@ -1557,34 +1563,34 @@ __global__ __launch_bounds__(256) void k_lm_step(const RobotDev* __restrict__ rb
   }
   const int argmin_cur = accept ? argmin_try : argmin_cur0;
   // the iterate that is current from here on: loaded first (loads return in order), copied below
-  constexpr int NQ = (8 * GTO_MAX_T + 255) / 256;
+  constexpr int NQ = (8 * GTO_MAX_T + NT - 1) / NT;
   double qv[NQ];
   {
     const double* __restrict__ src = accept ? Qt : Qc;
 #pragma unroll
     for (int u = 0; u < NQ; ++u) {
-      const int idx = tid + 256 * u;
+      const int idx = tid + NT * u;
       qv[u] = (idx < n * T) ? src[idx] : 0.0;
     }
   }
   // global loads of P2 (normal equations at the iterate that is current from here on), issued now so that
-  // their latency overlaps the trajectory copy below; wave w assembles waypoints s = w, w+4, ...
+  // their latency overlaps the trajectory copy below; wave w assembles waypoints s = w, w+NW, ...
   const double* __restrict__ oblk = bp.blocks + ((size_t)slot * B + b) * T * BLK_STRIDE;
   const double* __restrict__ gblk = bp.goalblk + ((size_t)slot * B + b) * 2 * BLK_STRIDE;
   const double alpha = sp.alpha;
   const bool inb = (r < n) && (c < n);
-  constexpr int KMAX = (GTO_MAX_T - 2 + 3) / 4;
-  constexpr int NU = (8 * GTO_MAX_T + 255) / 256;  // (waypoint, joint) items per thread
+  constexpr int KMAX = (GTO_MAX_T - 2 + NW - 1) / NW;
+  constexpr int NU = (8 * GTO_MAX_T + NT - 1) / NT;  // (waypoint, joint) items per thread
   double av[KMAX];  // undamped obstacle J^T J entry (r,c) of this wave's waypoints
 #pragma unroll
   for (int kk = 0; kk < KMAX; ++kk) {
-    const int s = wave + 4 * kk;
+    const int s = wave + NW * kk;
     av[kk] = (inb && s < m) ? oblk[(size_t)(s + 2) * BLK_STRIDE + BLK_JTJ + lane] : 0.0;
   }
   double jv[NU];  // obstacle J^T r of this thread's (waypoint, joint) items
 #pragma unroll
   for (int u = 0; u < NU; ++u) {
-    const int idx = tid + 256 * u, i = idx & 7;
+    const int idx = tid + NT * u, i = idx & 7;
     jv[u] = (idx < m * 8 && i < n) ? oblk[(size_t)((idx >> 3) + 2) * BLK_STRIDE + BLK_JTR + i] : 0.0;
   }
   const double gA0 = inb ? gblk[BLK_JTJ + lane] : 0.0;
@@ -1597,7 +1603,7 @@ __global__ __launch_bounds__(256) void k_lm_step(const RobotDev* __restrict__ rb
   // current iterate into LDS (rows >= n are padding); on accept it is the trial
 #pragma unroll
   for (int u = 0; u < NQ; ++u) {
-    const int idx = tid + 256 * u;
+    const int idx = tid + NT * u;
     if (idx < 8 * T) s_Q[idx] = qv[u];
     if (accept && idx < n * T) Qc[idx] = qv[u];
   }
@@ -1628,7 +1634,7 @@ __global__ __launch_bounds__(256) void k_lm_step(const RobotDev* __restrict__ rb
       __syncthreads();                            \
       const int nid = s_nid;                      \
       if (nid >= 0)                               \
-        for (int i_ = tid; i_ < sp.T * rb->n_frames; i_ += 256)     \
+        for (int i_ = tid; i_ < sp.T * rb->n_frames; i_ += NT)      \
           bp.qfs[(size_t)slot_id * sp.T * rb->n_frames + i_] = bp.qf[(size_t)nid * sp.T * rb->n_frames + i_]; \
     }                                             \
     return;                                       \
@@ -1648,7 +1654,7 @@ __global__ __launch_bounds__(256) void k_lm_step(const RobotDev* __restrict__ rb
   for (int u = 0; u < NU; ++u) actv[u] = 1;
 #pragma unroll
   for (int u = 0; u < NU; ++u) {
-    const int idx = tid + 256 * u;
+    const int idx = tid + NT * u;
     if (idx < m * 8) {
       const int sI = idx >> 3, i = idx & 7, t = sI + 2;
       double bv = 0.0;
@@ -1670,7 +1676,7 @@ __global__ __launch_bounds__(256) void k_lm_step(const RobotDev* __restrict__ rb
   // frozen variables of a waypoint as a bit mask (bit i = joint i): eight lanes of a ballot per waypoint
 #pragma unroll
   for (int u = 0; u < NU; ++u) {
-    const int idx = tid + 256 * u;
+    const int idx = tid + NT * u;
     const unsigned long long bal = __ballot(idx < m * 8 && actv[u] != 0);
     if (idx < m * 8 && (idx & 7) == 0) s_actm[idx >> 3] = (int)((bal >> (lane & 56)) & 0xffull);
   }
@@ -1689,7 +1695,7 @@ __global__ __launch_bounds__(256) void k_lm_step(const RobotDev* __restrict__ rb
     const int s_goal = T - 3, s_stand = sp.use_standoff ? sp.ts - 2 : -1;
 #pragma unroll
     for (int kk = 0; kk < KMAX; ++kk) {
-      const int s = wave + 4 * kk;
+      const int s = wave + NW * kk;
       if (s < m) {  // wave-uniform
         double a = fma(sp.w_obstacle, av[kk], dadd);
         if (s == s_goal) {  // goal waypoint T-1: goal block; its velocity term is alpha, not 2 alpha
@@ -1707,7 +1713,7 @@ __global__ __launch_bounds__(256) void k_lm_step(const RobotDev* __restrict__ rb
     if (lane == 0 && first < m) atomicMin(s_first_dense, first);
   }
   if (bp.dbg && b == 0 && tid == 0) bp.dbg[30] = clock64();
-  for (int idx = tid; idx < m * 8; idx += 256) {
+  for (int idx = tid; idx < m * 8; idx += NT) {
     const int sI = idx >> 3, i = idx & 7;
     const int a0 = (s_actm[sI] >> i) & 1;
     const int a1 = (sI < m - 1) ? (s_actm[sI + 1] >> i) & 1 : 1;
@@ -1851,7 +1857,7 @@ __global__ __launch_bounds__(256) void k_lm_step(const RobotDev* __restrict__ rb
   if (bp.dbg && b == 0 && tid == 0) bp.dbg[5] = clock64();
   // ---- P4: projected trial point; the LDS copy of Q becomes the trial, s_x the projected step
   double maxstep = 0.0;
-  for (int idx = tid; idx < m * 8; idx += 256) {
+  for (int idx = tid; idx < m * 8; idx += NT) {
     const int sI = idx >> 3, i = idx & 7, t = sI + 2;
     double sv = 0.0;
     if (i < n) {
@@ -1870,7 +1876,9 @@ __global__ __launch_bounds__(256) void k_lm_step(const RobotDev* __restrict__ rb
   maxstep = wave_max(maxstep);
   if (lane == 0) s_red[1 + wave] = maxstep;
   __syncthreads();
-  maxstep = fmax(fmax(s_red[1], s_red[2]), fmax(s_red[3], s_red[4]));
+  maxstep = s_red[1];
+#pragma unroll
+  for (int w = 1; w < NW; ++w) maxstep = fmax(maxstep, s_red[1 + w]);
   if (maxstep < sp.tol_step) GTO_FINISH(GTO_STATUS_CONVERGED);
 
   if (bp.dbg && b == 0 && tid == 0) bp.dbg[6] = clock64();
@@ -1878,23 +1886,29 @@ __global__ __launch_bounds__(256) void k_lm_step(const RobotDev* __restrict__ rb
   // Lane (r,c) adds A[r][c] s_r s_c; the lanes of column 0 also add the terms that are linear in s_r
   // (2 b_r s_r and the coupling -2 alpha s_r s'_r with the next waypoint), folded in as a lane constant.
   {
+    static_assert(NW == 4 || NW == 8, "the waypoint classes of the predicted decrease are laid out for 4 or 8 waves");
     const double c0 = (c == 0) ? 2.0 : 0.0;
-    double part = 0.0;
+    double part0 = 0.0, part1 = 0.0;  // class wave (and, with four waves, class wave + 4: the odd kk)
 #pragma unroll
     for (int kk = 0; kk < KMAX; ++kk) {
-      const int s = wave + 4 * kk;
+      const int s = wave + NW * kk;
       if (s < m) {  // wave-uniform
         const double sr = s_x[s * 8 + r], scv = s_x[s * 8 + c];
         const double xn = (s < m - 1) ? s_x[(s + 1) * 8 + r] : 0.0;
         const double lin = c0 * fma(-alpha, xn, s_b[s * 8 + r]);
-        part = fma(sr, fma(av[kk], scv, lin), part);
+        if (NW == 8 || (kk & 1) == 0) part0 = fma(sr, fma(av[kk], scv, lin), part0);
+        else part1 = fma(sr, fma(av[kk], scv, lin), part1);
       }
     }
-    part = wave_sum(part);
-    if (lane == 0) s_red[8 + wave] = part;
+    part0 = wave_sum(part0);
+    if (lane == 0) s_red[16 + wave] = part0;
+    if (NW == 4) {
+      part1 = wave_sum(part1);
+      if (lane == 0) s_red[16 + wave + 4] = part1;
+    }
   }
   __syncthreads();
-  const double acc = (s_red[8] + s_red[9]) + (s_red[10] + s_red[11]);
+  const double acc = ((s_red[16] + s_red[17]) + (s_red[18] + s_red[19])) + ((s_red[20] + s_red[21]) + (s_red[22] + s_red[23]));
   if (tid == 0) {
     st->f = f;
     st->lambda = lambda;
