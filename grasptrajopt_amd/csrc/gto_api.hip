@@ -9,7 +9,9 @@
 #include <cstring>
 #include <string>
 #include <chrono>
+#include <mutex>
 #include <thread>
+#include <utility>
 #include <vector>
 
 #include "gto_kernels.h"
@@ -74,9 +76,7 @@ struct gto_handle {
   size_t lm_lds = 0;
   int np = GTO_NB;     // block width of the normal equations: 8 (up to eight optimised joints) or 16
   DevBuf zws;          // k_lm_step_wide: block inverses [slots][T-2][np*np]
-  int base_lds_set = 0;
   int slots = 384;  // instances in flight inside one solve call (GTO_SLOTS); a finished instance hands its slot to the next one
-  bool ik_attr_set = false;
 };
 
 #define HIPCHK(h, call)                                                                              \
@@ -134,6 +134,24 @@ static int validate_opts(const gto_solver_opts* o, std::string& why) {
   if (o->grad_mode != GTO_GRAD_CENTRAL_DIFF && o->grad_mode != GTO_GRAD_ZERO) { why = "unknown grad_mode"; return 0; }
   if (!(o->lambda0 > 0)) { why = "lambda0 must be positive"; return 0; }
   return 1;
+}
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is process-wide per kernel: a handle for a smaller robot or goal set must
+// never lower what an earlier handle launches with.  One high-water mark per kernel, only ever raised.
+static hipError_t raise_dynamic_lds(const void* kernel, size_t bytes) {
+  static std::mutex mu;
+  static std::vector<std::pair<const void*, size_t>> marks;
+  std::lock_guard<std::mutex> lock(mu);
+  for (auto& m : marks)
+    if (m.first == kernel) {
+      if (bytes <= m.second) return hipSuccess;
+      const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+      if (e == hipSuccess) m.second = bytes;
+      return e;
+    }
+  const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e == hipSuccess) marks.emplace_back(kernel, bytes);
+  return e;
 }
 
 static size_t lm_lds_bytes(int T) {
@@ -428,24 +446,13 @@ int gto_create(const gto_robot_desc* d, const gto_solver_opts* opts, int device,
   if (const char* e = getenv("GTO_DEBUG_STEP_EXTRA_LDS")) h->lm_lds += (size_t)atoi(e);  // occupancy experiments
   if (h->lm_lds > 160 * 1024) { gto_destroy(h); return fail(nullptr, GTO_ERR_UNSUPPORTED, "T too large for the step kernel's LDS"); }
   {
-    // hipFuncSetAttribute is process-wide per kernel: track the largest request and only ever raise it
-    static size_t obs_attr[2] = {0, 0}, step_attr[2] = {0, 0};
     const int w = h->np == GTO_NB ? 0 : 1;
     const ObsLds lay(w ? 2 : GTO_MAX_TG, rb.n_frames, rb.n_links, (w ? 2 : GTO_MAX_TG) * rb.n_chunks, h->np);
     const size_t lds = std::min<size_t>((size_t)lay.total_doubles * sizeof(double) + h->dbg_extra_lds, 160 * 1024);
     if ((size_t)lay.total_doubles * sizeof(double) > 150 * 1024) { gto_destroy(h); return fail(nullptr, GTO_ERR_UNSUPPORTED, "robot too large for the obstacle kernel's LDS"); }
-    hipError_t e1 = hipSuccess, e2 = hipSuccess;
-    if (lds > obs_attr[w]) {
-      e1 = w ? hipFuncSetAttribute((const void*)k_obstacle_gram<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
-             : hipFuncSetAttribute((const void*)k_obstacle_gram<GTO_NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      obs_attr[w] = lds;
-    }
-    if (h->lm_lds > step_attr[w]) {
-      e2 = w ? hipFuncSetAttribute((const void*)k_lm_step_wide<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lm_lds)
-             : hipFuncSetAttribute((const void*)k_lm_step<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lm_lds);
-      if (!w && e2 == hipSuccess) e2 = hipFuncSetAttribute((const void*)k_lm_step<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lm_lds);
-      step_attr[w] = h->lm_lds;
-    }
+    hipError_t e1 = raise_dynamic_lds(w ? (const void*)k_obstacle_gram<16> : (const void*)k_obstacle_gram<GTO_NB>, lds);
+    hipError_t e2 = w ? raise_dynamic_lds((const void*)k_lm_step_wide<16>, h->lm_lds) : raise_dynamic_lds((const void*)k_lm_step<4>, h->lm_lds);
+    if (!w && e2 == hipSuccess) e2 = raise_dynamic_lds((const void*)k_lm_step<8>, h->lm_lds);
     if (e1 != hipSuccess || e2 != hipSuccess) {
       gto_destroy(h);
       return fail(nullptr, GTO_ERR_HIP, "hipFuncSetAttribute failed");
@@ -1087,10 +1094,7 @@ int gto_solve_ik_batch(gto_handle* h, int32_t B, const int32_t* scene_id, const 
   sp.max_iter = max_iter;
   const size_t lds = (size_t)ik_lds_doubles(h->rb.n_frames, h->rb.n_links, h->rb.n_opt) * sizeof(double);
   if (lds > 150 * 1024) return fail(h, GTO_ERR_UNSUPPORTED, "robot too large for the IK kernel's LDS");
-  if (!h->ik_attr_set) {
-    HIPCHK(h, hipFuncSetAttribute((const void*)k_ik_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    h->ik_attr_set = true;
-  }
+  HIPCHK(h, raise_dynamic_lds((const void*)k_ik_solve, lds));
   hipLaunchKernelGGL(k_ik_solve, dim3(B), dim3(256), lds, h->stream, h->d_rb, h->d_px, h->d_py, h->d_pz, h->d_chunks,
                      h->d_scenes, (const int32_t*)d_sid, (const double*)d_q0, (const double*)d_goals, (const double*)d_base, sp,
                      B, (double*)d_q, (double*)d_cost, (int32_t*)d_it, (int32_t*)d_stat);
@@ -1131,10 +1135,7 @@ int gto_solve_base_batch(gto_handle* h, int32_t B, int32_t n_max, const int32_t*
   sp.max_iter = max_iter;
   const size_t lds = (size_t)base_lds_doubles(n_max) * sizeof(double);
   if (lds > 160 * 1024) return fail(h, GTO_ERR_UNSUPPORTED, "goal set too large for the base kernel's LDS");
-  if ((int)lds > h->base_lds_set) {
-    HIPCHK(h, hipFuncSetAttribute((const void*)k_base_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    h->base_lds_set = (int)lds;
-  }
+  HIPCHK(h, raise_dynamic_lds((const void*)k_base_solve, lds));
   hipLaunchKernelGGL(k_base_solve, dim3(B), dim3(256), lds, h->stream, h->d_rb, (const double*)d_qc, (const double*)d_goals,
                      (const int32_t*)d_ng, sp, effort_weight, n_max, (double*)d_y, (double*)d_q, (double*)d_cost,
                      (int32_t*)d_it, (int32_t*)d_stat, (const double*)nullptr, (const double*)nullptr);
@@ -1179,10 +1180,7 @@ int gto_eval_base_objective(gto_handle* h, int32_t B, int32_t n_max, const int32
   sp.max_iter = 0;
   const size_t lds = (size_t)base_lds_doubles(n_max) * sizeof(double);
   if (lds > 160 * 1024) return fail(h, GTO_ERR_UNSUPPORTED, "goal set too large for the base kernel's LDS");
-  if ((int)lds > h->base_lds_set) {
-    HIPCHK(h, hipFuncSetAttribute((const void*)k_base_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    h->base_lds_set = (int)lds;
-  }
+  HIPCHK(h, raise_dynamic_lds((const void*)k_base_solve, lds));
   hipLaunchKernelGGL(k_base_solve, dim3(B), dim3(256), lds, h->stream, h->d_rb, (const double*)d_qc, (const double*)d_goals,
                      (const int32_t*)d_ng, sp, effort_weight, n_max, (double*)d_y, (double*)d_q, (double*)d_cost,
                      (int32_t*)nullptr, (int32_t*)nullptr, (const double*)d_y0, (const double*)d_q0);
@@ -1407,13 +1405,7 @@ int gto_plan_cost(gto_handle* h, int32_t scene_id, int32_t n, const double* plan
   if ((rc = stage_out(h, 0, part.data(), part.size() * sizeof(double), &dpart))) return rc;
   const size_t pc_lds = sizeof(double) * plan_cost_lds_doubles(h->rb.n_frames, h->rb.n_links, h->rb.n_opt);
   if (pc_lds > 150 * 1024) return fail(h, GTO_ERR_UNSUPPORTED, "robot too large for the plan-cost kernel's LDS");
-  {
-    static size_t pc_attr = 48 * 1024;  // process-wide per kernel: only ever raised
-    if (pc_lds > pc_attr) {
-      HIPCHK(h, hipFuncSetAttribute((const void*)k_plan_cost, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pc_lds));
-      pc_attr = pc_lds;
-    }
-  }
+  HIPCHK(h, raise_dynamic_lds((const void*)k_plan_cost, pc_lds));
   hipLaunchKernelGGL(k_plan_cost, dim3((unsigned)((T + GTO_PLAN_TG - 1) / GTO_PLAN_TG), n), dim3(256), pc_lds, h->stream, h->d_rb, h->d_px, h->d_py, h->d_pz, h->d_plink,
                      h->d_scenes + scene_id, (int)T, (const double*)dplans, (const double*)dbase, (double*)dpart);
   if ((rc = fetch_out(h, 0, part.data(), part.size() * sizeof(double)))) return rc;
