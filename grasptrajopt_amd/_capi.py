@@ -147,6 +147,7 @@ def load_library(path: Optional[str] = None):
     lib.gto_last_error.restype = C.c_char_p
     lib.gto_set_opts.argtypes = [H, C.POINTER(CSolverOpts)]
     lib.gto_set_scene.argtypes = [H, C.c_int32, _pf, _pf, _pi, _pd, C.c_double]
+    lib.gto_set_scene_values.argtypes = [H, C.c_int32, _pf, _pf, _pi, _pd, C.c_double]
     lib.gto_drop_scene.argtypes = [H, C.c_int32]
     solve_args = [H, C.c_int32, C.c_int32] + [C.c_void_p] * 12
     lib.gto_solve_batch.argtypes = solve_args
@@ -168,7 +169,7 @@ def load_library(path: Optional[str] = None):
     _pu8 = C.POINTER(C.c_uint8)
     lib.gto_depth_sdf_cost.argtypes = [C.c_int, _pf, C.c_int32, C.c_int32, _pd, _pd, _pd, _pd, _pu8, C.c_double, _pd, C.c_int64,
                                        C.c_float, C.c_float, _pf, _pu8, _pf, _pd, _pu8]
-    for fn in ("gto_create", "gto_set_opts", "gto_set_scene", "gto_drop_scene", "gto_solve_batch",
+    for fn in ("gto_create", "gto_set_opts", "gto_set_scene", "gto_set_scene_values", "gto_drop_scene", "gto_solve_batch",
                "gto_solve_batch_device", "gto_last_kernel_time", "gto_last_kernel_work", "gto_set_profiling", "gto_set_stream", "gto_set_mode", "gto_share_scene",
                "gto_eval_fk", "gto_eval_points", "gto_eval_objective", "gto_eval_obstacle_normal_eq", "gto_plan_cost", "gto_solve_ik_batch",
                "gto_solve_base_batch", "gto_eval_base_objective", "gto_depth_sdf_cost"):
@@ -180,7 +181,7 @@ def load_library(path: Optional[str] = None):
 
 EXPORTED_SYMBOLS = (
     "gto_default_opts", "gto_version", "gto_create", "gto_destroy", "gto_last_error", "gto_set_opts",
-    "gto_set_scene", "gto_drop_scene", "gto_solve_batch", "gto_solve_batch_device",
+    "gto_set_scene", "gto_set_scene_values", "gto_drop_scene", "gto_solve_batch", "gto_solve_batch_device",
     "gto_last_kernel_time", "gto_last_kernel_work", "gto_set_profiling", "gto_set_stream", "gto_set_mode", "gto_share_scene", "gto_eval_fk",
     "gto_eval_points",
     "gto_eval_objective", "gto_eval_obstacle_normal_eq", "gto_plan_cost", "gto_solve_ik_batch", "gto_solve_base_batch",
@@ -244,7 +245,9 @@ class SolverHandle:
             setattr(self.opts, k, v)
         self._check(self.lib.gto_set_opts(self._h, C.byref(self.opts)), "gto_set_opts")
 
-    def set_scene(self, scene_id: int, c_all, c_obs, shape: Sequence[int], origin, res: float):
+    def set_scene(self, scene_id: int, c_all, c_obs, shape: Sequence[int], origin, res: float, values_only: bool = False):
+        """values_only: gto_set_scene_values, the fields without the solver's records and distance fields (such a scene
+        serves plan_cost and eval_points only)."""
         ca = np.ascontiguousarray(c_all, dtype=np.float32).reshape(-1)
         co = None if c_obs is None else np.ascontiguousarray(c_obs, dtype=np.float32).reshape(-1)
         shp = _i32(list(shape))
@@ -252,8 +255,9 @@ class SolverHandle:
         if ca.size != n or (co is not None and co.size != n):
             raise ValueError(f"field size {ca.size} does not match shape {tuple(shp)}")
         org = _f64(np.asarray(origin).reshape(3))
-        self._check(self.lib.gto_set_scene(self._h, scene_id, _p(ca, _pf), _p(co, _pf), _p(shp, _pi),
-                                           _p(org, _pd), float(res)), "gto_set_scene")
+        fn = self.lib.gto_set_scene_values if values_only else self.lib.gto_set_scene
+        self._check(fn(self._h, scene_id, _p(ca, _pf), _p(co, _pf), _p(shp, _pi), _p(org, _pd), float(res)),
+                    "gto_set_scene_values" if values_only else "gto_set_scene")
         self.scenes[scene_id] = (tuple(int(s) for s in shp), org.copy(), float(res))
 
     def drop_scene(self, scene_id: int):

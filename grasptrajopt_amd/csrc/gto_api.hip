@@ -554,8 +554,8 @@ int gto_share_scene(gto_handle* dst, int32_t dst_id, gto_handle* src, int32_t sr
   return sync_scene_table(dst);
 }
 
-int gto_set_scene(gto_handle* h, int32_t id, const float* c_all, const float* c_obs, const int32_t shape[3],
-                  const double origin[3], double res) {
+static int set_scene_impl(gto_handle* h, int32_t id, const float* c_all, const float* c_obs, const int32_t shape[3],
+                          const double origin[3], double res, bool values_only) {
   if (!h) return GTO_ERR_INVALID_ARG;
   if (!c_all || !shape || !origin) return fail(h, GTO_ERR_INVALID_ARG, "null argument");
   if (id < 0 || id >= 65536) return fail(h, GTO_ERR_INVALID_ARG, "scene_id out of range [0,65536)");
@@ -591,8 +591,11 @@ int gto_set_scene(gto_handle* h, int32_t id, const float* c_all, const float* c_
   } else {
     dob = da;
   }
-  // gather-friendly voxel records (one-time, outside the timed solve)
+  // gather-friendly voxel records (one-time, outside the timed solve); a values-only scene (gto_set_scene_values: seed
+  // scoring and point look-ups) stops at the two float fields
   VoxelRec *ra = nullptr, *rob = nullptr;
+  uint8_t *dista = nullptr, *distb = nullptr, *scratch = nullptr;
+  if (!values_only) {
   SCN(dalloc((void**)&ra, nvox * sizeof(VoxelRec)));
   const unsigned nblk = (unsigned)((nvox + 255) / 256);
   hipLaunchKernelGGL(k_build_records, dim3(nblk), dim3(256), 0, h->stream, da, ra, shape[0], shape[1], shape[2]);
@@ -603,7 +606,6 @@ int gto_set_scene(gto_handle* h, int32_t id, const float* c_all, const float* c_
     rob = ra;
   }
   // broad-phase distance fields: ping-pong relaxation, the scratch half is freed again
-  uint8_t *dista = nullptr, *distb = nullptr, *scratch = nullptr;
   SCN(dalloc((void**)&scratch, nvox));
   for (int which = 0; which < (rob != ra ? 2 : 1); ++which) {
     uint8_t* d0 = nullptr;
@@ -619,9 +621,10 @@ int gto_set_scene(gto_handle* h, int32_t id, const float* c_all, const float* c_
     (which ? distb : dista) = d0;
   }
   if (rob == ra) distb = dista;
+  }
   SCN(hipStreamSynchronize(h->stream));
   SCN(hipGetLastError());
-  (void)hipFree(scratch);
+  if (scratch) (void)hipFree(scratch);
 #undef SCN
   if ((size_t)id >= h->scenes.size()) {
     SceneDev z;
@@ -648,6 +651,16 @@ int gto_set_scene(gto_handle* h, int32_t id, const float* c_all, const float* c_
   s.inv2r = 1.0 / (2.0 * res);
   s.valid = 1;
   return sync_scene_table(h);
+}
+
+int gto_set_scene(gto_handle* h, int32_t id, const float* c_all, const float* c_obs, const int32_t shape[3],
+                  const double origin[3], double res) {
+  return set_scene_impl(h, id, c_all, c_obs, shape, origin, res, false);
+}
+
+int gto_set_scene_values(gto_handle* h, int32_t id, const float* c_all, const float* c_obs, const int32_t shape[3],
+                         const double origin[3], double res) {
+  return set_scene_impl(h, id, c_all, c_obs, shape, origin, res, true);
 }
 
 int gto_drop_scene(gto_handle* h, int32_t id) {
@@ -824,6 +837,9 @@ static int check_scene_ids_host(gto_handle* h, const int32_t* ids, int B) {
   for (int b = 0; b < B; ++b)
     if (ids[b] < 0 || (size_t)ids[b] >= h->scenes.size() || !h->scenes[ids[b]].valid)
       return fail(h, GTO_ERR_NO_SCENE, "scene_id refers to a scene that was never set");
+  for (int b = 0; b < B; ++b)
+    if (!h->scenes[ids[b]].r_all)
+      return fail(h, GTO_ERR_NO_SCENE, "scene_id refers to a values-only scene (gto_set_scene_values): it serves gto_plan_cost and gto_eval_points only");
   return GTO_OK;
 }
 

@@ -234,7 +234,7 @@ class GTORobotModel:
         if plan.shape[1] != h.T:
             raise NotImplementedError(f"plans must have T={h.T} waypoints on this handle")
         shape, origin, res = self.field_geometry()
-        h.set_scene(self.SCRATCH_SCENE, sdf_cost_obstacle, None, shape, origin, res)
+        h.set_scene(self.SCRATCH_SCENE, sdf_cost_obstacle, None, shape, origin, res, values_only=True)  # scored, never solved on
         cost, dist = h.plan_cost(self.SCRATCH_SCENE, plan[None], base_position)
         return float(cost[0]), float(dist[0])
 

@@ -140,6 +140,12 @@ int gto_set_opts(gto_handle* h, const gto_solver_opts* opts);
  */
 int gto_set_scene(gto_handle* h, int32_t scene_id, const float* c_all, const float* c_obs,
                   const int32_t shape[3], const double origin[3], double res);
+/* The same upload without the solver's acceleration structures (voxel records, distance fields: 3.6x the bytes of the
+ * two fields and 48 relaxation sweeps): such a scene serves gto_plan_cost and gto_eval_points only (seed scoring of a
+ * field that is never solved on: GTORobotModel.compute_plan_cost, gto/gto_models.py:204-215); every solve or
+ * objective entry point rejects it with GTO_ERR_NO_SCENE. */
+int gto_set_scene_values(gto_handle* h, int32_t scene_id, const float* c_all, const float* c_obs,
+                         const int32_t shape[3], const double origin[3], double res);
 int gto_drop_scene(gto_handle* h, int32_t scene_id);
 
 /*

@@ -157,6 +157,17 @@ def test_plan_cost_vs_oracle(capi, oracle_mod):
     assert co.max() > 0
     np.testing.assert_allclose(cg, co, rtol=1e-12)
     np.testing.assert_allclose(dg, do, rtol=1e-14)
+    # a values-only scene (gto_set_scene_values: no records, no distance fields) scores and looks up the same ...
+    h.set_scene(3, prob.scene.c_all, prob.scene.c_obs, prob.scene.shape, prob.scene.origin, prob.scene.res, values_only=True)
+    c3, d3 = h.plan_cost(3, Q, prob.base[0])
+    np.testing.assert_array_equal(c3, cg)
+    for a, b in zip(h.eval_points(3, prob.qc[:2], prob.base[:2]), h.eval_points(0, prob.qc[:2], prob.base[:2])):
+        np.testing.assert_array_equal(a, b)
+    # ... and every solve or objective entry point refuses it
+    with pytest.raises(capi.GTOError, match="values-only"):
+        h.solve_batch(3, prob.qc, prob.goals, prob.n_goals, prob.S, prob.base, prob.Q0)
+    with pytest.raises(capi.GTOError, match="values-only"):
+        h.eval_obstacle_normal_eq(3, prob.base, prob.Q0)
     h.close()
 
 
