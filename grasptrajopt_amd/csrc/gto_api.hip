@@ -56,6 +56,7 @@ struct gto_handle {
   int check_every = 4;
   hipEvent_t ev_chk[2] = {nullptr, nullptr};
   int dbg_cut = 0;
+  int dist_relax = 0;  // GTO_DIST_RELAX: build the distance fields by relaxation sweeps instead of the separable passes
   // GTO_OBS_INTERLEAVE: waypoints of an obstacle workgroup nG apart instead of consecutive, so that the waypoints next to
   // the obstacles (neighbours in time) land in different workgroups: 0 never, 1 always, 2 (default) in launches with few
   // instances in flight, where the longest workgroup decides the round (+5 % for one batch at a time, -2 % at saturation)
@@ -189,6 +190,7 @@ int gto_create(const gto_robot_desc* d, const gto_solver_opts* opts, int device,
   h->opts = *opts;
   if (const char* e = getenv("GTO_CHECK_EVERY")) h->check_every = atoi(e);
   if (const char* e = getenv("GTO_OBS_INTERLEAVE")) h->obs_interleave = std::max(0, std::min(2, atoi(e)));
+  if (const char* e = getenv("GTO_DIST_RELAX")) h->dist_relax = atoi(e) ? 1 : 0;
   if (const char* e = getenv("GTO_DEBUG_CUT")) h->dbg_cut = atoi(e);
   if (const char* e = getenv("GTO_DEBUG_EXTRA_LDS")) h->dbg_extra_lds = (size_t)atoi(e);
   if (h->dbg_cut) fprintf(stderr, "[gto] WARNING: GTO_DEBUG_CUT=%d cuts the obstacle kernel short: timing experiments only, RESULTS ARE GARBAGE\n", h->dbg_cut);
@@ -610,14 +612,20 @@ static int set_scene_impl(gto_handle* h, int32_t id, const float* c_all, const f
   for (int which = 0; which < (rob != ra ? 2 : 1); ++which) {
     uint8_t* d0 = nullptr;
     SCN(dalloc((void**)&d0, nvox));
-    uint8_t* d1 = scratch;
-    hipLaunchKernelGGL(k_dist_init, dim3(nblk), dim3(256), 0, h->stream, which ? rob : ra, d0, (long)nvox);
-    for (int it = 0; it < GTO_DIST_CAP; ++it) {
-      hipLaunchKernelGGL(k_dist_relax, dim3(nblk), dim3(256), 0, h->stream, d0, d1, shape[0], shape[1], shape[2]);
-      std::swap(d0, d1);
+    if (h->dist_relax) {  // GTO_DIST_RELAX=1: the reference construction, GTO_DIST_CAP sweeps of 3x3x3 min-plus-one (A/B and tests)
+      uint8_t* d1 = scratch;
+      hipLaunchKernelGGL(k_dist_init, dim3(nblk), dim3(256), 0, h->stream, which ? rob : ra, d0, (long)nvox);
+      for (int it = 0; it < GTO_DIST_CAP; ++it) {
+        hipLaunchKernelGGL(k_dist_relax, dim3(nblk), dim3(256), 0, h->stream, d0, d1, shape[0], shape[1], shape[2]);
+        std::swap(d0, d1);
+      }
+      static_assert(GTO_DIST_CAP % 2 == 0, "ping-pong parity: the result is back in the buffer allocated for it");
+    } else {  // separable: one exact pass per axis, scratch -> d0 -> scratch -> d0
+      hipLaunchKernelGGL(k_dist_init, dim3(nblk), dim3(256), 0, h->stream, which ? rob : ra, scratch, (long)nvox);
+      hipLaunchKernelGGL(k_dist_axis, dim3(nblk), dim3(256), 0, h->stream, scratch, d0, shape[0], shape[1], shape[2], 2);
+      hipLaunchKernelGGL(k_dist_axis, dim3(nblk), dim3(256), 0, h->stream, d0, scratch, shape[0], shape[1], shape[2], 1);
+      hipLaunchKernelGGL(k_dist_axis, dim3(nblk), dim3(256), 0, h->stream, scratch, d0, shape[0], shape[1], shape[2], 0);
     }
-    // GTO_DIST_CAP is even: the result is back in the buffer allocated for it, `scratch` is scratch again
-    static_assert(GTO_DIST_CAP % 2 == 0, "ping-pong parity");
     (which ? distb : dista) = d0;
   }
   if (rob == ra) distb = dista;

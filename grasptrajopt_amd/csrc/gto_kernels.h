@@ -653,6 +653,34 @@ __global__ void k_dist_relax(const uint8_t* __restrict__ in, uint8_t* __restrict
   out[i] = (uint8_t)(best > GTO_DIST_CAP ? GTO_DIST_CAP : best);
 }
 
+// The same field in three launches instead of GTO_DIST_CAP sweeps: the Chebyshev metric is separable,
+//   d(p) = min_{dx,dy,dz} max(|dx|, |dy|, |dz|, d0(p + d)) = min_dx max(|dx|, min_dy max(|dy|, min_dz max(|dz|, d0))),
+// so one pass per axis with out(p) = min_{|o| <= cap} max(|o|, in(p + o e_axis)) is exact (max distributes over min);
+// the scan stops as soon as |o| reaches the best value found.  Threads run along z (the fastest axis), so the loads of a
+// wave are contiguous for every offset of every axis.
+__global__ void k_dist_axis(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int nx, int ny, int nz, int axis) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long nvox = (long)nx * ny * nz;
+  if (i >= nvox) return;
+  const int iz = (int)(i % nz), iy = (int)((i / nz) % ny), ix = (int)(i / ((long)nz * ny));
+  const int pos = axis == 0 ? ix : (axis == 1 ? iy : iz), len = axis == 0 ? nx : (axis == 1 ? ny : nz);
+  const long stride = axis == 0 ? (long)nz * ny : (axis == 1 ? (long)nz : 1L);
+  int best = in[i];
+  for (int o = 1; o < best; ++o) {  // |o| >= best cannot improve: max(|o|, .) >= best
+    if (pos - o >= 0) {
+      const int v = in[i - o * stride];
+      const int c = v > o ? v : o;
+      best = c < best ? c : best;
+    }
+    if (pos + o < len) {
+      const int v = in[i + o * stride];
+      const int c = v > o ? v : o;
+      best = c < best ? c : best;
+    }
+  }
+  out[i] = (uint8_t)best;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Dominant kernel.  One workgroup per (instance, group of TG consecutive waypoints):
 //   grid.x = 8 * ceil(B/8) * ceil(nT/TG) (+ B goal workgroups);  b == blockIdx (mod 8), so all waypoints

@@ -189,9 +189,13 @@ class Solver:
         for k in p:
             if k not in self.opt.parameters:
                 raise KeyError(f"unknown parameter '{k}'")
-        self._p_dict = {k: np.zeros(shape) for k, shape in self.opt.parameters.items()}
+        self._p_dict = {k: np.zeros(shape, dtype=np.float32 if k in ("sdf_cost_all", "sdf_cost_obstacle") else np.float64)
+                        for k, shape in self.opt.parameters.items() if k not in p}
         for k, v in p.items():
-            self._p_dict[k] = np.asarray(v, dtype=np.float64).reshape(self.opt.parameters[k])
+            # the two cost fields stay float32 (they are float32 at the boundary, include/gto_solver.h): converting 2 x 2 M
+            # voxels to float64 here and back in set_scene cost more than the upload itself
+            keep = k in ("sdf_cost_all", "sdf_cost_obstacle") and getattr(v, "dtype", None) == np.float32
+            self._p_dict[k] = (np.asarray(v) if keep else np.asarray(v, dtype=np.float64)).reshape(self.opt.parameters[k])
         self._scene_dirty = True
 
     def stats(self) -> Dict:

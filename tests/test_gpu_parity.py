@@ -269,7 +269,8 @@ def test_slots_hand_over_to_waiting_instances(capi, oracle_mod, monkeypatch, slo
 
 
 @pytest.mark.parametrize("knob,value", [("GTO_OBS_TG", "1"), ("GTO_OBS_TG", "2"), ("GTO_OBS_TG", "4"), ("GTO_OBS_INTERLEAVE", "0"),
-                                        ("GTO_OBS_INTERLEAVE", "1"), ("GTO_CHECK_EVERY", "1"), ("GTO_CHECK_EVERY", "7")])
+                                        ("GTO_OBS_INTERLEAVE", "1"), ("GTO_CHECK_EVERY", "1"), ("GTO_CHECK_EVERY", "7"),
+                                        ("GTO_STEP_NW_FEW", "4"), ("GTO_DIST_RELAX", "1")])
 def test_launch_geometry_does_not_change_results(capi, oracle_mod, monkeypatch, knob, value):
     """How the waypoints are dealt to the workgroups of the obstacle kernel (group size, consecutive or interleaved) and
     how often the host looks at the progress word are scheduling decisions: every instance gets bit-for-bit the same
@@ -285,6 +286,15 @@ def test_launch_geometry_does_not_change_results(capi, oracle_mod, monkeypatch, 
         got = h2.solve_batch(*prob.solve_args())
         for a, b in zip(ref, got):
             np.testing.assert_array_equal(a, b)
+    if knob == "GTO_DIST_RELAX":
+        # the distance field built by 48 relaxation sweeps (h2) and by one separable pass per axis (h) cull the same
+        # chunks: the obstacle kernel gathers exactly the same number of surface points
+        work = []
+        for x in (h, h2):
+            x.set_profiling(True)
+            x.solve_batch(*prob.solve_args())
+            work.append(x.last_kernel_work()[0])
+        assert work[0] == work[1] and work[0] > 0
     h2.close()
     h.close()
 
