@@ -69,6 +69,12 @@ struct gto_handle {
   long long* dbg = nullptr;
   // staging for the host-pointer entry points
   DevBuf in[8], out[8];
+  // pinned twins of the staging buffers: host arrays are copied through them, so that the transfers are real DMA at a
+  // steady rate (a hipMemcpyAsync from pageable memory stages inside the runtime: 1-6 ms of jitter per call with four
+  // lanes copying at once) and never depend on what kind of memory the caller's arrays live in
+  DevBuf pin_in[8], pin_out[8];
+  struct PendingOut { void* host; const void* pin; size_t bytes; };
+  std::vector<PendingOut> pending_out;  // device -> pinned copies in flight; finish_out() delivers them after the sync
   // profiling of the dominant kernel
   bool profiling = false;
   std::vector<hipEvent_t> ev;
@@ -85,11 +91,13 @@ struct gto_handle {
     hipError_t e_ = (call);                                                                          \
     if (e_ != hipSuccess) {                                                                          \
       (h)->err = std::string(#call) + ": " + hipGetErrorString(e_);                                  \
+      (h)->pending_out.clear(); /* an entry point that fails delivers nothing */                     \
       return GTO_ERR_HIP;                                                                            \
     }                                                                                                \
   } while (0)
 
 static int fail(gto_handle* h, int code, const std::string& msg) {
+  if (h) h->pending_out.clear();
   if (h) h->err = msg;
   else g_create_error = msg;
   return code;
@@ -495,6 +503,8 @@ void gto_destroy(gto_handle* h) {
   for (DevBuf* b : bufs) (void)hipFree(b->p);
   for (auto& b : h->in) (void)hipFree(b.p);
   for (auto& b : h->out) (void)hipFree(b.p);
+  for (auto& b : h->pin_in) if (b.p) (void)hipHostFree(b.p);
+  for (auto& b : h->pin_out) if (b.p) (void)hipHostFree(b.p);
   for (auto e : h->ev) (void)hipEventDestroy(e);
   if (h->stream && h->own_stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -1064,12 +1074,24 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
 }
 
 // host-pointer staging helpers
+static int ensure_pinned(gto_handle* h, DevBuf& b, size_t bytes) {
+  if (bytes <= b.cap) return GTO_OK;
+  if (b.p) HIPCHK(h, hipHostFree(b.p));
+  b.p = nullptr;
+  b.cap = 0;
+  const size_t want = bytes + bytes / 4 + 256;
+  HIPCHK(h, hipHostMalloc(&b.p, want));
+  b.cap = want;
+  return GTO_OK;
+}
 static int stage_in(gto_handle* h, int slot, const void* src, size_t bytes, const void** dptr) {
   *dptr = nullptr;
   if (!src) return GTO_OK;
   int rc = ensure(h, h->in[slot], bytes);
   if (rc) return rc;
-  HIPCHK(h, hipMemcpyAsync(h->in[slot].p, src, bytes, hipMemcpyHostToDevice, h->stream));
+  if ((rc = ensure_pinned(h, h->pin_in[slot], bytes))) return rc;  // free again: every entry point ends with a stream sync
+  memcpy(h->pin_in[slot].p, src, bytes);
+  HIPCHK(h, hipMemcpyAsync(h->in[slot].p, h->pin_in[slot].p, bytes, hipMemcpyHostToDevice, h->stream));
   *dptr = h->in[slot].p;
   return GTO_OK;
 }
@@ -1083,7 +1105,21 @@ static int stage_out(gto_handle* h, int slot, const void* host, size_t bytes, vo
 }
 static int fetch_out(gto_handle* h, int slot, void* host, size_t bytes) {
   if (!host) return GTO_OK;
-  HIPCHK(h, hipMemcpyAsync(host, h->out[slot].p, bytes, hipMemcpyDeviceToHost, h->stream));
+  int rc = ensure_pinned(h, h->pin_out[slot], bytes);
+  if (rc) return rc;
+  HIPCHK(h, hipMemcpyAsync(h->pin_out[slot].p, h->out[slot].p, bytes, hipMemcpyDeviceToHost, h->stream));
+  h->pending_out.push_back({host, h->pin_out[slot].p, bytes});
+  return GTO_OK;
+}
+// after the stream sync that follows the fetch_out calls of an entry point: pinned -> the caller's arrays
+static int sync_and_finish_out(gto_handle* h) {
+  const hipError_t e = hipStreamSynchronize(h->stream);
+  if (e != hipSuccess) {
+    h->pending_out.clear();
+    HIPCHK(h, e);
+  }
+  for (const auto& po : h->pending_out) memcpy(po.host, po.pin, po.bytes);
+  h->pending_out.clear();
   return GTO_OK;
 }
 
@@ -1127,7 +1163,7 @@ int gto_solve_ik_batch(gto_handle* h, int32_t B, const int32_t* scene_id, const 
   if ((rc = fetch_out(h, 2, cost_out, B * sizeof(double)))) return rc;
   if ((rc = fetch_out(h, 3, iters_out, B * sizeof(int32_t)))) return rc;
   if ((rc = fetch_out(h, 4, status_out, B * sizeof(int32_t)))) return rc;
-  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if ((rc = sync_and_finish_out(h))) return rc;
   return GTO_OK;
 }
 
@@ -1169,7 +1205,7 @@ int gto_solve_base_batch(gto_handle* h, int32_t B, int32_t n_max, const int32_t*
   if ((rc = fetch_out(h, 2, cost_out, B * sizeof(double)))) return rc;
   if ((rc = fetch_out(h, 3, iters_out, B * sizeof(int32_t)))) return rc;
   if ((rc = fetch_out(h, 4, status_out, B * sizeof(int32_t)))) return rc;
-  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if ((rc = sync_and_finish_out(h))) return rc;
   return GTO_OK;
 }
 
@@ -1210,7 +1246,7 @@ int gto_eval_base_objective(gto_handle* h, int32_t B, int32_t n_max, const int32
                      (int32_t*)nullptr, (int32_t*)nullptr, (const double*)d_y0, (const double*)d_q0);
   HIPCHK(h, hipGetLastError());
   if ((rc = fetch_out(h, 2, cost_out, B * sizeof(double)))) return rc;
-  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if ((rc = sync_and_finish_out(h))) return rc;
   return GTO_OK;
 }
 
@@ -1250,7 +1286,7 @@ int gto_solve_batch(gto_handle* h, int32_t B, int32_t n_max, const int32_t* scen
   if ((rc = fetch_out(h, 2, cost_out, B * sizeof(double)))) return rc;
   if ((rc = fetch_out(h, 3, iters_out, B * sizeof(int32_t)))) return rc;
   if ((rc = fetch_out(h, 4, status_out, B * sizeof(int32_t)))) return rc;
-  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if ((rc = sync_and_finish_out(h))) return rc;
   return GTO_OK;
 }
 
@@ -1267,7 +1303,7 @@ int gto_eval_fk(gto_handle* h, int32_t nq, const double* q, double* frames_out) 
   if ((rc = stage_out(h, 0, frames_out, ob, &dout))) return rc;
   hipLaunchKernelGGL(k_eval_fk, dim3((nq + 63) / 64), dim3(64), 0, h->stream, h->d_rb, nq, (const double*)dq, (double*)dout);
   if ((rc = fetch_out(h, 0, frames_out, ob))) return rc;
-  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if ((rc = sync_and_finish_out(h))) return rc;
   return GTO_OK;
 }
 
@@ -1298,7 +1334,7 @@ int gto_eval_points(gto_handle* h, int32_t scene_id, int32_t nq, const double* q
   if ((rc = fetch_out(h, 1, offset_out, (size_t)nq * P * sizeof(int32_t)))) return rc;
   if ((rc = fetch_out(h, 2, value_out, (size_t)nq * P * sizeof(double)))) return rc;
   if ((rc = fetch_out(h, 3, grad_out, (size_t)nq * P * 3 * sizeof(double)))) return rc;
-  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if ((rc = sync_and_finish_out(h))) return rc;
   return GTO_OK;
 }
 
@@ -1433,7 +1469,7 @@ int gto_plan_cost(gto_handle* h, int32_t scene_id, int32_t n, const double* plan
   hipLaunchKernelGGL(k_plan_cost, dim3((unsigned)((T + GTO_PLAN_TG - 1) / GTO_PLAN_TG), n), dim3(256), pc_lds, h->stream, h->d_rb, h->d_px, h->d_py, h->d_pz, h->d_plink,
                      h->d_scenes + scene_id, (int)T, (const double*)dplans, (const double*)dbase, (double*)dpart);
   if ((rc = fetch_out(h, 0, part.data(), part.size() * sizeof(double)))) return rc;
-  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if ((rc = sync_and_finish_out(h))) return rc;
   HIPCHK(h, hipGetLastError());
   for (int i = 0; i < n; ++i) {
     double c = 0.0, dd = 0.0;
