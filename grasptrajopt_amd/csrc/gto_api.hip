@@ -984,7 +984,6 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
   bp.qfs = (double*)h->qfs.p;
   bp.cap = W;
   bp.n_total = B;
-  const size_t ndof = h->rb.ndof;
   HIPCHK(h, hipMemsetAsync(bp.n_done, 0, sizeof(int32_t), st));
   // the finished-counter reaches the host through a word in pinned memory that the step kernel writes; the tag tells
   // this call's values from what the last launches of the previous call may still be writing

@@ -737,7 +737,7 @@ __global__ __launch_bounds__(256, GTO_OBS_MIN_WAVES) void k_obstacle_gram(const 
   __shared__ unsigned s_touched[GTO_MAX_TG];  // per waypoint of the group: links whose Gram got a contribution
 
   const int bid = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int L = rb->n_links, n = rb->n_opt, T = sp.T, ndof = rb->ndof, F = rb->n_frames;
+  const int L = rb->n_links, n = rb->n_opt, T = sp.T, F = rb->n_frames;
   typedef Blk<NP> BK;
   const ObsLds lay(TG, F, L, cap_active, NP);
   double* s_vis = smem_obs + lay.vis;

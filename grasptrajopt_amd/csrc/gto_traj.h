@@ -214,7 +214,6 @@ __global__ __launch_bounds__(64 * NW, 4) void k_traj_solve(
   if (lane0 < L) ldesc = rb->link_anc[lane0];
   const double* __restrict__ tVo = tab + 64 * F;
   const double* __restrict__ tU = tVo + 16 * L;
-  const double* __restrict__ tI = tU + 16 * n;  // link_frame [L], opt_frame [n], prismatic flag [n], parent [F]
   const bool grad_on = sp.grad_mode == GTO_GRAD_CENTRAL_DIFF;
 
   // solver state: uniform over the workgroup, every thread carries it
