@@ -1300,7 +1300,12 @@ int gto_eval_fk(gto_handle* h, int32_t nq, const double* q, double* frames_out) 
   size_t ob = (size_t)nq * h->rb.n_frames * 16 * sizeof(double);
   if ((rc = stage_in(h, 0, q, (size_t)nq * h->rb.ndof * sizeof(double), &dq))) return rc;
   if ((rc = stage_out(h, 0, frames_out, ob, &dout))) return rc;
-  hipLaunchKernelGGL(k_eval_fk, dim3((nq + 63) / 64), dim3(64), 0, h->stream, h->d_rb, nq, (const double*)dq, (double*)dout);
+  {
+    const size_t lds = sizeof(double) * eval_kin_lds_doubles(h->rb.n_frames, h->rb.n_links, h->rb.n_opt);
+    HIPCHK(h, raise_dynamic_lds((const void*)k_eval_kin, lds));
+    hipLaunchKernelGGL(k_eval_kin, dim3((nq + GTO_EVAL_TG - 1) / GTO_EVAL_TG), dim3(256), lds, h->stream, h->d_rb, nq, (const double*)dq,
+                       (double*)dout, (double*)nullptr);
+  }
   if ((rc = fetch_out(h, 0, frames_out, ob))) return rc;
   if ((rc = sync_and_finish_out(h))) return rc;
   return GTO_OK;
@@ -1325,7 +1330,12 @@ int gto_eval_points(gto_handle* h, int32_t scene_id, int32_t nq, const double* q
   if ((rc = stage_out(h, 1, offset_out, (size_t)nq * P * sizeof(int32_t), &doff))) return rc;
   if ((rc = stage_out(h, 2, value_out, (size_t)nq * P * sizeof(double), &dval))) return rc;
   if ((rc = stage_out(h, 3, grad_out, (size_t)nq * P * 3 * sizeof(double), &dgrad))) return rc;
-  hipLaunchKernelGGL(k_eval_kin, dim3((nq + 63) / 64), dim3(64), 0, h->stream, h->d_rb, nq, (const double*)dq, (double*)h->vis.p);
+  {
+    const size_t lds = sizeof(double) * eval_kin_lds_doubles(h->rb.n_frames, h->rb.n_links, h->rb.n_opt);
+    HIPCHK(h, raise_dynamic_lds((const void*)k_eval_kin, lds));
+    hipLaunchKernelGGL(k_eval_kin, dim3((nq + GTO_EVAL_TG - 1) / GTO_EVAL_TG), dim3(256), lds, h->stream, h->d_rb, nq, (const double*)dq,
+                       (double*)nullptr, (double*)h->vis.p);
+  }
   hipLaunchKernelGGL(k_eval_points, dim3((P + 255) / 256, nq), dim3(256), 0, h->stream, h->d_rb, h->d_px, h->d_py, h->d_pz,
                      h->d_plink, h->d_perm, want_field ? h->d_scenes + scene_id : nullptr, nq, (const double*)h->vis.p,
                      (const double*)dbase, use_obs, (double*)dx, (int32_t*)doff, (double*)dval, (double*)dgrad);

@@ -80,10 +80,6 @@ struct Chunk {
 };
 
 // ---------------------------------------------------------------- 3x4 affine helpers (row-major)
-__host__ __device__ inline void aff_identity(double* m) {
-  for (int i = 0; i < 12; ++i) m[i] = 0.0;
-  m[0] = m[5] = m[10] = 1.0;
-}
 __host__ __device__ inline void aff_mul(const double* a, const double* b, double* c) {
   double r[12];
   for (int i = 0; i < 3; ++i) {
@@ -119,51 +115,10 @@ __host__ __device__ inline void rt2aff(const double* R, const double* t, double*
     m[4 * i + 3] = t[i];
   }
 }
-// optas/spatialmath.py:90-100 angvec2r with a unit axis u
-__host__ __device__ inline void angvec2r_unit(double theta, const double* u, double* R) {
-  double sk[9] = {0, -u[2], u[1], u[2], 0, -u[0], -u[1], u[0], 0};
-  double sk2[9];
-  mat3_mul(sk, sk, sk2);
-  double s = sin(theta), c1 = 1.0 - cos(theta);
-  for (int i = 0; i < 9; ++i) R[i] = s * sk[i] + c1 * sk2[i];
-  R[0] += 1.0;
-  R[4] += 1.0;
-  R[8] += 1.0;
-}
 __host__ __device__ inline void cross3(const double* a, const double* b, double* c) {
   c[0] = a[1] * b[2] - a[2] * b[1];
   c[1] = a[2] * b[0] - a[0] * b[2];
   c[2] = a[0] * b[1] - a[1] * b[0];
-}
-
-// Forward kinematics of every frame (optas/models.py:826-868, prefix-shared).
-// frames: [n_frames][12], indexed with `stride` doubles between consecutive entries of one frame
-// element so that per-thread scratch (stride 1) and LDS/transposed layouts can share the code.
-__host__ __device__ inline void fk_frames(const RobotDev* rb, const double* q, double* frames) {
-  for (int i = 0; i < rb->n_frames; ++i) {
-    double T[12];
-    if (rb->parent[i] < 0) {
-      double I[12];
-      aff_identity(I);
-      aff_mul(I, rb->origin[i], T);
-    } else {
-      aff_mul(frames + 12 * rb->parent[i], rb->origin[i], T);
-    }
-    int jt = rb->joint_type[i];
-    if (jt == GTO_JOINT_REVOLUTE) {
-      double R[9], M[12], z[3] = {0, 0, 0};
-      angvec2r_unit(q[rb->q_index[i]], rb->axis_unit[i], R);
-      rt2aff(R, z, M);
-      aff_mul(T, M, T);
-    } else if (jt == GTO_JOINT_PRISMATIC) {
-      double qi = q[rb->q_index[i]];
-      double tr[3] = {qi * rb->axis_unit[i][0], qi * rb->axis_unit[i][1], qi * rb->axis_unit[i][2]};
-      double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, M[12];
-      rt2aff(I3, tr, M);
-      aff_mul(T, M, T);
-    }
-    for (int k = 0; k < 12; ++k) frames[12 * i + k] = T[k];
-  }
 }
 
 // index of (i,j), i<=j, in the packed upper triangle of a symmetric 6x6

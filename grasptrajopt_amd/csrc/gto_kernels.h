@@ -206,94 +206,6 @@ __device__ inline void wave_sync_lds() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// Forward kinematics of ONE configuration by a whole workgroup (optas/models.py:826-868, prefix
-// shared): s_q [ndof] in LDS -> s_fr [n_frames][12] global frame transforms in LDS.
-// Must be called by every thread of the block (contains barriers).
-__device__ inline void fk_block(const RobotDev* rb, const double* s_q, double* s_fr, int tid) {
-  const int F = rb->n_frames;
-  if (tid < F) {  // local transform L_i = origin_i @ joint_motion_i(q)
-    const int jt = rb->joint_type[tid];
-    const double* O = rb->origin[tid];
-    double* L = s_fr + 12 * tid;
-    if (jt == GTO_JOINT_REVOLUTE) {
-      // Rodrigues about the unit axis u: R = cos*I + sin*[u]x + (1-cos) u u^T (optas/spatialmath.py:90-100)
-      const double th = s_q[rb->q_index[tid]];
-      const double sn = sin(th), cs = cos(th), c1 = 1.0 - cs;
-      const double u0 = rb->axis_unit[tid][0], u1 = rb->axis_unit[tid][1], u2 = rb->axis_unit[tid][2];
-      const double R00 = cs + c1 * u0 * u0, R01 = c1 * u0 * u1 - sn * u2, R02 = c1 * u0 * u2 + sn * u1;
-      const double R10 = c1 * u1 * u0 + sn * u2, R11 = cs + c1 * u1 * u1, R12 = c1 * u1 * u2 - sn * u0;
-      const double R20 = c1 * u2 * u0 - sn * u1, R21 = c1 * u2 * u1 + sn * u0, R22 = cs + c1 * u2 * u2;
-#pragma unroll
-      for (int r = 0; r < 3; ++r) {
-        const double o0 = O[4 * r], o1 = O[4 * r + 1], o2 = O[4 * r + 2];
-        L[4 * r] = o0 * R00 + o1 * R10 + o2 * R20;
-        L[4 * r + 1] = o0 * R01 + o1 * R11 + o2 * R21;
-        L[4 * r + 2] = o0 * R02 + o1 * R12 + o2 * R22;
-        L[4 * r + 3] = O[4 * r + 3];
-      }
-    } else if (jt == GTO_JOINT_PRISMATIC) {
-      const double qi = s_q[rb->q_index[tid]];
-      const double t0 = qi * rb->axis_unit[tid][0], t1 = qi * rb->axis_unit[tid][1], t2 = qi * rb->axis_unit[tid][2];
-#pragma unroll
-      for (int r = 0; r < 3; ++r) {
-        const double o0 = O[4 * r], o1 = O[4 * r + 1], o2 = O[4 * r + 2];
-        L[4 * r] = o0;
-        L[4 * r + 1] = o1;
-        L[4 * r + 2] = o2;
-        L[4 * r + 3] = o0 * t0 + o1 * t1 + o2 * t2 + O[4 * r + 3];
-      }
-    } else {
-      for (int k = 0; k < 12; ++k) L[k] = O[k];
-    }
-  }
-  __syncthreads();
-  // chain T_i = T_parent @ L_i in place; lane r (<3) carries row r of the running product in registers,
-  // so a serial chain needs no LDS write->read round trip (only branching parents are re-read)
-  if (tid < 3) {
-    double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
-    int have = -1;  // frame whose row is held in p0..p3
-    for (int i = 0; i < F; ++i) {
-      const int p = rb->parent[i];
-      if (p < 0) {  // root: T = L
-        const double* Lr = s_fr + 12 * i + 4 * tid;
-        p0 = Lr[0];
-        p1 = Lr[1];
-        p2 = Lr[2];
-        p3 = Lr[3];
-        have = i;
-        continue;
-      }
-      if (p != have) {
-        wave_sync_lds();
-        const double* P = s_fr + 12 * p + 4 * tid;
-        p0 = P[0];
-        p1 = P[1];
-        p2 = P[2];
-        p3 = P[3];
-      }
-      const double* Lm = s_fr + 12 * i;
-      const double t0 = p0 * Lm[0] + p1 * Lm[4] + p2 * Lm[8];
-      const double t1 = p0 * Lm[1] + p1 * Lm[5] + p2 * Lm[9];
-      const double t2 = p0 * Lm[2] + p1 * Lm[6] + p2 * Lm[10];
-      const double t3 = p0 * Lm[3] + p1 * Lm[7] + p2 * Lm[11] + p3;
-      __builtin_amdgcn_wave_barrier();  // every row has read L_i before any row overwrites it
-      double* Oo = s_fr + 12 * i + 4 * tid;
-      Oo[0] = t0;
-      Oo[1] = t1;
-      Oo[2] = t2;
-      Oo[3] = t3;
-      p0 = t0;
-      p1 = t1;
-      p2 = t2;
-      p3 = t3;
-      have = i;
-    }
-  }
-  __syncthreads();
-}
-
-// Ordering point for LDS traffic inside ONE wavefront (no s_barrier: DS operations of a wave are
-// processed in issue order; the fence keeps the compiler from moving accesses across it).
 __device__ inline void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -301,7 +213,7 @@ __device__ inline void wave_sync() {
 }
 
 // Forward kinematics of TWO configurations at once by one wavefront: lanes 0-31 work on s_q[0..],
-// s_fr[0..], lanes 32-63 on s_q[GTO_MAX_DOF..], s_fr[GTO_MAX_FRAMES*12..] (same math as fk_block).
+// s_fr[0..], lanes 32-63 on s_q[GTO_MAX_DOF..], s_fr[GTO_MAX_FRAMES*12..] (one frame after the other along the tree).
 __device__ __forceinline__ void fk_pair_wave(const RobotDev* rb, const double* s_q2, double* s_fr2, int lane) {
   const int half = lane >> 5, l = lane & 31;
   const double* s_q = s_q2 + half * GTO_MAX_DOF;
@@ -547,61 +459,6 @@ __device__ __forceinline__ void fk_mfma_tree(const RobotDev* __restrict__ rb, co
     }
   }
   if (dbgp && tid == 0) dbgp[7] = clock64();
-}
-
-// Kinematics of one configuration: visual transforms of the collision links, world screws of the
-// optimised joints and (optionally) the gripper / ee frames. Runs in ONE thread (private scratch).
-__device__ inline void kin_eval(const RobotDev* rb, const double* q, double* vis, double* screw, double* grip_ee) {
-  double frames[GTO_MAX_FRAMES * 12];
-  fk_frames(rb, q, frames);
-  const int L = rb->n_links;
-  if (vis) {
-    for (int l = 0; l < L; ++l) {
-      double V[12];
-      aff_mul(frames + 12 * rb->link_frame[l], rb->vis_origin[l], V);
-      for (int k = 0; k < 12; ++k) vis[12 * l + k] = V[k];
-    }
-  }
-  if (screw) {
-    for (int i = 0; i < rb->n_frames; ++i) {
-      int j = rb->opt_of_frame[i];
-      if (j < 0) continue;
-      const double* F = frames + 12 * i;
-      const double* u = rb->axis_unit[i];
-      double a[3], o[3];
-      for (int r = 0; r < 3; ++r) {
-        a[r] = F[4 * r] * u[0] + F[4 * r + 1] * u[1] + F[4 * r + 2] * u[2];
-        o[r] = F[4 * r + 3];
-      }
-      double* s = screw + 6 * j;
-      if (rb->joint_type[i] == GTO_JOINT_PRISMATIC) {
-        s[0] = s[1] = s[2] = 0.0;
-        s[3] = a[0];
-        s[4] = a[1];
-        s[5] = a[2];
-      } else {
-        double oxa[3];
-        cross3(o, a, oxa);
-        s[0] = a[0];
-        s[1] = a[1];
-        s[2] = a[2];
-        s[3] = oxa[0];
-        s[4] = oxa[1];
-        s[5] = oxa[2];
-      }
-    }
-  }
-  if (grip_ee) {
-    for (int k = 0; k < 12; ++k) {
-      grip_ee[k] = frames[12 * rb->frame_gripper + k];
-      grip_ee[12 + k] = frames[12 * rb->frame_ee + k];
-    }
-  }
-}
-
-__device__ inline void load_full_q(const RobotDev* rb, const double* Q0b, const double* Qopt, int T, int t, double* q) {
-  for (int i = 0; i < rb->ndof; ++i) q[i] = Q0b[(size_t)i * T + t];
-  for (int j = 0; j < rb->n_opt; ++j) q[rb->opt_index[j]] = Qopt[(size_t)j * T + t];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2963,23 +2820,53 @@ __global__ __launch_bounds__(64) void k_lm_finalize(const RobotDev* __restrict__
 
 // ------------------------------------------------------------------------------------------------
 // Evaluation kernels (parity / seed scoring entry points)
-__global__ void k_eval_fk(const RobotDev* __restrict__ rb, int nq, const double* __restrict__ q, double* __restrict__ out) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= nq) return;
-  double frames[GTO_MAX_FRAMES * 12];
-  fk_frames(rb, q + (size_t)i * rb->ndof, frames);
-  for (int f = 0; f < rb->n_frames; ++f) {
-    double* o = out + ((size_t)i * rb->n_frames + f) * 16;
-    for (int k = 0; k < 12; ++k) o[k] = frames[12 * f + k];
-    o[12] = o[13] = o[14] = 0.0;
-    o[15] = 1.0;
-  }
+#define GTO_EVAL_TG 4  // configurations per workgroup of k_eval_kin
+__host__ __device__ inline int eval_kin_lds_doubles(int F, int L, int n) {
+  return fk_tab_doubles(F, L, n) + GTO_EVAL_TG * F * 2 + fk_scratch_doubles(F, GTO_EVAL_TG) + GTO_EVAL_TG * L * 12 + GTO_EVAL_TG * GTO_NB * 6;
 }
-
-__global__ void k_eval_kin(const RobotDev* __restrict__ rb, int nq, const double* __restrict__ q, double* __restrict__ vis) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= nq) return;
-  kin_eval(rb, q + (size_t)i * rb->ndof, vis + (size_t)i * rb->n_links * 12, nullptr, nullptr);
+// Kinematics of nq configurations by the solver's own forward kinematics (fk_mfma_tree, four configurations per
+// workgroup): frames_out [nq][F][16] global transform of every frame (4x4 row-major; gto_eval_fk, pinned against
+// optas/models.py:826-868) and / or vis_out [nq][L][12] visual transforms of the collision links (gto_eval_points).
+__global__ __launch_bounds__(256) void k_eval_kin(const RobotDev* __restrict__ rb, int nq, const double* __restrict__ q,
+                                                  double* __restrict__ frames_out, double* __restrict__ vis_out) {
+  constexpr int TG = GTO_EVAL_TG;
+  const int i0 = blockIdx.x * TG, tid = threadIdx.x;
+  const int F = rb->n_frames, L = rb->n_links, n = rb->n_opt, ndof = rb->ndof;
+  const int ng = min(TG, nq - i0);
+  extern __shared__ __attribute__((aligned(16))) double smem_ek[];
+  double* s_tab = smem_ek;
+  double* s_sc = s_tab + fk_tab_doubles(F, L, n);
+  double* s_X = s_sc + TG * F * 2;
+  double* s_vis = s_X + fk_scratch_doubles(F, TG);
+  double* s_screw = s_vis + TG * L * 12;
+  const int nt = fk_tab_doubles(F, L, n);
+  for (int k = tid; k < nt; k += 256) s_tab[k] = rb->fk_tab[k];
+  for (int idx = tid; idx < ng * F; idx += 256) {
+    const int kq = idx / F, f = idx - kq * F;
+    const int jt = rb->joint_type[f], dq = rb->q_index[f];
+    double a = 0.0, cs = 1.0;
+    if (dq >= 0) {
+      const double qv = q[(size_t)(i0 + kq) * ndof + dq];
+      if (jt == GTO_JOINT_REVOLUTE) sincos(qv, &a, &cs);
+      else if (jt == GTO_JOINT_PRISMATIC) a = qv;
+    }
+    s_sc[2 * idx] = a;
+    s_sc[2 * idx + 1] = cs;
+  }
+  __syncthreads();
+  fk_mfma_tree(rb, s_tab, ng, s_sc, s_X, reinterpret_cast<int*>(s_X + ng * 32 * F + 64), tid, s_vis, s_screw);
+  __syncthreads();
+  if (frames_out) {  // X_f = G_f^T, row-major, in the ping-pong half the last round wrote
+    for (int idx = tid; idx < ng * F * 16; idx += 256) {
+      const int kq = idx / (F * 16), r_ = idx - kq * F * 16, f = r_ >> 4, e = r_ & 15;
+      const double* Xg = s_X + (size_t)kq * 32 * F + (rb->fk_rounds & 1) * 16 * F;
+      double v = Xg[16 * f + 4 * (e & 3) + (e >> 2)];
+      if (e >= 12) v = (e == 15) ? 1.0 : 0.0;  // the affine part is exact by construction
+      frames_out[((size_t)(i0 + kq) * F + f) * 16 + e] = v;
+    }
+  }
+  if (vis_out)
+    for (int idx = tid; idx < ng * L * 12; idx += 256) vis_out[(size_t)i0 * L * 12 + idx] = s_vis[idx];
 }
 
 // thread per (configuration, sorted point); outputs in the caller's original point order via perm
