@@ -1380,6 +1380,31 @@ static int eval_common(gto_handle* h, int B, int n_max, const int32_t* scene_id,
   if ((rc = stage_in(h, 4, standoff, (size_t)B * 16 * sizeof(double), &d_so))) return rc;
   if ((rc = stage_in(h, 5, base_pos, (size_t)B * 3 * sizeof(double), &d_base))) return rc;
   if ((rc = stage_in(h, 6, Q, B * ndof * T * sizeof(double), &d_Q0))) return rc;
+  if (h->mode == GTO_MODE_SINGLE_LAUNCH && h->np == GTO_NB) {
+    // the single-launch kernel's own evaluation path (one trajectory evaluation of k_traj_solve, Q taken as it is): what
+    // that mode's solve iterates on is then what the fixture and oracle comparisons look at
+    if ((rc = ensure(h, h->evterms, (size_t)B * 4 * sizeof(double)))) return rc;
+    if ((rc = ensure(h, h->evblocks, (size_t)B * T * BLK_STRIDE * sizeof(double)))) return rc;
+    TrajArgs a = {};
+    a.scene_id = (const int32_t*)d_sid, a.qc = (const double*)d_qc, a.goals = (const double*)d_goals, a.n_goals = (const int32_t*)d_ng;
+    a.standoff = (const double*)d_so, a.base_pos = (const double*)d_base, a.Q0 = (const double*)d_Q0;
+    a.B = B, a.raw = 1, a.eval_only = 1;
+    a.ev_terms = (double*)h->evterms.p, a.ev_blocks = (double*)h->evblocks.p;
+    if ((rc = launch_traj(h, h->stream, a, make_params(h, n_max, standoff != nullptr)))) return rc;
+    std::vector<double> terms((size_t)B * 4);
+    blocks.resize((size_t)B * T * BLK_STRIDE);
+    HIPCHK(h, hipMemcpyAsync(terms.data(), h->evterms.p, terms.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(blocks.data(), h->evblocks.p, blocks.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipGetLastError());
+    states.assign(B, InstState{});
+    ssfixed.assign((size_t)B * 4, 0.0);
+    for (int b = 0; b < B; ++b) {
+      states[b].fgoal_try = terms[4 * b], states[b].fvel_try = terms[4 * b + 2], states[b].argmin_try = (int32_t)terms[4 * b + 3];
+      for (int t = 0; t < 2; ++t) ssfixed[4 * b + t] = blocks[((size_t)b * T + t) * BLK_STRIDE + BLK_SS];
+    }
+    return GTO_OK;
+  }
   if ((rc = ensure_workspace(h, B))) return rc;
   SolveParams sp = make_params(h, n_max, standoff != nullptr);
   BatchPtrs bp = make_ptrs(h, (const int32_t*)d_sid, (const double*)d_qc, (const double*)d_goals, (const int32_t*)d_ng,

@@ -104,9 +104,10 @@ def test_points_offsets_values_vs_oracle(capi, oracle_mod):
 # ------------------------------------------------------------------------------------------ objective pieces
 @pytest.mark.parametrize("robot,n_goals,standoff", [("panda", 1, True), ("panda", 5, True), ("panda", 3, False),
                                                      ("fetch", 2, True)])
-def test_objective_terms_vs_oracle(capi, oracle_mod, robot, n_goals, standoff):
+@pytest.mark.parametrize("mode", [0, 1])  # which kernels evaluate: k_lm_init + k_obstacle_gram | k_traj_solve's evaluation pass
+def test_objective_terms_vs_oracle(capi, oracle_mod, robot, n_goals, standoff, mode):
     prob = Problem(robot, B=5, scene_seed=3, n_goals=n_goals, use_standoff=standoff, base=(0.01, 0.0, -0.02))
-    h, o = make_pair(capi, oracle_mod, prob)
+    h, o = make_pair(capi, oracle_mod, prob, mode=mode)
     rng = np.random.default_rng(0)
     Q = prob.Q0.copy()
     oi = prob.desc.opt_index
@@ -121,9 +122,10 @@ def test_objective_terms_vs_oracle(capi, oracle_mod, robot, n_goals, standoff):
 
 
 @pytest.mark.parametrize("robot,dense", [("panda", True), ("fetch", True), ("panda", False), ("fetch", False)])
-def test_obstacle_normal_equations_vs_oracle(capi, oracle_mod, robot, dense):
+@pytest.mark.parametrize("mode", [0, 1])
+def test_obstacle_normal_equations_vs_oracle(capi, oracle_mod, robot, dense, mode):
     prob = Problem(robot, B=4, scene_seed=1, base=(0.0, 0.02, 0.01))
-    h, o = make_pair(capi, oracle_mod, prob)
+    h, o = make_pair(capi, oracle_mod, prob, mode=mode)
     Q = prob.Q0.copy()
     oi = prob.desc.opt_index
     if dense:
@@ -348,8 +350,9 @@ def test_hip_base_placement_ends_where_lbfgsb_ends(capi, oracle_mod):
     h.close()
 
 
+@pytest.mark.parametrize("mode", [0, 1])
 @pytest.mark.parametrize("robot", ["panda", "fetch", "panda_5k"])
-def test_hip_obstacle_blocks_against_finite_difference_jacobians(capi, oracle_mod, robot):
+def test_hip_obstacle_blocks_against_finite_difference_jacobians(capi, oracle_mod, robot, mode):
     """k_obstacle_gram's blocks (wrench Grams per link on the matrix core, projected onto the joint screws) against a
     point-by-point numpy assembly with FINITE-DIFFERENCE point Jacobians (tests/independent.py): no analytic Jacobian
     of anybody's is trusted."""
@@ -358,6 +361,7 @@ def test_hip_obstacle_blocks_against_finite_difference_jacobians(capi, oracle_mo
     prob = Problem(robot, B=2, scene_seed=3, T=T)
     opts = oracle_mod.reference_opts(T=T, standoff_offset=-4)
     h = capi.SolverHandle(prob.desc, prob.cfg["link_ee"], prob.cfg["link_gripper"], opts, device=0)
+    h.set_mode(mode)
     prob.finish(h.eval_fk)
     h.set_scene(*prob.scene_args())
     nz = sum(check_obstacle_blocks_against_fd(h, prob.desc, T, T - 4, prob.Q0[b], prob.base[b]) for b in range(prob.B))
@@ -579,8 +583,9 @@ def _fixture_handle(capi, robot, g, kind=None):
     return h
 
 
+@pytest.mark.parametrize("mode", [0, 1])
 @pytest.mark.parametrize("robot", ["panda", "fetch"])
-def test_objective_terms_vs_reference_fixture(capi, robot):
+def test_objective_terms_vs_reference_fixture(capi, robot, mode):
     """gto_eval_objective against the reference's cost expressions (gto/gto_planner.py:84-135): f_goal of the set and of
     every goal alone, arg-min goal (bit-exact), f_obs on a dense random field (every point's voxel matters) and on a
     sparse one, f_vel.  1e-10 relative."""
@@ -588,6 +593,7 @@ def test_objective_terms_vs_reference_fixture(capi, robot):
     Q = g[f"{robot}_Q"]
     for tag in [str(c) for c in g["cases"] if str(c).startswith(robot)]:
         h = _fixture_handle(capi, robot, g, tag.split("_")[-1])
+        h.set_mode(mode)
         RT = g[tag + "_RT"]
         n = RT.shape[1]
         so = g[f"{robot}_standoff"] if "_so1_" in tag else None
