@@ -256,6 +256,7 @@ def test_slots_hand_over_to_waiting_instances(capi, oracle_mod, monkeypatch, slo
     ref = h.solve_batch(*prob.solve_args())
     monkeypatch.setenv("GTO_SLOTS", str(slots))
     h2 = capi.SolverHandle(prob.desc, prob.cfg["link_ee"], prob.cfg["link_gripper"], oracle_mod.reference_opts(max_iter=12), device=0)
+    h2.set_mode(0)  # slots belong to the rounds mode, whatever GTO_MODE says
     h2.set_scene(*prob.scene_args())
     for _ in range(2):  # the second call reuses the workspace and the lists of the first
         got = h2.solve_batch(*prob.solve_args())
@@ -283,6 +284,7 @@ def test_launch_geometry_does_not_change_results(capi, oracle_mod, monkeypatch, 
     ref = h.solve_batch(*prob.solve_args())
     monkeypatch.setenv(knob, value)
     h2 = capi.SolverHandle(prob.desc, prob.cfg["link_ee"], prob.cfg["link_gripper"], oracle_mod.reference_opts(max_iter=15), device=0)
+    h2.set_mode(0)
     h2.set_scene(*prob.scene_args())
     for _ in range(2):
         got = h2.solve_batch(*prob.solve_args())
