@@ -1,6 +1,7 @@
 // gto_api.hip — host side of libgto_hip.so: the C ABI declared in include/gto_solver.h.
 // Owns all device memory behind the opaque handle; no torch, no CPU fallback.
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
 
 #include <algorithm>
 #include <cmath>
@@ -1573,9 +1574,61 @@ int gto_depth_sdf_cost(int device, const float* depth, int32_t H, int32_t W, con
   double *d_px = d_p, *d_py = d_p + N, *d_pz = d_p + 2 * N;
   hipLaunchKernelGGL(k_depth_backproject, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, 0, d_depth, H, W, d_mats + 9,
                      d_mats + 18, d_mask, threshold, d_px, d_py, d_pz, d_valid);
-  if (nq)
+  const char* brute_env = getenv("GTO_DEPTH_BRUTE");
+  const bool brute = brute_env && atoi(brute_env) != 0;  // the exhaustive search (reference construction; the two are compared in a test)
+  if (nq && brute) {
     hipLaunchKernelGGL(k_depth_sdf, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, 0, d_px, d_py, d_pz, (int)N, d_depth, H, W,
                        d_mats, d_mats + 34, d_q, (long)nq, epsilon, w_inside, d_sdf, d_in, d_cost);
+  } else if (nq) {
+    // bounding-box hierarchy over 8 x 4 pixel tiles of the depth image (k_depth_sdf_bvh): same distances, bit for bit
+    const int tx = (W + GTO_BVH_TILE_W - 1) / GTO_BVH_TILE_W, ty = (H + GTO_BVH_TILE_H - 1) / GTO_BVH_TILE_H;
+    int P = 1;
+    while (P < tx || P < ty) P <<= 1;
+    if (P > 1024) {
+      cleanup();
+      return fail(nullptr, GTO_ERR_UNSUPPORTED, "gto_depth_sdf_cost: depth image larger than 8192 x 4096");
+    }
+    double* d_boxes = (double*)dalloc((size_t)(2 * P * P) * 6 * sizeof(double));
+    if (!d_boxes) {
+      cleanup();
+      return fail(nullptr, GTO_ERR_ALLOC, "gto_depth_sdf_cost: device allocation failed");
+    }
+    hipLaunchKernelGGL(k_bvh_leaves, dim3((unsigned)((P * P + 255) / 256)), dim3(256), 0, 0, d_px, d_py, d_pz, H, W, P, d_boxes);
+    if (P > 1) hipLaunchKernelGGL(k_bvh_up, dim3(1), dim3(1024), 0, 0, P, d_boxes);
+    // queries in Morton order of their position (coherent waves): 30-bit keys, hipCUB radix sort of (key, index)
+    if (nq >= ((int64_t)1 << 31)) {
+      cleanup();
+      return fail(nullptr, GTO_ERR_UNSUPPORTED, "gto_depth_sdf_cost: more than 2^31 queries");
+    }
+    unsigned* d_keys = (unsigned*)dalloc((size_t)nq * 4 * sizeof(unsigned));  // keys in / out, indices in / out
+    if (!d_keys) {
+      cleanup();
+      return fail(nullptr, GTO_ERR_ALLOC, "gto_depth_sdf_cost: device allocation failed");
+    }
+    unsigned long long* d_stats = nullptr;
+    if (getenv("GTO_DEPTH_STATS")) {
+      d_stats = (unsigned long long*)dalloc(3 * sizeof(unsigned long long));
+      if (d_stats) DCHK(hipMemset(d_stats, 0, 3 * sizeof(unsigned long long)));
+    }
+    unsigned *d_keys2 = d_keys + nq, *d_idx = d_keys + 2 * nq, *d_idx2 = d_keys + 3 * nq;
+    hipLaunchKernelGGL(k_query_keys, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, 0, d_q, (long)nq, d_boxes, d_keys, d_idx);
+    size_t tmp_bytes = 0;
+    DCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, d_keys, d_keys2, d_idx, d_idx2, (int)nq, 0, 30, (hipStream_t)0));
+    void* d_tmp = dalloc(tmp_bytes);
+    if (!d_tmp) {
+      cleanup();
+      return fail(nullptr, GTO_ERR_ALLOC, "gto_depth_sdf_cost: device allocation failed");
+    }
+    DCHK(hipcub::DeviceRadixSort::SortPairs(d_tmp, tmp_bytes, d_keys, d_keys2, d_idx, d_idx2, (int)nq, 0, 30, (hipStream_t)0));
+    hipLaunchKernelGGL(k_depth_sdf_bvh, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, 0, d_px, d_py, d_pz, d_boxes, P, d_idx2, d_depth, H, W,
+                       d_mats, d_mats + 34, d_q, (long)nq, epsilon, w_inside, d_sdf, d_in, d_cost, d_stats);
+    if (d_stats) {
+      unsigned long long st[3];
+      DCHK(hipMemcpy(st, d_stats, sizeof st, hipMemcpyDeviceToHost));
+      fprintf(stderr, "[gto] depth field search: %lld queries, nodes popped per query %.1f, leaves per query %.1f, loop iterations per wave %.1f\n",
+              (long long)nq, (double)st[0] / nq, (double)st[1] / nq, (double)st[2] / ((nq + 63) / 64));
+    }
+  }
   DCHK(hipGetLastError());
   DCHK(hipDeviceSynchronize());
   if (sdf_out && nq) DCHK(hipMemcpy(sdf_out, d_sdf, (size_t)nq * sizeof(float), hipMemcpyDeviceToHost));

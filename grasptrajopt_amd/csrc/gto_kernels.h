@@ -3013,32 +3013,14 @@ __global__ void k_depth_backproject(const float* __restrict__ depth, int H, int 
 // get_sdf (:56-61) + is_outside (:126-141) + cost map (:84-89): one query per thread, the cloud streamed
 // through LDS in tiles; exact nearest neighbour by exhaustive search in FP64 (the KD-tree of the reference
 // returns the same distance), a few ms for 10^5 queries x 3*10^5 points at the FP64 vector rate.
-__global__ __launch_bounds__(256) void k_depth_sdf(const double* __restrict__ px, const double* __restrict__ py,
-                                                   const double* __restrict__ pz, int N, const float* __restrict__ depth,
-                                                   int H, int W, const double* __restrict__ K,
-                                                   const double* __restrict__ cam_inv, const double* __restrict__ query,
-                                                   long nq, float epsilon, float w_inside, float* __restrict__ sdf_out,
-                                                   uint8_t* __restrict__ inside_out, float* __restrict__ cost_out) {
-#pragma clang fp contract(off)  // see k_depth_backproject
-  __shared__ double sx[256], sy[256], sz[256];
-  const long q = (long)blockIdx.x * 256 + threadIdx.x;
-  const bool live = q < nq;
-  const double q0 = live ? query[3 * q] : 0.0, q1 = live ? query[3 * q + 1] : 0.0, q2 = live ? query[3 * q + 2] : 0.0;
-  double best = INFINITY;
-  for (int base = 0; base < N; base += 256) {
-    const int j = base + threadIdx.x;
-    sx[threadIdx.x] = j < N ? px[j] : INFINITY;
-    sy[threadIdx.x] = j < N ? py[j] : INFINITY;
-    sz[threadIdx.x] = j < N ? pz[j] : INFINITY;
-    __syncthreads();
-#pragma unroll 8
-    for (int k = 0; k < 256; ++k) {
-      const double dx = q0 - sx[k], dy = q1 - sy[k], dz = q2 - sz[k];
-      const double d2 = (dx * dx + dy * dy) + dz * dz;
-      best = fmin(best, d2);  // NaN (inf - inf never occurs: queries are finite) is ignored by fmin
-    }
-    __syncthreads();
-  }
+// What follows the nearest-neighbour search of a query (mesh_to_sdf/depth_point_cloud.py:56-141): sign by the depth-buffer
+// visibility test, cost map.  best = squared distance to the nearest point of the cloud.
+__device__ __forceinline__ void depth_sdf_finish(bool live, long q, double q0, double q1, double q2, double best,
+                                                 const float* __restrict__ depth, int H, int W, const double* __restrict__ K,
+                                                 const double* __restrict__ cam_inv, float epsilon, float w_inside,
+                                                 float* __restrict__ sdf_out, uint8_t* __restrict__ inside_out,
+                                                 float* __restrict__ cost_out) {
+#pragma clang fp contract(off)
   if (!live) return;
   float dist = (float)sqrt(best);
   double pc[3], u[3];
@@ -3065,4 +3047,205 @@ __global__ __launch_bounds__(256) void k_depth_sdf(const double* __restrict__ px
   if (sdf_out) sdf_out[q] = dist;
   if (inside_out) inside_out[q] = outside ? 0 : 1;
   if (cost_out) cost_out[q] = c;
+}
+
+__global__ __launch_bounds__(256) void k_depth_sdf(const double* __restrict__ px, const double* __restrict__ py,
+                                                   const double* __restrict__ pz, int N, const float* __restrict__ depth,
+                                                   int H, int W, const double* __restrict__ K,
+                                                   const double* __restrict__ cam_inv, const double* __restrict__ query,
+                                                   long nq, float epsilon, float w_inside, float* __restrict__ sdf_out,
+                                                   uint8_t* __restrict__ inside_out, float* __restrict__ cost_out) {
+#pragma clang fp contract(off)  // see k_depth_backproject
+  __shared__ double sx[256], sy[256], sz[256];
+  const long q = (long)blockIdx.x * 256 + threadIdx.x;
+  const bool live = q < nq;
+  const double q0 = live ? query[3 * q] : 0.0, q1 = live ? query[3 * q + 1] : 0.0, q2 = live ? query[3 * q + 2] : 0.0;
+  double best = INFINITY;
+  for (int base = 0; base < N; base += 256) {
+    const int j = base + threadIdx.x;
+    sx[threadIdx.x] = j < N ? px[j] : INFINITY;
+    sy[threadIdx.x] = j < N ? py[j] : INFINITY;
+    sz[threadIdx.x] = j < N ? pz[j] : INFINITY;
+    __syncthreads();
+#pragma unroll 8
+    for (int k = 0; k < 256; ++k) {
+      const double dx = q0 - sx[k], dy = q1 - sy[k], dz = q2 - sz[k];
+      const double d2 = (dx * dx + dy * dy) + dz * dz;
+      best = fmin(best, d2);  // NaN (inf - inf never occurs: queries are finite) is ignored by fmin
+    }
+    __syncthreads();
+  }
+  depth_sdf_finish(live, q, q0, q1, q2, best, depth, H, W, K, cam_inv, epsilon, w_inside, sdf_out, inside_out, cost_out);
+}
+
+// ---- the same nearest-neighbour distances without the exhaustive search.  The cloud comes from a depth image, so
+// pixels that are close in the image are (mostly) close in space: tiles of 8 x 4 pixels are the leaves of a bounding-box
+// hierarchy, the tiles taken in Morton order of their (column, row) so that every node of the implicit complete binary
+// tree (heap indexing, P x P leaf slots, P a power of two) covers a rectangle of the image.  No sorting, no copy of
+// the points.  A query walks the tree nearer child first and skips every box that cannot hold a closer point.  The
+// skip test is exact in floating point: for a point p of a box, |q - p| >= (distance of q to the box) holds per axis
+// also after rounding (subtraction, product and sum are monotone), and the box distance is summed in the same order
+// as the point distance, so the minimum over the visited points is the minimum over all points, bit for bit.
+#define GTO_BVH_TILE_W 8
+#define GTO_BVH_TILE_H 4
+__host__ __device__ inline unsigned bvh_compact1by1(unsigned v) {
+  v &= 0x55555555u;
+  v = (v | (v >> 1)) & 0x33333333u;
+  v = (v | (v >> 2)) & 0x0f0f0f0fu;
+  v = (v | (v >> 4)) & 0x00ff00ffu;
+  v = (v | (v >> 8)) & 0x0000ffffu;
+  return v;
+}
+// boxes: [node][6] = lo x, y, z, hi x, y, z; an empty box is (+inf, -inf): its distance from anything is +inf
+__global__ void k_bvh_leaves(const double* __restrict__ px, const double* __restrict__ py, const double* __restrict__ pz, int H,
+                             int W, int P, double* __restrict__ boxes) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= P * P) return;
+  const int cx = (int)bvh_compact1by1((unsigned)s), cy = (int)bvh_compact1by1((unsigned)s >> 1);
+  double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (int r = 0; r < GTO_BVH_TILE_H; ++r)
+    for (int c = 0; c < GTO_BVH_TILE_W; ++c) {
+      const int y = cy * GTO_BVH_TILE_H + r, x = cx * GTO_BVH_TILE_W + c;
+      if (y >= H || x >= W) continue;
+      const size_t j = (size_t)y * W + x;
+      const double v[3] = {px[j], py[j], pz[j]};
+      if (!(v[0] < INFINITY)) continue;  // invalid pixel (point at infinity)
+      for (int k = 0; k < 3; ++k) {
+        lo[k] = fmin(lo[k], v[k]);
+        hi[k] = fmax(hi[k], v[k]);
+      }
+    }
+  double* b = boxes + (size_t)(P * P - 1 + s) * 6;
+  for (int k = 0; k < 3; ++k) b[k] = lo[k], b[3 + k] = hi[k];
+}
+// inner nodes, level by level from the leaves up (one workgroup: 2 P^2 nodes are a few ten thousand)
+__global__ __launch_bounds__(1024) void k_bvh_up(int P, double* __restrict__ boxes) {
+  for (int first = (P * P - 1) / 2, count = P * P / 2; count >= 1; first = (first - 1) / 2, count >>= 1) {
+    for (int i = threadIdx.x; i < count; i += 1024) {
+      const int n = first + i;
+      const double* a = boxes + (size_t)(2 * n + 1) * 6;
+      const double* c = boxes + (size_t)(2 * n + 2) * 6;
+      double* o = boxes + (size_t)n * 6;
+      for (int k = 0; k < 3; ++k) o[k] = fmin(a[k], c[k]), o[3 + k] = fmax(a[3 + k], c[3 + k]);
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (count == 1) break;
+  }
+}
+__device__ __forceinline__ double bvh_box_d2(const double* __restrict__ b, double q0, double q1, double q2) {
+#pragma clang fp contract(off)
+  const double ex = fmax(fmax(b[0] - q0, q0 - b[3]), 0.0), ey = fmax(fmax(b[1] - q1, q1 - b[4]), 0.0),
+               ez = fmax(fmax(b[2] - q2, q2 - b[5]), 0.0);
+  return (ex * ex + ey * ey) + ez * ez;
+}
+// Queries are visited in Morton order of their position (30-bit keys over the cloud's bounding box grown by its own
+// extent on every side; the sort is hipCUB's radix sort), so that the 64 lanes of a wave ask for neighbouring points
+// and walk nearly the same boxes: in the caller's order (a grid in C order: 64 consecutive voxels are a line across
+// the whole workspace) the lanes of a wave diverge at every node.
+__host__ __device__ inline unsigned bvh_part1by2(unsigned v) {
+  v &= 0x3ffu;
+  v = (v | (v << 16)) & 0x030000ffu;
+  v = (v | (v << 8)) & 0x0300f00fu;
+  v = (v | (v << 4)) & 0x030c30c3u;
+  v = (v | (v << 2)) & 0x09249249u;
+  return v;
+}
+__global__ void k_query_keys(const double* __restrict__ query, long nq, const double* __restrict__ boxes, unsigned* __restrict__ keys,
+                             unsigned* __restrict__ idx) {
+  const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= nq) return;
+  unsigned key = 0u;
+  for (int k = 0; k < 3; ++k) {
+    const double lo = boxes[k], hi = boxes[3 + k], ext = hi - lo;
+    double u = ext > 0.0 && ext < INFINITY ? (query[3 * q + k] - (lo - ext)) / (3.0 * ext) : 0.0;
+    u = fmin(fmax(u, 0.0), 1.0);
+    key |= bvh_part1by2((unsigned)(u * 1023.0)) << k;
+  }
+  keys[q] = key;
+  idx[q] = (unsigned)q;
+}
+__global__ __launch_bounds__(256) void k_depth_sdf_bvh(const double* __restrict__ px, const double* __restrict__ py,
+                                                       const double* __restrict__ pz, const double* __restrict__ boxes, int P,
+                                                       const unsigned* __restrict__ order,
+                                                       const float* __restrict__ depth, int H, int W,
+                                                       const double* __restrict__ K, const double* __restrict__ cam_inv,
+                                                       const double* __restrict__ query, long nq, float epsilon, float w_inside,
+                                                       float* __restrict__ sdf_out, uint8_t* __restrict__ inside_out,
+                                                       float* __restrict__ cost_out, unsigned long long* __restrict__ stats) {
+#pragma clang fp contract(off)
+  // PACKET traversal: the 64 queries of a wave (neighbours in space, see k_query_keys) walk the tree TOGETHER with one
+  // stack; a node is entered when any lane still needs it, and the 32 points of a leaf are fetched once per wave and
+  // tried by every lane.  Trying more points than a lane needs cannot change its minimum (they are points of the cloud),
+  // so the result is the exhaustive search's; what changes is that a leaf costs one coalesced read per wave instead of
+  // one scattered read per lane (per-lane traversal moved 18 KB per query through the caches).
+  __shared__ int s_stack[4][64];
+  __shared__ double s_pts[4][3][GTO_BVH_TILE_W * GTO_BVH_TILE_H];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const long slot = (long)blockIdx.x * 256 + tid;
+  const bool live = slot < nq;
+  const long q = live ? (long)order[slot] : 0;  // the slot-th query in Morton order
+  const double q0 = live ? query[3 * q] : 0.0, q1 = live ? query[3 * q + 1] : 0.0, q2 = live ? query[3 * q + 2] : 0.0;
+  double best = INFINITY;
+  const int first_leaf = P * P - 1;
+  int* stk = s_stack[wave];
+  int sp = 0;  // wave-uniform
+  unsigned n_pop = 0, n_leaf = 0;
+  if (lane == 0) stk[0] = 0;
+  sp = 1;
+  wave_sync_lds();
+  while (sp > 0) {
+    const int n = __builtin_amdgcn_readfirstlane(stk[sp - 1]);
+    --sp;
+    ++n_pop;
+    const bool need = live && bvh_box_d2(boxes + (size_t)n * 6, q0, q1, q2) < best;
+    if (!__any(need)) continue;  // too far for every lane (it may have become so since it was pushed)
+    if (n >= first_leaf) {
+      ++n_leaf;
+      const int s = n - first_leaf;
+      const int cx = (int)bvh_compact1by1((unsigned)s), cy = (int)bvh_compact1by1((unsigned)s >> 1);
+      if (lane < GTO_BVH_TILE_W * GTO_BVH_TILE_H) {  // one pixel per lane; pixels outside the image count as invalid
+        const int y = cy * GTO_BVH_TILE_H + lane / GTO_BVH_TILE_W, x = cx * GTO_BVH_TILE_W + lane % GTO_BVH_TILE_W;
+        const bool in = y < H && x < W;
+        const size_t j = in ? (size_t)y * W + x : 0;
+        s_pts[wave][0][lane] = in ? px[j] : INFINITY;
+        s_pts[wave][1][lane] = in ? py[j] : INFINITY;
+        s_pts[wave][2][lane] = in ? pz[j] : INFINITY;
+      }
+      wave_sync_lds();
+#pragma unroll 8
+      for (int k = 0; k < GTO_BVH_TILE_W * GTO_BVH_TILE_H; ++k) {
+        const double dx = q0 - s_pts[wave][0][k], dy = q1 - s_pts[wave][1][k], dz = q2 - s_pts[wave][2][k];
+        const double d2 = (dx * dx + dy * dy) + dz * dz;
+        best = fmin(best, d2);  // invalid pixels are points at infinity: d2 = inf
+      }
+      wave_sync_lds();  // every lane is done with the tile before the next leaf overwrites it
+    } else {
+      const int c1 = 2 * n + 1, c2 = c1 + 1;
+      const double d1 = bvh_box_d2(boxes + (size_t)c1 * 6, q0, q1, q2), d2 = bvh_box_d2(boxes + (size_t)c2 * 6, q0, q1, q2);
+      const bool n1 = live && d1 < best, n2 = live && d2 < best;
+      // the child more lanes are closer to is entered first (it is pushed last)
+      const bool c1_first = __popcll(__ballot(live && d1 <= d2)) * 2 >= __popcll(__ballot(live));
+      const bool any1 = __any(n1), any2 = __any(n2);
+      const int firstc = c1_first ? c1 : c2, secondc = c1_first ? c2 : c1;
+      const bool any_first = c1_first ? any1 : any2, any_second = c1_first ? any2 : any1;
+      if (any_second) {
+        if (lane == 0) stk[sp] = secondc;
+        ++sp;
+      }
+      if (any_first) {
+        if (lane == 0) stk[sp] = firstc;
+        ++sp;
+      }
+      wave_sync_lds();
+    }
+  }
+  if (stats) {
+    if (lane == 0) {
+      atomicAdd(stats, (unsigned long long)n_pop * 64);
+      atomicAdd(stats + 1, (unsigned long long)n_leaf * 64);
+      atomicAdd(stats + 2, (unsigned long long)n_pop);
+    }
+  }
+  depth_sdf_finish(live, q, q0, q1, q2, best, depth, H, W, K, cam_inv, epsilon, w_inside, sdf_out, inside_out, cost_out);
 }

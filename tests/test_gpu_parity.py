@@ -569,6 +569,42 @@ def test_depth_cost_field_matches_reference_golden_and_oracle(capi, oracle_mod):
     assert dpc.get_sdf(np.zeros((0, 3))).shape == (0,)
 
 
+@pytest.mark.parametrize("scene", ["noise", "surfaces"])
+def test_depth_cost_field_tree_search_equals_exhaustive_search(capi, monkeypatch, scene):
+    """The nearest-neighbour search of gto_depth_sdf_cost walks a bounding-box hierarchy over tiles of the depth image
+    (k_depth_sdf_bvh); GTO_DEPTH_BRUTE=1 keeps the exhaustive search (k_depth_sdf, the reference construction).  Signed
+    distances, inside flags and costs must be the same bits: every voxel centre of a grid around the cloud, a ragged
+    image (sizes that are no multiple of the tile), invalid pixels and a masked target."""
+    import grasptrajopt_amd as g_
+    rng = np.random.default_rng(11)
+    H, W = 123, 181
+    K = np.array([[160.0, 0.0, 90.3], [0, 161.0, 61.1], [0, 0, 1.0]])
+    if scene == "noise":
+        depth = (0.6 + 0.5 * rng.random((H, W))).astype(np.float32)
+    else:  # a floor plane seen at an angle with two boxes on it: what a depth camera sees
+        v, u = np.mgrid[0:H, 0:W]
+        depth = (0.9 + 0.002 * (v - H / 2) + 0.0005 * (u - W / 2)).astype(np.float32)
+        depth[40:70, 50:90] -= 0.15
+        depth[75:100, 110:150] -= 0.07
+    depth[rng.random((H, W)) < 0.07] = 0.0
+    mask = np.zeros((H, W), np.uint8)
+    mask[45:60, 55:80] = 1
+    a = 0.4
+    cam = np.eye(4)
+    cam[:3, :3] = np.array([[0, -np.sin(a), np.cos(a)], [-1.0, 0, 0], [0, -np.cos(a), -np.sin(a)]])
+    cam[:3, 3] = [-0.3, 0.05, 0.8]
+    ax = np.linspace(-0.6, 1.6, 40)
+    q = np.stack(np.meshgrid(ax, ax - 0.5, ax - 0.4, indexing="ij"), -1).reshape(-1, 3)
+    out = []
+    for brute in ("0", "1"):
+        monkeypatch.setenv("GTO_DEPTH_BRUTE", brute)
+        dpc = g_.DepthPointCloud(depth, K, cam, target_mask=mask, threshold=1.4)
+        out.append((dpc.get_sdf(q), ~dpc.is_outside(q), dpc.get_sdf_cost(q, epsilon=0.05, w_inside=1.5)))
+    for x, y in zip(*out):
+        np.testing.assert_array_equal(x, y)
+    assert out[0][1].any() and (out[0][2] > 0).any()
+
+
 # ------------------------------------------------------------------------------------------ assembled objectives
 # tests/golden/objective.npz holds what the reference's OWN setup_optimization code computes (executed with numeric
 # stand-ins for CasADi, tests/golden/make_objective_golden.py): these tests tie the HIP path to the reference

@@ -14,7 +14,15 @@ import grasptrajopt_amd as g  # noqa: E402
 rng = np.random.default_rng(0)
 H, W = 480, 640
 K = np.array([[600.0, 0, 320.0], [0, 600.0, 240.0], [0, 0, 1.0]])
-depth = (0.8 + 0.4 * rng.random((H, W))).astype(np.float32)
+noise = len(sys.argv) > 1 and sys.argv[1] == "noise"
+if noise:  # every pixel at a random depth: the worst case for the bounding boxes of the image tiles
+    depth = (0.8 + 0.4 * rng.random((H, W))).astype(np.float32)
+else:  # a floor seen at an angle with a few boxes on it, one millimetre of sensor noise
+    v, u = np.mgrid[0:H, 0:W]
+    depth = (1.0 + 0.0012 * (v - H / 2) + 0.0003 * (u - W / 2)).astype(np.float32)
+    for (r0, r1, c0, c1, dz) in ((150, 260, 200, 330, 0.2), (280, 400, 380, 520, 0.1), (100, 180, 420, 480, 0.3)):
+        depth[r0:r1, c0:c1] -= dz
+    depth += (0.001 * rng.standard_normal((H, W))).astype(np.float32)
 a = 0.5
 cam = np.eye(4)
 cam[:3, :3] = np.array([[0, -np.sin(a), np.cos(a)], [-1.0, 0, 0], [0, -np.cos(a), -np.sin(a)]])
