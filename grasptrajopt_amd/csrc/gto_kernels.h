@@ -3180,6 +3180,7 @@ __global__ __launch_bounds__(256) void k_depth_sdf_bvh(const double* __restrict_
   // so the result is the exhaustive search's; what changes is that a leaf costs one coalesced read per wave instead of
   // one scattered read per lane (per-lane traversal moved 18 KB per query through the caches).
   __shared__ int s_stack[4][64];
+  __shared__ double s_sbox[4][64][6];  // the box of every stacked node (read from memory once, when its parent is entered)
   __shared__ double s_pts[4][3][GTO_BVH_TILE_W * GTO_BVH_TILE_H];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const long slot = (long)blockIdx.x * 256 + tid;
@@ -3192,13 +3193,14 @@ __global__ __launch_bounds__(256) void k_depth_sdf_bvh(const double* __restrict_
   int sp = 0;  // wave-uniform
   unsigned n_pop = 0, n_leaf = 0;
   if (lane == 0) stk[0] = 0;
+  if (lane < 6) s_sbox[wave][0][lane] = boxes[lane];
   sp = 1;
   wave_sync_lds();
   while (sp > 0) {
     const int n = __builtin_amdgcn_readfirstlane(stk[sp - 1]);
     --sp;
     ++n_pop;
-    const bool need = live && bvh_box_d2(boxes + (size_t)n * 6, q0, q1, q2) < best;
+    const bool need = live && bvh_box_d2(s_sbox[wave][sp], q0, q1, q2) < best;
     if (!__any(need)) continue;  // too far for every lane (it may have become so since it was pushed)
     if (n >= first_leaf) {
       ++n_leaf;
@@ -3222,6 +3224,7 @@ __global__ __launch_bounds__(256) void k_depth_sdf_bvh(const double* __restrict_
       wave_sync_lds();  // every lane is done with the tile before the next leaf overwrites it
     } else {
       const int c1 = 2 * n + 1, c2 = c1 + 1;
+      const double bx = lane < 12 ? boxes[(size_t)c1 * 6 + lane] : 0.0;  // both children's boxes: twelve consecutive doubles
       const double d1 = bvh_box_d2(boxes + (size_t)c1 * 6, q0, q1, q2), d2 = bvh_box_d2(boxes + (size_t)c2 * 6, q0, q1, q2);
       const bool n1 = live && d1 < best, n2 = live && d2 < best;
       // the child more lanes are closer to is entered first (it is pushed last)
@@ -3229,12 +3232,16 @@ __global__ __launch_bounds__(256) void k_depth_sdf_bvh(const double* __restrict_
       const bool any1 = __any(n1), any2 = __any(n2);
       const int firstc = c1_first ? c1 : c2, secondc = c1_first ? c2 : c1;
       const bool any_first = c1_first ? any1 : any2, any_second = c1_first ? any2 : any1;
+      // lane l < 12 holds entry l % 6 of child c1 (l < 6) or c2: it files it under the slot its child gets
+      const bool mine_is_second = (lane < 6) != c1_first;
       if (any_second) {
         if (lane == 0) stk[sp] = secondc;
+        if (lane < 12 && mine_is_second) s_sbox[wave][sp][lane % 6] = bx;
         ++sp;
       }
       if (any_first) {
         if (lane == 0) stk[sp] = firstc;
+        if (lane < 12 && !mine_is_second) s_sbox[wave][sp][lane % 6] = bx;
         ++sp;
       }
       wave_sync_lds();
