@@ -3,7 +3,8 @@
 The reference back-projects a depth image, builds a scikit-learn KD-tree over the points and queries it
 at every voxel centre to produce ``sdf_cost_all`` / ``sdf_cost_obstacle`` (seconds per scene,
 examples/pybullet_gto_planning.py:180-190).  Here the back-projection, the exact nearest-neighbour
-distance (exhaustive search in FP64 on the MI355X), the visibility test ``is_outside`` and the cost map
+distance (FP64 on the MI355X: a bounding-box hierarchy over tiles of the depth image walked by packets of 64
+neighbouring queries; same bits as an exhaustive search), the visibility test ``is_outside`` and the cost map
 run in ``gto_depth_sdf_cost``; the values are bit-identical to the reference (tests/golden/depth_cost.npz).
 """
 from __future__ import annotations
