@@ -69,6 +69,9 @@ struct gto_handle {
   int obs_tg = 3;  // waypoints per workgroup of the obstacle kernel: they share the table staging, the FK barriers and the launch overhead
   long long* dbg = nullptr;
   // staging for the host-pointer entry points
+  // buffers of the scene that the last gto_set_scene replaced: the next replacement of the same size takes them instead of
+  // going through hipMalloc / hipFree (fourteen calls of 0.2-0.3 ms each: most of a small scene's upload time)
+  std::vector<std::pair<void*, size_t>> spare;
   DevBuf in[8], out[8];
   // pinned twins of the staging buffers: host arrays are copied through them, so that the transfers are real DMA at a
   // steady rate (a hipMemcpyAsync from pageable memory stages inside the runtime: 1-6 ms of jitter per call with four
@@ -502,6 +505,7 @@ void gto_destroy(gto_handle* h) {
   for (int p = 0; p < 2; ++p)
     if (h->ev_chk[p]) (void)hipEventDestroy(h->ev_chk[p]);
   for (DevBuf* b : bufs) (void)hipFree(b->p);
+  for (auto& sp_ : h->spare) (void)hipFree(sp_.first);
   for (auto& b : h->in) (void)hipFree(b.p);
   for (auto& b : h->out) (void)hipFree(b.p);
   for (auto& b : h->pin_in) if (b.p) (void)hipHostFree(b.p);
@@ -591,6 +595,13 @@ static int set_scene_impl(gto_handle* h, int32_t id, const float* c_all, const f
     if (e_ != hipSuccess) return fail_free(e_, #call); \
   } while (0)
   auto dalloc = [&](void** p, size_t bytes) {
+    for (size_t k = 0; k < h->spare.size(); ++k)
+      if (h->spare[k].second == bytes) {  // a buffer of the scene replaced last time
+        *p = h->spare[k].first;
+        h->spare.erase(h->spare.begin() + k);
+        owned.push_back(*p);
+        return hipSuccess;
+      }
     hipError_t e = hipMalloc(p, bytes);
     if (e == hipSuccess) owned.push_back(*p);
     return e;
@@ -643,7 +654,6 @@ static int set_scene_impl(gto_handle* h, int32_t id, const float* c_all, const f
   }
   SCN(hipStreamSynchronize(h->stream));
   SCN(hipGetLastError());
-  if (scratch) (void)hipFree(scratch);
 #undef SCN
   if ((size_t)id >= h->scenes.size()) {
     SceneDev z;
@@ -651,6 +661,23 @@ static int set_scene_impl(gto_handle* h, int32_t id, const float* c_all, const f
     h->scenes.resize(id + 1, z);
   }
   SceneDev& s = h->scenes[id];
+  // what is left of the previous spares did not fit this scene: free it; the replaced scene's buffers become the spares
+  for (auto& sp_ : h->spare) (void)hipFree(sp_.first);
+  h->spare.clear();
+  if (scratch) h->spare.emplace_back((void*)scratch, nvox);
+  if (s.valid == 1) {
+    const size_t ov = (size_t)s.nx * s.ny * s.nz;
+    auto keep = [&](const void* p_, size_t bytes) {
+      if (p_) h->spare.emplace_back(const_cast<void*>(p_), bytes);
+    };
+    if (s.c_obs != s.c_all) keep(s.c_obs, ov * sizeof(float));
+    keep(s.c_all, ov * sizeof(float));
+    if (s.r_obs != s.r_all) keep(s.r_obs, ov * sizeof(VoxelRec));
+    keep(s.r_all, ov * sizeof(VoxelRec));
+    if (s.d_obs != s.d_all) keep(s.d_obs, ov);
+    keep(s.d_all, ov);
+    s.valid = 0;
+  }
   int rcf = free_scene(h, s);
   if (rcf) return rcf;
   s.c_all = da;
@@ -1521,6 +1548,46 @@ int gto_plan_cost(gto_handle* h, int32_t scene_id, int32_t n, const double* plan
 
 
 // ------------------------------------------------------------------ cost field from a depth image (row f-2)
+// Device buffers of gto_depth_sdf_cost are kept between calls (the entry point has no handle to hang them on): a call
+// allocates a dozen buffers, and hipMalloc / hipFree cost more than the kernels for the reference's 5 cm grids.  A buffer is
+// reused for a request of at most half its size up to its size; at most 1 GiB stays cached per process.
+namespace {
+struct DepthPool {
+  struct Item { int device; void* p; size_t cap; };
+  std::mutex mu;
+  std::vector<Item> items;
+  size_t cached = 0;
+  void* take(int device, size_t bytes, size_t* cap_out) {
+    {
+      std::lock_guard<std::mutex> lock(mu);
+      for (size_t k = 0; k < items.size(); ++k)
+        if (items[k].device == device && items[k].cap >= bytes && items[k].cap <= 2 * bytes + 4096) {
+          void* p = items[k].p;
+          *cap_out = items[k].cap;
+          cached -= items[k].cap;
+          items.erase(items.begin() + k);
+          return p;
+        }
+    }
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+    *cap_out = bytes;
+    return p;
+  }
+  void give(int device, void* p, size_t cap) {
+    std::lock_guard<std::mutex> lock(mu);
+    items.push_back({device, p, cap});
+    cached += cap;
+    while (cached > ((size_t)1 << 30) && !items.empty()) {  // oldest first
+      (void)hipFree(items.front().p);
+      cached -= items.front().cap;
+      items.erase(items.begin());
+    }
+  }
+};
+DepthPool g_depth_pool;
+}  // namespace
+
 int gto_depth_sdf_cost(int device, const float* depth, int32_t H, int32_t W, const double* K, const double* Kinv,
                        const double* cam_pose, const double* cam_inv, const uint8_t* target_mask, double threshold,
                        const double* query, int64_t nq, float epsilon, float w_inside, float* sdf_out,
@@ -1531,15 +1598,18 @@ int gto_depth_sdf_cost(int device, const float* depth, int32_t H, int32_t W, con
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(nullptr, GTO_ERR_NO_DEVICE, "no HIP device");
   if (device >= 0 && hipSetDevice(device) != hipSuccess) return fail(nullptr, GTO_ERR_NO_DEVICE, "hipSetDevice failed");
   const size_t N = (size_t)H * W;
-  std::vector<void*> bufs;
+  int cur_dev = 0;
+  (void)hipGetDevice(&cur_dev);
+  std::vector<std::pair<void*, size_t>> bufs;
   auto dalloc = [&](size_t bytes) -> void* {
-    void* p = nullptr;
-    if (hipMalloc(&p, bytes ? bytes : 8) != hipSuccess) return nullptr;
-    bufs.push_back(p);
+    size_t cap = 0;
+    void* p = g_depth_pool.take(cur_dev, bytes ? bytes : 8, &cap);
+    if (p) bufs.emplace_back(p, cap);
     return p;
   };
   auto cleanup = [&]() {
-    for (void* p : bufs) (void)hipFree(p);
+    (void)hipDeviceSynchronize();  // nothing of this call may still be using them when the next call takes them
+    for (auto& b : bufs) g_depth_pool.give(cur_dev, b.first, b.second);
   };
 #define DCHK(expr)                                                                                     \
   do {                                                                                                 \
