@@ -914,16 +914,22 @@ static int launch_traj(gto_handle* h, hipStream_t st, TrajArgs a, const SolvePar
   a.blocks = (double*)h->trajws.p;
   a.counters = (unsigned long long*)h->counters.p;
   a.dbg = h->dbg;
-  const int nw = a.B <= h->traj_few ? h->traj_nw_few : h->traj_nw;
-  const size_t budget = (nw == 16 ? 156 : (nw == 8 ? 78 : 38)) * 1024;  // 1, 2, 4 workgroups per CU
-  int G = h->traj_g;
-  if (G <= 0) {
-    G = 2;
-    for (int g = 3; g >= 2; --g)  // three waypoints per task: 16 tasks for T = 50, two rounds of eight waves
-      if ((size_t)TrajLds(sp.T, rb.n_frames, rb.n_links, rb.n_chunks, rb.n_opt, rb.n_xst, g, nw).total * sizeof(double) <= budget) { G = g; break; }
+  // wavefronts per workgroup: as configured, halved while the layout of a robot with many frames / links does not fit
+  int nw = a.B <= h->traj_few ? h->traj_nw_few : h->traj_nw;
+  int G = 2;
+  size_t lds = 0;
+  for (;; nw >>= 1) {
+    const size_t budget = (nw == 16 ? 156 : (nw == 8 ? 78 : 38)) * 1024;  // 1, 2, 4 workgroups per CU
+    G = h->traj_g;
+    if (G <= 0) {
+      G = 2;
+      for (int g = 3; g >= 2; --g)  // three waypoints per task: 16 tasks for T = 50, two rounds of eight waves
+        if ((size_t)TrajLds(sp.T, rb.n_frames, rb.n_links, rb.n_chunks, rb.n_opt, rb.n_xst, g, nw).total * sizeof(double) <= budget) { G = g; break; }
+    }
+    lds = (size_t)TrajLds(sp.T, rb.n_frames, rb.n_links, rb.n_chunks, rb.n_opt, rb.n_xst, G, nw).total * sizeof(double);
+    if (lds <= 160 * 1024 || nw == 4) break;
   }
   a.G = G;
-  const size_t lds = (size_t)TrajLds(sp.T, rb.n_frames, rb.n_links, rb.n_chunks, rb.n_opt, rb.n_xst, G, nw).total * sizeof(double);
   if (lds > 160 * 1024) return fail(h, GTO_ERR_UNSUPPORTED, "robot / T too large for the solve kernel's LDS");
   HIPCHK(h, hipMemsetAsync(a.counters, 0, 16 * sizeof(unsigned long long), st));
   hipEvent_t e0 = nullptr, e1 = nullptr;

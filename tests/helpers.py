@@ -67,3 +67,57 @@ def point_cloud_robot(points):
         link_names=["root"], link_frame=np.array([0], dtype=np.int32), visual_xyz=np.zeros((1, 3)),
         visual_rpy=np.zeros((1, 3)), points=np.asarray(points, dtype=np.float64), normals=np.zeros((P, 3)),
         point_link=np.zeros(P, dtype=np.int32))
+
+
+def random_robot(seed, n_frames=None, n_opt=None):
+    """A random kinematic tree with surface points: branching, revolute / prismatic / fixed joints in any order, random
+    origins and axes, optimised joints along one chain (the one that carries the end effector) and parameter joints on
+    side branches, collision links on some frames.  Exercises what the built-in arms do not: branching before and after
+    optimised joints, prismatic optimised joints, fixed frames inside the chain, up to 24 frames."""
+    rng = np.random.default_rng(seed)
+    F = int(n_frames or rng.integers(8, 25))
+    n = int(n_opt or rng.integers(3, 9))
+    chain_len = int(min(F - 1, n + rng.integers(0, 4)))   # frames of the main chain below the root (some fixed)
+    parent = np.full(F, -1, dtype=np.int32)
+    jt = np.zeros(F, dtype=np.int32)
+    chain = list(range(1, chain_len + 1))
+    for k, f in enumerate(chain):
+        parent[f] = f - 1
+    movable = rng.permutation(chain)[:n]
+    for f in movable:
+        jt[f] = 2 if rng.random() < 0.25 else 1
+    side = list(range(chain_len + 1, F))
+    for f in side:                                       # side branches hang anywhere on what exists already
+        parent[f] = int(rng.integers(0, f))
+        jt[f] = int(rng.choice([0, 1, 2], p=[0.4, 0.4, 0.2]))
+    act = [f for f in range(F) if jt[f] != 0]
+    q_index = np.full(F, -1, dtype=np.int32)
+    for k, f in enumerate(act):
+        q_index[f] = k
+    ndof = len(act)
+    opt_index = np.array(sorted(q_index[f] for f in movable), dtype=np.int32)
+    param_index = np.array([k for k in range(ndof) if k not in set(opt_index.tolist())], dtype=np.int32)
+    origin_xyz = rng.uniform(-0.12, 0.12, size=(F, 3))
+    origin_xyz[chain, 2] = rng.uniform(0.08, 0.22, size=len(chain))   # the chain reaches outward
+    origin_rpy = rng.uniform(-1.5, 1.5, size=(F, 3))
+    origin_xyz[0] = origin_rpy[0] = 0.0
+    axis = rng.standard_normal((F, 3))
+    axis /= np.linalg.norm(axis, axis=1, keepdims=True)
+    lower = np.where([jt[f] == 2 for f in act], -0.15, -2.2) * rng.uniform(0.6, 1.0, ndof)
+    upper = np.where([jt[f] == 2 for f in act], 0.15, 2.2) * rng.uniform(0.6, 1.0, ndof)
+    link_frames = sorted(set([0, chain[-1]] + [int(f) for f in rng.choice(np.arange(1, F), size=min(F - 1, int(rng.integers(3, 9))), replace=False)]))
+    L = len(link_frames)
+    pts, plink = [], []
+    for l in range(L):
+        m = int(rng.integers(40, 160))
+        c = rng.uniform(-0.03, 0.03, 3)
+        pts.append(c + rng.standard_normal((m, 3)) * rng.uniform(0.015, 0.05, 3))
+        plink.append(np.full(m, l, dtype=np.int32))
+    names = [f"f{i}" for i in range(F)]
+    return RobotDesc(
+        name=f"random{seed}", frame_names=names, parent=parent, joint_type=jt, q_index=q_index, origin_xyz=origin_xyz,
+        origin_rpy=origin_rpy, axis=axis, actuated_joint_names=[f"j{k}" for k in range(ndof)], lower=lower, upper=upper,
+        opt_index=opt_index, param_index=param_index, link_names=[names[f] for f in link_frames],
+        link_frame=np.array(link_frames, dtype=np.int32), visual_xyz=rng.uniform(-0.02, 0.02, (L, 3)),
+        visual_rpy=rng.uniform(-0.5, 0.5, (L, 3)), points=np.concatenate(pts), normals=np.zeros((sum(len(p) for p in pts), 3)),
+        point_link=np.concatenate(plink)), names[chain[-1]]

@@ -12,6 +12,7 @@ import numpy as np
 import pytest
 
 from conftest import golden
+from grasptrajopt_amd import synthetic as syn
 from helpers import Problem, cfg_of, point_cloud_robot
 
 pytestmark = pytest.mark.gpu
@@ -368,6 +369,63 @@ def test_hip_obstacle_blocks_against_finite_difference_jacobians(capi, oracle_mo
     h.set_scene(*prob.scene_args())
     nz = sum(check_obstacle_blocks_against_fd(h, prob.desc, T, T - 4, prob.Q0[b], prob.base[b]) for b in range(prob.B))
     assert nz >= 4
+    h.close()
+
+
+@pytest.mark.parametrize("seed", list(range(24)))
+def test_random_robots_match_oracle(capi, oracle_mod, seed):
+    """Random kinematic trees (tests/helpers.random_robot: branching, prismatic and fixed joints anywhere, 3-8 optimised
+    joints, side branches with parameter joints, up to 24 frames): forward kinematics of every frame, objective terms,
+    obstacle normal equations and the solve itself, HIP against the oracle."""
+    from helpers import random_robot
+    desc, ee = random_robot(seed)
+    T, B = 20, 6
+    opts = oracle_mod.reference_opts(T=T, standoff_offset=-4, max_iter=25)
+    h = capi.SolverHandle(desc, ee, ee, opts, device=0, n_gripper_points=40)
+    o = oracle_mod.Oracle(desc, ee, ee, opts, n_gripper_points=40)
+    rng = np.random.default_rng(100 + seed)
+    lo, hi = desc.lower, desc.upper
+    q = rng.uniform(lo, hi, size=(16, desc.ndof))
+    np.testing.assert_allclose(h.eval_fk(q), o.eval_fk(q), rtol=0, atol=1e-12)
+    # a field around the robot: a dense random band so that every link meets cost and gradient somewhere
+    n, res = 40, 0.05
+    origin = (-1.0, -1.0, -1.0)
+    c_all = (0.03 * rng.random(n ** 3) * (rng.random(n ** 3) < 0.3)).astype(np.float32)
+    c_obs = (0.03 * rng.random(n ** 3) * (rng.random(n ** 3) < 0.2)).astype(np.float32)
+    for x in (h, o):
+        x.set_scene(0, c_all, c_obs, (n, n, n), origin, res)
+    qc = rng.uniform(0.3 * lo, 0.3 * hi, size=(B, desc.ndof))
+    qg = rng.uniform(0.8 * lo, 0.8 * hi, size=(B, desc.ndof))
+    qg[:, desc.param_index] = qc[:, desc.param_index]
+    fe = desc.frame_index(ee)
+    goals = o.eval_fk(qg)[:, fe].reshape(B, 1, 16)
+    S = syn.standoff_pose(-0.05, "z")
+    base = np.zeros((B, 3))
+    Q0 = np.stack([syn.make_seed(qc[b], qg[b], T, desc.param_index) for b in range(B)])
+    a = h.eval_objective(0, goals, 1, S, base, Q0)
+    b_ = o.eval_objective(0, goals, 1, S, base, Q0)
+    for x, y in zip(a[:3], b_[:3]):
+        np.testing.assert_allclose(x, y, rtol=1e-9, atol=1e-13)
+    A, g, ss = h.eval_obstacle_normal_eq(0, base, Q0)
+    Ao, go, sso = o.eval_obstacle_normal_eq(0, base, Q0)
+    np.testing.assert_allclose(A[:, 2:], Ao[:, 2:], rtol=1e-8, atol=1e-10 * max(np.abs(Ao).max(), 1e-30))
+    np.testing.assert_allclose(g[:, 2:], go[:, 2:], rtol=1e-8, atol=1e-10 * max(np.abs(go).max(), 1e-30))
+    np.testing.assert_allclose(ss, sso, rtol=1e-11, atol=1e-15)
+    for mode in (0, 1):
+        h.set_mode(mode)
+        Qg, _, fg, itg, stg = h.solve_batch(0, qc, goals, 1, S, base, Q0)
+        Qo, _, fo, ito, sto = o.solve_batch(0, qc, goals, 1, S, base, Q0)
+        np.testing.assert_array_equal(itg, ito)
+        np.testing.assert_array_equal(stg, sto)
+        np.testing.assert_allclose(Qg, Qo, rtol=0, atol=1e-6)
+        np.testing.assert_allclose(fg, fo, rtol=1e-8)
+    # inverse kinematics of the same goals (whole LM loop in one workgroup), without and with the collision term
+    for sid in (None, 0):
+        qi, fi, iti, sti = h.solve_ik_batch(sid, qc, goals[:, 0], base, max_iter=40)
+        qo2, fo2, ito2, sto2 = o.solve_ik_batch(sid, qc, goals[:, 0], base, max_iter=40)
+        np.testing.assert_array_equal(iti, ito2)
+        np.testing.assert_array_equal(sti, sto2)
+        np.testing.assert_allclose(qi, qo2, rtol=0, atol=1e-6)
     h.close()
 
 
