@@ -429,6 +429,43 @@ def test_random_robots_match_oracle(capi, oracle_mod, seed):
     h.close()
 
 
+@pytest.mark.parametrize("seed,n_opt", [(50, 9), (51, 11), (52, 12), (53, 14), (54, 16), (55, 10)])
+def test_random_wide_robots_match_oracle(capi, oracle_mod, seed, n_opt):
+    """Nine to sixteen optimised joints on random trees (16-wide blocks, k_lm_step_wide): the solve against the oracle."""
+    from helpers import random_robot
+    desc, ee = random_robot(seed, n_frames=max(n_opt + 4, 14), n_opt=n_opt)
+    assert desc.n_opt == n_opt
+    T, B = 16, 4
+    opts = oracle_mod.reference_opts(T=T, standoff_offset=-3, max_iter=20)
+    h = capi.SolverHandle(desc, ee, ee, opts, device=0, n_gripper_points=40)
+    o = oracle_mod.Oracle(desc, ee, ee, opts, n_gripper_points=40)
+    rng = np.random.default_rng(200 + seed)
+    lo, hi = desc.lower, desc.upper
+    n, res = 40, 0.06
+    c_all = (0.03 * rng.random(n ** 3) * (rng.random(n ** 3) < 0.3)).astype(np.float32)
+    c_obs = (0.03 * rng.random(n ** 3) * (rng.random(n ** 3) < 0.2)).astype(np.float32)
+    for x in (h, o):
+        x.set_scene(0, c_all, c_obs, (n, n, n), (-1.2, -1.2, -1.2), res)
+    qc = rng.uniform(0.3 * lo, 0.3 * hi, size=(B, desc.ndof))
+    qg = rng.uniform(0.8 * lo, 0.8 * hi, size=(B, desc.ndof))
+    qg[:, desc.param_index] = qc[:, desc.param_index]
+    goals = o.eval_fk(qg)[:, desc.frame_index(ee)].reshape(B, 1, 16)
+    S = syn.standoff_pose(-0.05, "z")
+    base = np.zeros((B, 3))
+    Q0 = np.stack([syn.make_seed(qc[b], qg[b], T, desc.param_index) for b in range(B)])
+    a = h.eval_objective(0, goals, 1, S, base, Q0)
+    b_ = o.eval_objective(0, goals, 1, S, base, Q0)
+    for x, y in zip(a[:3], b_[:3]):
+        np.testing.assert_allclose(x, y, rtol=1e-9, atol=1e-13)
+    Qg, _, fg, itg, stg = h.solve_batch(0, qc, goals, 1, S, base, Q0)
+    Qo, _, fo, ito, sto = o.solve_batch(0, qc, goals, 1, S, base, Q0)
+    np.testing.assert_array_equal(itg, ito)
+    np.testing.assert_array_equal(stg, sto)
+    np.testing.assert_allclose(Qg, Qo, rtol=0, atol=1e-6)
+    np.testing.assert_allclose(fg, fo, rtol=1e-8)
+    h.close()
+
+
 def test_full_size_properties(capi, oracle_mod):
     """BASELINE.json configs[1] sizes (Panda, ~5k surface points, 128^3 field, 64 goals, T=50):
     too slow for the scalar oracle end-to-end, so checked through size-independent properties."""
