@@ -466,6 +466,63 @@ def test_random_wide_robots_match_oracle(capi, oracle_mod, seed, n_opt):
     h.close()
 
 
+@pytest.mark.parametrize("seed", list(range(60, 70)))
+def test_random_edge_cases_match_oracle(capi, oracle_mod, seed):
+    """Edge cases the benchmark workloads never meet, on random trees: links with 1, 64, 65 or several hundred surface
+    points (chunk boundaries), tiny and anisotropic grids, most of the robot outside the grid (clipped voxel indices),
+    a base offset, ragged goal sets of up to nine goals, standoff on and off, short horizons."""
+    from helpers import random_robot
+    rng = np.random.default_rng(300 + seed)
+    desc, ee = random_robot(seed)
+    counts = rng.choice([1, 2, 63, 64, 65, 128, 129, 300], size=desc.n_links)
+    pts, plink = [], []
+    for l, m in enumerate(counts):
+        pts.append(rng.uniform(-0.04, 0.04, 3) + rng.standard_normal((m, 3)) * 0.03)
+        plink.append(np.full(m, l, dtype=np.int32))
+    desc.points, desc.point_link = np.concatenate(pts), np.concatenate(plink)
+    desc.normals = np.zeros_like(desc.points)
+    T = int(rng.choice([4, 5, 9, 20]))
+    off = -int(rng.integers(1, max(2, T - 2)))
+    use_so = bool(rng.integers(0, 2))
+    B, n_max = 5, 9
+    opts = oracle_mod.reference_opts(T=T, standoff_offset=off, max_iter=15, grad_mode=int(rng.integers(0, 2)))
+    h = capi.SolverHandle(desc, ee, ee, opts, device=0, n_gripper_points=30)
+    o = oracle_mod.Oracle(desc, ee, ee, opts, n_gripper_points=30)
+    shape = tuple(int(v) for v in rng.choice([2, 3, 5, 8, 17, 33], size=3))
+    res = float(rng.choice([0.02, 0.07, 0.3]))
+    origin = tuple(rng.uniform(-0.6, 0.1, 3))
+    nv = int(np.prod(shape))
+    c_all = (0.05 * rng.random(nv) * (rng.random(nv) < 0.6)).astype(np.float32)
+    c_obs = (0.05 * rng.random(nv) * (rng.random(nv) < 0.4)).astype(np.float32)
+    for x in (h, o):
+        x.set_scene(0, c_all, c_obs, shape, origin, res)
+    lo, hi = desc.lower, desc.upper
+    qc = rng.uniform(0.3 * lo, 0.3 * hi, size=(B, desc.ndof))
+    n_goals = rng.integers(1, n_max + 1, size=B).astype(np.int32)
+    qg = rng.uniform(0.8 * lo, 0.8 * hi, size=(B, n_max, desc.ndof))
+    goals = o.eval_fk(qg.reshape(-1, desc.ndof))[:, desc.frame_index(ee)].reshape(B, n_max, 16)
+    S = syn.standoff_pose(-0.05, "z") if use_so else None
+    base = rng.uniform(-0.2, 0.2, size=(B, 3))
+    Q0 = np.stack([syn.make_seed(qc[b], np.where(np.isin(np.arange(desc.ndof), desc.param_index), qc[b], qg[b, 0]), T, desc.param_index) for b in range(B)])
+    a = h.eval_objective(0, goals, n_goals, S, base, Q0)
+    b_ = o.eval_objective(0, goals, n_goals, S, base, Q0)
+    for x, y in zip(a[:3], b_[:3]):
+        np.testing.assert_allclose(x, y, rtol=1e-9, atol=1e-13)
+    np.testing.assert_array_equal(a[3], b_[3])
+    xyz, offs, val, grad = h.eval_points(0, qc, base, use_obs=True)
+    xo, oo, vo, go = o.eval_points(0, qc, base, use_obs=True)
+    np.testing.assert_array_equal(offs, oo)          # clipped voxel indices, bit for bit
+    np.testing.assert_array_equal(val, vo)
+    for mode in (0, 1):
+        h.set_mode(mode)
+        Qg, _, fg, itg, stg = h.solve_batch(0, qc, goals, n_goals, S, base, Q0)
+        Qo, _, fo, ito, sto = o.solve_batch(0, qc, goals, n_goals, S, base, Q0)
+        np.testing.assert_array_equal(itg, ito)
+        np.testing.assert_array_equal(stg, sto)
+        np.testing.assert_allclose(Qg, Qo, rtol=0, atol=1e-6)
+    h.close()
+
+
 def test_full_size_properties(capi, oracle_mod):
     """BASELINE.json configs[1] sizes (Panda, ~5k surface points, 128^3 field, 64 goals, T=50):
     too slow for the scalar oracle end-to-end, so checked through size-independent properties."""
