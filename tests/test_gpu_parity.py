@@ -523,6 +523,31 @@ def test_random_edge_cases_match_oracle(capi, oracle_mod, seed):
     h.close()
 
 
+@pytest.mark.parametrize("seed", list(range(80, 88)))
+def test_random_robots_base_placement_matches_oracle(capi, oracle_mod, seed):
+    """Base placement (row f-4) on random trees: ragged goal sets, with and without the effort term."""
+    from helpers import random_robot
+    desc, ee = random_robot(seed)
+    rng = np.random.default_rng(400 + seed)
+    h = capi.SolverHandle(desc, ee, ee, oracle_mod.reference_opts(), device=0, n_gripper_points=30)
+    o = oracle_mod.Oracle(desc, ee, ee, oracle_mod.reference_opts(), n_gripper_points=30)
+    B, n_max = 5, 6
+    qc = rng.uniform(0.3 * desc.lower, 0.3 * desc.upper, size=(B, desc.ndof))
+    goals = np.zeros((B, n_max, 4, 4))
+    for b in range(B):
+        gb, _ = syn.make_base_goal_sets(desc, o.eval_fk, ee, qc[b], 1, n_max, seed * 10 + b, spread=0.4, shift=0.2, turn=0.4)
+        goals[b] = gb[0]
+    n_goals = rng.integers(1, n_max + 1, size=B).astype(np.int32)
+    for w, iters in ((0.0, 60), (0.5, 25)):
+        yg, qg, fg, itg, stg = h.solve_base_batch(qc, goals, n_goals, w, max_iter=iters)
+        yo, qo, fo, ito, sto = o.solve_base_batch(qc, goals, n_goals, w, max_iter=iters)
+        np.testing.assert_array_equal(itg, ito)
+        np.testing.assert_array_equal(stg, sto)
+        np.testing.assert_allclose(fg, fo, rtol=1e-7, atol=1e-12)
+        np.testing.assert_allclose(yg, yo, rtol=0, atol=1e-6)
+    h.close()
+
+
 def test_full_size_properties(capi, oracle_mod):
     """BASELINE.json configs[1] sizes (Panda, ~5k surface points, 128^3 field, 64 goals, T=50):
     too slow for the scalar oracle end-to-end, so checked through size-independent properties."""
