@@ -471,7 +471,7 @@ def main():
                                 "same call size (profiles/traffic.json)"}
 
         cpu_baseline = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the CPU baseline is a 1-GPU-run item (rank 0, N = 1)
             from oracle import oracle
             oracle.build()
             o = oracle.Oracle(desc, cfg["link_ee"], cfg["link_gripper"], opts, n_gripper_points=100)
