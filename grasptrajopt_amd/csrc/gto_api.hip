@@ -15,6 +15,8 @@
 #include <utility>
 #include <vector>
 
+#include <sys/prctl.h>
+
 #include "gto_kernels.h"
 #include "gto_traj.h"
 
@@ -42,7 +44,7 @@ struct gto_handle {
   SceneDev* d_scenes = nullptr;
   size_t d_scenes_cap = 0;
   // solve workspace (grown on demand)
-  DevBuf state, Qcur, Qtry, vis, screw, blocks, goalblk, ssfixed, ndone, qf, slotbuf, qfs;
+  DevBuf state, Qcur, Qtry, vis, screw, blocks, goalblk, ssfixed, ndone, qf, livebuf, qfs;
   DevBuf trajws, evterms, evblocks, counters;  // k_traj_solve: block workspace, evaluation outputs, work counters
   int traj_nw = 8;        // wavefronts per workgroup (instance) of k_traj_solve: 4, 8 or 16 (GTO_TRAJ_NW)
   int traj_nw_few = 16;   // ... when a call has few instances (latency matters more than occupancy)
@@ -51,11 +53,19 @@ struct gto_handle {
   int mode = GTO_MODE_ROUNDS;  // gto_set_mode / GTO_MODE: rounds of two launches over slots, or one launch per call (gto_traj.h)
   unsigned long long last_counters[4] = {0, 0, 0, 0};
   int32_t* h_ndone = nullptr;  // pinned
-  unsigned long long* h_progress = nullptr;  // pinned, device-visible: (call tag << 32 | finished) written by the step kernel
+  // pinned, device-visible, written by the first workgroup of every step launch: word 0 = call tag << 32 | instances
+  // finished, word 1 = call tag << 32 | round of that launch.  The host sizes its launches by the first and stays at most
+  // `ahead` rounds in front of the second: no event, no copy, nothing in the stream between the kernels
+  unsigned long long* h_progress = nullptr;
   unsigned long long* d_progress = nullptr;  // its device address
   unsigned progress_tag = 0;
-  int check_every = 4;
-  hipEvent_t ev_chk[2] = {nullptr, nullptr};
+  int ahead = 8;           // GTO_AHEAD: rounds the host may enqueue beyond the last one it has seen running
+  int ahead_few = 8;       // GTO_AHEAD_FEW: ... in launches with few instances in flight (short rounds)
+  // speculation (gto_kernels.h GTO_KSPEC): candidates a step generates after a round without an accepted evaluation, in
+  // launches with few instances in flight (more work, fewer dependent rounds); after an accepted evaluation once at most
+  // `spec_deep` instances are in flight (the GPU is nearly idle then: every candidate is free)
+  int spec_rej = 4, spec_acc = 3, spec_deep = 6, spec_kmax = 1;
+  int spec_few = 16;  // GTO_SPEC_FEW: speculation starts once at most this many instances are in flight: before that the GPU is full and every extra evaluation costs time
   int dbg_cut = 0;
   int dist_relax = 0;  // GTO_DIST_RELAX: build the distance fields by relaxation sweeps instead of the separable passes
   // GTO_OBS_INTERLEAVE: waypoints of an obstacle workgroup nG apart instead of consecutive, so that the waypoints next to
@@ -167,12 +177,6 @@ static hipError_t raise_dynamic_lds(const void* kernel, size_t bytes) {
   return e;
 }
 
-static size_t lm_lds_bytes(int T) {
-  size_t m = (size_t)T - 2;
-  size_t dbl = m * 64 + 4 * m * 8 + 8 * (size_t)T + 16 + 32;
-  return dbl * sizeof(double) + m * 8 * sizeof(int) + 64;
-}
-
 int gto_create(const gto_robot_desc* d, const gto_solver_opts* opts, int device, gto_handle** out) {
   if (!d || !opts || !out) return fail(nullptr, GTO_ERR_INVALID_ARG, "null argument");
   *out = nullptr;
@@ -200,7 +204,12 @@ int gto_create(const gto_robot_desc* d, const gto_solver_opts* opts, int device,
     (void)hipGetDevice(&h->device);
   }
   h->opts = *opts;
-  if (const char* e = getenv("GTO_CHECK_EVERY")) h->check_every = atoi(e);
+  if (const char* e = getenv("GTO_AHEAD")) h->ahead = h->ahead_few = std::max(1, atoi(e));
+  if (const char* e = getenv("GTO_AHEAD_FEW")) h->ahead_few = std::max(1, atoi(e));
+  if (const char* e = getenv("GTO_SPEC_REJ")) h->spec_rej = std::max(1, std::min(GTO_KSPEC, atoi(e)));
+  if (const char* e = getenv("GTO_SPEC_ACC")) h->spec_acc = std::max(1, std::min(GTO_KSPEC, atoi(e)));
+  if (const char* e = getenv("GTO_SPEC_DEEP")) h->spec_deep = std::max(0, atoi(e));
+  if (const char* e = getenv("GTO_SPEC_FEW")) h->spec_few = std::max(0, atoi(e));
   if (const char* e = getenv("GTO_OBS_INTERLEAVE")) h->obs_interleave = std::max(0, std::min(2, atoi(e)));
   if (const char* e = getenv("GTO_DIST_RELAX")) h->dist_relax = atoi(e) ? 1 : 0;
   if (const char* e = getenv("GTO_DEBUG_CUT")) h->dbg_cut = atoi(e);
@@ -456,17 +465,21 @@ int gto_create(const gto_robot_desc* d, const gto_solver_opts* opts, int device,
             up((void**)&h->d_chunks, chunks.data(), chunks.size() * sizeof(Chunk));
   if (!ok) { gto_destroy(h); return fail(nullptr, GTO_ERR_ALLOC, "device allocation failed in gto_create"); }
   h->np = rb.n_opt <= GTO_NB ? GTO_NB : 16;
-  h->lm_lds = h->np == GTO_NB ? lm_lds_bytes(opts->T) : lm_wide_lds_bytes(opts->T, 16);
+  h->lm_lds = h->np == GTO_NB ? lm_lds_bytes(opts->T, 1) : lm_wide_lds_bytes(opts->T, 16);
   if (const char* e = getenv("GTO_DEBUG_STEP_EXTRA_LDS")) h->lm_lds += (size_t)atoi(e);  // occupancy experiments
   if (h->lm_lds > 160 * 1024) { gto_destroy(h); return fail(nullptr, GTO_ERR_UNSUPPORTED, "T too large for the step kernel's LDS"); }
+  // candidates per step the eight-wave step kernel's LDS has room for at this T
+  h->spec_kmax = 1;
+  if (h->np == GTO_NB)
+    while (h->spec_kmax < GTO_KSPEC && lm_lds_bytes(opts->T, h->spec_kmax + 1) <= 160 * 1024 - 256) ++h->spec_kmax;
   {
     const int w = h->np == GTO_NB ? 0 : 1;
     const ObsLds lay(w ? 2 : GTO_MAX_TG, rb.n_frames, rb.n_links, (w ? 2 : GTO_MAX_TG) * rb.n_chunks, h->np);
     const size_t lds = std::min<size_t>((size_t)lay.total_doubles * sizeof(double) + h->dbg_extra_lds, 160 * 1024);
     if ((size_t)lay.total_doubles * sizeof(double) > 150 * 1024) { gto_destroy(h); return fail(nullptr, GTO_ERR_UNSUPPORTED, "robot too large for the obstacle kernel's LDS"); }
     hipError_t e1 = raise_dynamic_lds(w ? (const void*)k_obstacle_gram<16> : (const void*)k_obstacle_gram<GTO_NB>, lds);
-    hipError_t e2 = w ? raise_dynamic_lds((const void*)k_lm_step_wide<16>, h->lm_lds) : raise_dynamic_lds((const void*)k_lm_step<4>, h->lm_lds);
-    if (!w && e2 == hipSuccess) e2 = raise_dynamic_lds((const void*)k_lm_step<8>, h->lm_lds);
+    hipError_t e2 = w ? raise_dynamic_lds((const void*)k_lm_step_wide<16>, h->lm_lds) : raise_dynamic_lds((const void*)k_lm_step<4, 1>, h->lm_lds);
+    if (!w && e2 == hipSuccess) e2 = raise_dynamic_lds((const void*)k_lm_step<8, GTO_KSPEC>, lm_lds_bytes(opts->T, h->spec_kmax));
     if (e1 != hipSuccess || e2 != hipSuccess) {
       gto_destroy(h);
       return fail(nullptr, GTO_ERR_HIP, "hipFuncSetAttribute failed");
@@ -499,11 +512,9 @@ void gto_destroy(gto_handle* h) {
   (void)hipFree(h->d_plink);
   (void)hipFree(h->d_perm);
   (void)hipFree(h->d_chunks);
-  DevBuf* bufs[] = {&h->zws, &h->trajws, &h->evterms, &h->evblocks, &h->counters, &h->state, &h->Qcur, &h->Qtry, &h->vis, &h->screw, &h->blocks, &h->goalblk, &h->ssfixed, &h->ndone, &h->qf, &h->slotbuf, &h->qfs};
+  DevBuf* bufs[] = {&h->zws, &h->trajws, &h->evterms, &h->evblocks, &h->counters, &h->state, &h->Qcur, &h->Qtry, &h->vis, &h->screw, &h->blocks, &h->goalblk, &h->ssfixed, &h->ndone, &h->qf, &h->livebuf, &h->qfs};
   if (h->h_ndone) (void)hipHostFree(h->h_ndone);
   if (h->h_progress) (void)hipHostFree(h->h_progress);
-  for (int p = 0; p < 2; ++p)
-    if (h->ev_chk[p]) (void)hipEventDestroy(h->ev_chk[p]);
   for (DevBuf* b : bufs) (void)hipFree(b->p);
   for (auto& sp_ : h->spare) (void)hipFree(sp_.first);
   for (auto& b : h->in) (void)hipFree(b.p);
@@ -783,6 +794,9 @@ static SolveParams make_params(const gto_handle* h, int n_max, bool use_standoff
   sp.lambda0 = o.lambda0;
   sp.dbg_cut = h->dbg_cut;
   sp.interleave = h->obs_interleave == 1;
+  sp.round = sp.parity = 0;
+  sp.kcap = h->np == GTO_NB ? GTO_KSPEC : 1;  // candidate copies of the workspace (the wide step kernel generates one)
+  sp.k_acc = sp.k_rej = sp.k_eval = 1;
   return sp;
 }
 
@@ -792,24 +806,23 @@ static int ensure_workspace(gto_handle* h, int B) {
   int rc;
   if ((rc = ensure(h, h->state, (size_t)B * sizeof(InstState)))) return rc;
   if ((rc = ensure(h, h->Qcur, (size_t)B * n * T * sizeof(double)))) return rc;
-  if ((rc = ensure(h, h->Qtry, (size_t)B * n * T * sizeof(double)))) return rc;
+  const size_t kcap = h->np == GTO_NB ? GTO_KSPEC : 1;
+  if ((rc = ensure(h, h->Qtry, kcap * B * n * T * sizeof(double)))) return rc;
   const size_t bstride = (size_t)h->np * h->np + h->np + 8;
-  if ((rc = ensure(h, h->blocks, (size_t)2 * B * T * bstride * sizeof(double)))) return rc;
-  if ((rc = ensure(h, h->goalblk, (size_t)2 * B * 2 * bstride * sizeof(double)))) return rc;
+  if ((rc = ensure(h, h->blocks, (kcap + 1) * B * T * bstride * sizeof(double)))) return rc;
+  if ((rc = ensure(h, h->goalblk, (kcap + 1) * B * 2 * bstride * sizeof(double)))) return rc;
   if (h->np != GTO_NB && (rc = ensure(h, h->zws, (size_t)std::min(B, h->slots) * (T - 2) * h->np * h->np * sizeof(double)))) return rc;
   if ((rc = ensure(h, h->ssfixed, (size_t)B * 4 * sizeof(double)))) return rc;
   if ((rc = ensure(h, h->ndone, 64))) return rc;
   if ((rc = ensure(h, h->qf, (size_t)B * T * rb.n_frames * sizeof(double)))) return rc;
-  if ((rc = ensure(h, h->slotbuf, ((size_t)std::min(B, h->slots) + 16) * sizeof(int32_t)))) return rc;
-  if ((rc = ensure(h, h->qfs, (size_t)std::min(B, h->slots) * T * rb.n_frames * sizeof(double)))) return rc;
+  if ((rc = ensure(h, h->livebuf, (2 * (1 + kcap) * (size_t)std::min(B, h->slots) + 16) * sizeof(int32_t)))) return rc;
+  if ((rc = ensure(h, h->qfs, 2 * (size_t)std::min(B, h->slots) * kcap * T * rb.n_frames * sizeof(double)))) return rc;
   if (!h->h_ndone) HIPCHK(h, hipHostMalloc((void**)&h->h_ndone, 64));
   if (!h->h_progress) {
     HIPCHK(h, hipHostMalloc((void**)&h->h_progress, 64, hipHostMallocMapped));
     *h->h_progress = 0ull;
     HIPCHK(h, hipHostGetDevicePointer((void**)&h->d_progress, h->h_progress, 0));
   }
-  for (int p = 0; p < 2; ++p)
-    if (!h->ev_chk[p]) HIPCHK(h, hipEventCreateWithFlags(&h->ev_chk[p], hipEventDisableTiming));
   return GTO_OK;
 }
 
@@ -831,7 +844,9 @@ static BatchPtrs make_ptrs(gto_handle* h, const int32_t* scene_id, const double*
   bp.ss_fixed = (double*)h->ssfixed.p;
   bp.n_done = (int32_t*)h->ndone.p;
   bp.qf = (double*)h->qf.p;
-  bp.slot_inst = nullptr;  // slots only exist inside the solve loop
+  bp.live = nullptr;  // the live lists only exist inside the solve loop
+  bp.jobs = nullptr;
+  bp.nlive = nullptr;
   bp.next = nullptr;
   bp.qfs = nullptr;
   bp.cap = 0;
@@ -844,7 +859,7 @@ static BatchPtrs make_ptrs(gto_handle* h, const int32_t* scene_id, const double*
 static inline int obstacle_grid(int B, int nG) { return 8 * ((B + 7) / 8) * nG; }
 
 static int launch_obstacle(gto_handle* h, hipStream_t st, const BatchPtrs& bp, const SolveParams& sp, int B, int t_begin,
-                           int nT, int fixed_mode, bool timed, bool with_goal_terms = false, int n_slots = 0, int tg = 0) {
+                           int nT, int fixed_mode, bool timed, bool with_goal_terms = false, int n_jobs = 0, int tg = 0) {
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (timed) {
     size_t need = (size_t)(h->last_launches + 1) * 2;
@@ -860,7 +875,7 @@ static int launch_obstacle(gto_handle* h, hipStream_t st, const BatchPtrs& bp, c
   // waypoints per workgroup: groups of h->obs_tg (the two pinned waypoints form one group)
   const int TG = fixed_mode ? 1 : std::max(1, std::min(tg > 0 ? tg : h->obs_tg, nT));  // the init pass has 4 virtual waypoints
   const int nG = (nT + TG - 1) / TG;
-  const int nb = n_slots > 0 ? n_slots : B;  // workgroups are laid out for the slots in flight; B stays the batch (strides)
+  const int nb = n_jobs > 0 ? n_jobs : B;  // workgroups are laid out for the evaluation jobs there can be; B stays the batch (strides)
   const int n_regular = obstacle_grid(nb, nG);
   const int cap_active = TG * h->rb.n_chunks;
   const ObsLds lay(TG, h->rb.n_frames, h->rb.n_links, cap_active, h->np);
@@ -1009,18 +1024,20 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
   h->last_ms = 0.0;
   if (h->dbg) HIPCHK(h, hipMemsetAsync(h->dbg + 40, 0, 8 * sizeof(long long), st));
 
-  // Slots: at most W instances are in flight; an instance that finishes hands its slot to the next one that has
-  // not started (k_lm_step), so every round works on a full house until the batch runs out, instead of
-  // dragging the tail of its slowest instances through ever emptier rounds.
+  // At most W instances are in flight; the step kernel of an instance that finishes puts the next one of the call that
+  // has not started into the next round's live list, so every round works on a full house until the batch runs out,
+  // instead of dragging the tail of its slowest instances through ever emptier rounds.
   const int W = std::min(B, h->slots);
-  bp.slot_inst = (int32_t*)h->slotbuf.p;
-  bp.next = bp.slot_inst + W;
+  bp.live = (int32_t*)h->livebuf.p;
+  bp.jobs = bp.live + 2 * W;
+  bp.nlive = bp.jobs + 2 * W * sp.kcap;
+  bp.next = bp.nlive + 4;
   bp.qfs = (double*)h->qfs.p;
   bp.cap = W;
   bp.n_total = B;
   HIPCHK(h, hipMemsetAsync(bp.n_done, 0, sizeof(int32_t), st));
-  // the finished-counter reaches the host through a word in pinned memory that the step kernel writes; the tag tells
-  // this call's values from what the last launches of the previous call may still be writing
+  // the finished-counter and the round counter reach the host through two words in pinned memory that the step kernel
+  // writes; the tag tells this call's values from what the last launches of the previous call may still be writing
   h->progress_tag = h->progress_tag + 1 ? h->progress_tag + 1 : 1;
   bp.progress = h->d_progress;
   bp.progress_tag = (unsigned long long)h->progress_tag << 32;
@@ -1031,51 +1048,80 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
   }
   if (h->np == GTO_NB) hipLaunchKernelGGL(k_lm_init<GTO_NB>, dim3(B), dim3(256), 0, st, h->d_rb, bp, sp, B, 0);
   else hipLaunchKernelGGL(k_lm_init<16>, dim3(B), dim3(256), 0, st, h->d_rb, bp, sp, B, 0);
-  if ((rc = launch_obstacle(h, st, bp, sp, B, 0, 4, 1, false))) return rc;
-  // one round = evaluate the trial trajectories of the slots (obstacle kernel) + accept/solve/new trial (step
-  // kernel).  An instance may start late: enough rounds for every slot to serve its share one after the other.
+  {
+    BatchPtrs bpi = bp;
+    bpi.live = nullptr;  // the init pass indexes the batch directly
+    if ((rc = launch_obstacle(h, st, bpi, sp, B, 0, 4, 1, false))) return rc;
+  }
+  // one round = evaluate the candidate trial trajectories of the instances in flight (obstacle kernel) +
+  // accept/solve/new candidates (step kernel).  An instance may start late: enough rounds for every position to serve its
+  // share one after the other.
   const int max_rounds = ((B + W - 1) / W + 1) * (sp.max_iter + 2);
-  int n_checks = 0, known_done = 0;
-  bool live = true;
-  for (int k = 0; k <= max_rounds && live; ++k) {
-    // the goal workgroups skip fresh instances themselves: k_lm_init already produced the seed's goal terms
-    // instances in flight, as far as the host knows (the finished-counter it has seen is a few rounds old)
-    const int in_flight = std::min(W, B - known_done);
-    const bool few = in_flight <= h->few_instances;
-    const int tg = few ? h->obs_tg_few : h->obs_tg;
-    sp.interleave = h->obs_interleave == 1 || (h->obs_interleave == 2 && few);
-    if ((rc = launch_obstacle(h, st, bp, sp, B, 2, T - 2, 0, h->profiling, true, W, tg))) return rc;
-    if (h->np == GTO_NB) {
-      if (few && h->step_nw_few == 8) hipLaunchKernelGGL(k_lm_step<8>, dim3(W), dim3(512), h->lm_lds, st, h->d_rb, bp, sp, B);
-      else hipLaunchKernelGGL(k_lm_step<4>, dim3(W), dim3(256), h->lm_lds, st, h->d_rb, bp, sp, B);
-    }
-    else hipLaunchKernelGGL(k_lm_step_wide<16>, dim3(W), dim3(256), h->lm_lds, st, h->d_rb, bp, sp, B, (double*)h->zws.p);
-    // Early exit.  Every few rounds the finished-instance counter is copied back (4 bytes) and an event is
-    // recorded, but the host only LOOKS at the copy of the previous check: by then the GPU has long passed that
-    // point, so the host never waits on the GPU's critical path and the queue never drains (a blocking
-    // read-back every 8 rounds cost 25-30 us of idle GPU each).  The price is a few rounds of empty launches
-    // after the last instance finishes.
-    if (h->check_every > 0 && (k % h->check_every) == h->check_every - 1 && k < max_rounds) {
-      // throttle: never more than two check intervals ahead of the GPU (an event, no copy: the counter itself arrives
-      // through the progress word)
-      const int p = n_checks & 1;
-      HIPCHK(h, hipEventRecord(h->ev_chk[p], st));
-      if (n_checks > 0) {
-        // sleep-poll instead of hipEventSynchronize: the runtime spins there, one host core per lane, and a node
-        // with 8 GPUs x 4 lanes may not have 32 cores to burn; 50 us do not matter
-        for (;;) {
-          const hipError_t qe = hipEventQuery(h->ev_chk[1 - p]);
-          if (qe == hipSuccess) break;
-          if (qe != hipErrorNotReady) HIPCHK(h, qe);
-          std::this_thread::sleep_for(std::chrono::microseconds(50));
+  int known_done = 0, seen_round = -1;
+  int k_prev = 1;  // candidates per instance the last step launch may have generated
+  auto read_progress = [&]() {
+    const unsigned long long p0 = __atomic_load_n(h->h_progress, __ATOMIC_RELAXED), p1 = __atomic_load_n(h->h_progress + 1, __ATOMIC_RELAXED);
+    if ((unsigned)(p0 >> 32) == h->progress_tag) known_done = std::max(known_done, (int)(p0 & 0xffffffffull));
+    if ((unsigned)(p1 >> 32) == h->progress_tag) seen_round = std::max(seen_round, (int)(p1 & 0xffffffffull));
+  };
+  // naps of the throttle below: tens of microseconds, which the default timer slack of a thread (50 us) would double
+  const int old_slack = prctl(PR_GET_TIMERSLACK);
+  if (old_slack > 1000) (void)prctl(PR_SET_TIMERSLACK, 1000UL);
+  int rc_loop = GTO_OK;
+  for (int k = 0; k <= max_rounds; ++k) {
+    // instances in flight, as far as the host knows (the finished-counter it has seen is a few rounds old: an upper bound)
+    read_progress();
+    int in_flight = std::min(W, B - known_done);
+    bool few = in_flight <= h->few_instances;
+    // throttle: never more than `ahead` rounds in front of the last step launch seen running, so that the launches stay
+    // sized to what is left and the empty rounds after the last instance finishes stay few; the queue never drains
+    // (sleep-poll, not a blocking wait: the runtime spins in those, one host core per lane)
+    const int ahead = few ? h->ahead_few : h->ahead;
+    for (long naps = 0; k - seen_round > ahead + 1; ++naps) {
+      std::this_thread::sleep_for(std::chrono::microseconds(few ? 10 : 50));
+      read_progress();
+      if ((naps & 1023) == 1023) {  // a stream that went idle or failed without reaching the round: do not wait for ever
+        const hipError_t qe = hipStreamQuery(st);
+        if (qe != hipErrorNotReady) {
+          read_progress();
+          if (k - seen_round > ahead + 1) {
+            h->err = qe == hipSuccess ? "solve loop: the stream went idle before the rounds it was given ran" : std::string("solve loop: ") + hipGetErrorString(qe);
+            rc_loop = GTO_ERR_HIP;
+            break;
+          }
         }
       }
-      const unsigned long long pv = *(volatile unsigned long long*)h->h_progress;
-      if ((unsigned)(pv >> 32) == h->progress_tag) known_done = std::max(known_done, (int)(pv & 0xffffffffull));
-      if (known_done >= B) live = false;
-      ++n_checks;
+    }
+    if (rc_loop) break;
+    if (known_done >= B) break;
+    in_flight = std::min(W, B - known_done);
+    few = in_flight <= h->few_instances;
+    const int tg = few ? h->obs_tg_few : h->obs_tg;
+    sp.interleave = h->obs_interleave == 1 || (h->obs_interleave == 2 && few);
+    sp.round = k;
+    sp.parity = k & 1;
+    // the goal workgroups skip fresh instances themselves: k_lm_init already produced the seed's goal terms
+    sp.k_eval = k_prev;
+    if ((rc = launch_obstacle(h, st, bp, sp, B, 2, T - 2, 0, h->profiling, true, in_flight * k_prev, tg))) { rc_loop = rc; break; }
+    if (h->np == GTO_NB) {
+      if (few && h->step_nw_few == 8) {
+        // few instances in flight: eight waves per instance and candidate trial points ahead of their evaluation
+        sp.k_rej = in_flight <= h->spec_few ? std::min(h->spec_rej, h->spec_kmax) : 1;
+        sp.k_acc = in_flight <= std::min(h->spec_deep, h->spec_few) ? std::min(h->spec_acc, h->spec_kmax) : 1;
+        const int kl = std::max(sp.k_acc, sp.k_rej);
+        hipLaunchKernelGGL((k_lm_step<8, GTO_KSPEC>), dim3(in_flight), dim3(512), lm_lds_bytes(T, kl), st, h->d_rb, bp, sp, B);
+        k_prev = kl;
+      } else {
+        sp.k_acc = sp.k_rej = 1;
+        hipLaunchKernelGGL((k_lm_step<4, 1>), dim3(in_flight), dim3(256), h->lm_lds, st, h->d_rb, bp, sp, B);
+        k_prev = 1;
+      }
+    } else {
+      hipLaunchKernelGGL(k_lm_step_wide<16>, dim3(in_flight), dim3(256), h->lm_lds, st, h->d_rb, bp, sp, B, (double*)h->zws.p);
     }
   }
+  if (old_slack > 1000) (void)prctl(PR_SET_TIMERSLACK, (unsigned long)old_slack);
+  if (rc_loop) return rc_loop;
   hipLaunchKernelGGL(k_lm_finalize, dim3(B), dim3(64), 0, st, h->d_rb, bp, sp, B, Q_out, dQ_out, cost_out, iters_out, status_out);
   HIPCHK(h, hipGetLastError());
   if (h->dbg) {
@@ -1434,7 +1480,7 @@ static int eval_common(gto_handle* h, int B, int n_max, const int32_t* scene_id,
     states.assign(B, InstState{});
     ssfixed.assign((size_t)B * 4, 0.0);
     for (int b = 0; b < B; ++b) {
-      states[b].fgoal_try = terms[4 * b], states[b].fvel_try = terms[4 * b + 2], states[b].argmin_try = (int32_t)terms[4 * b + 3];
+      states[b].fgoal_try[0] = terms[4 * b], states[b].fvel_try[0] = terms[4 * b + 2], states[b].argmin_try[0] = (int32_t)terms[4 * b + 3];
       for (int t = 0; t < 2; ++t) ssfixed[4 * b + t] = blocks[((size_t)b * T + t) * BLK_STRIDE + BLK_SS];
     }
     return GTO_OK;
@@ -1484,10 +1530,10 @@ int gto_eval_objective(gto_handle* h, int32_t B, int32_t n_max, const int32_t* s
     double so = ssf[4 * b] + ssf[4 * b + 1];
     const size_t bstride = (size_t)h->np * h->np + h->np + 8, bss = (size_t)h->np * h->np + h->np;
     for (int t = 2; t < T; ++t) so += blocks[((size_t)b * T + t) * bstride + bss];
-    if (f_goal) f_goal[b] = st[b].fgoal_try;
+    if (f_goal) f_goal[b] = st[b].fgoal_try[0];
     if (f_obs) f_obs[b] = h->opts.w_obstacle * so;
-    if (f_vel) f_vel[b] = st[b].fvel_try;
-    if (goal_argmin) goal_argmin[b] = st[b].argmin_try;
+    if (f_vel) f_vel[b] = st[b].fvel_try[0];
+    if (goal_argmin) goal_argmin[b] = st[b].argmin_try[0];
   }
   return GTO_OK;
 }

@@ -273,17 +273,23 @@ def test_slots_hand_over_to_waiting_instances(capi, oracle_mod, monkeypatch, slo
 
 
 @pytest.mark.parametrize("knob,value", [("GTO_OBS_TG", "1"), ("GTO_OBS_TG", "2"), ("GTO_OBS_TG", "4"), ("GTO_OBS_INTERLEAVE", "0"),
-                                        ("GTO_OBS_INTERLEAVE", "1"), ("GTO_CHECK_EVERY", "1"), ("GTO_CHECK_EVERY", "7"),
-                                        ("GTO_STEP_NW_FEW", "4"), ("GTO_DIST_RELAX", "1")])
+                                        ("GTO_OBS_INTERLEAVE", "1"), ("GTO_AHEAD", "1"), ("GTO_AHEAD", "24"),
+                                        ("GTO_STEP_NW_FEW", "4"), ("GTO_DIST_RELAX", "1"), ("GTO_FEW_INSTANCES", "0"),
+                                        ("GTO_FEW_INSTANCES", "8"), ("GTO_SPEC_REJ", "1"), ("GTO_SPEC_REJ", "2"), ("GTO_SPEC_REJ", "3"),
+                                        ("GTO_SPEC_ACC,GTO_SPEC_DEEP", "4,100000"), ("GTO_SPEC_ACC,GTO_SPEC_DEEP,GTO_SPEC_REJ", "2,100000,1"),
+                                        ("GTO_SPEC_ACC,GTO_SPEC_DEEP,GTO_SPEC_REJ", "1,0,1")])
 def test_launch_geometry_does_not_change_results(capi, oracle_mod, monkeypatch, knob, value):
-    """How the waypoints are dealt to the workgroups of the obstacle kernel (group size, consecutive or interleaved) and
-    how often the host looks at the progress word are scheduling decisions: every instance gets bit-for-bit the same
-    trajectory, cost and iteration count (a (waypoint, link) key is folded by one wave in chunk order, the keys of a
-    waypoint are added up in link order)."""
+    """How the waypoints are dealt to the workgroups of the obstacle kernel (group size, consecutive or interleaved), how
+    far the host runs ahead of the GPU, when a call switches to the launches for few instances in flight, and how many
+    candidate trial points a step hands out ahead of their evaluation (speculation: after a rejection the next trial point
+    is known; GTO_SPEC_*) are scheduling decisions: every instance gets bit-for-bit the same trajectory, cost and iteration
+    count (a (waypoint, link) key is folded by one wave in chunk order, the keys of a waypoint are added up in link order;
+    the candidates of a step are walked in the order the sequential algorithm would have met them)."""
     prob = Problem("panda", B=24, scene_seed=5, n_goals=2)
     h, o = make_pair(capi, oracle_mod, prob, max_iter=15)
     ref = h.solve_batch(*prob.solve_args())
-    monkeypatch.setenv(knob, value)
+    for kn, va in zip(knob.split(","), value.split(",")):
+        monkeypatch.setenv(kn, va)
     h2 = capi.SolverHandle(prob.desc, prob.cfg["link_ee"], prob.cfg["link_gripper"], oracle_mod.reference_opts(max_iter=15), device=0)
     h2.set_mode(0)
     h2.set_scene(*prob.scene_args())
