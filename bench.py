@@ -116,6 +116,9 @@ def main():
     ap.add_argument("--scenes-per-gpu", type=int, default=32,
                     help="scene-sharded leg (N > 1, or --scene-sharded): scenes per GPU, 8 grasps each (BASELINE configs[3] is 256 per GPU)")
     ap.add_argument("--scene-sharded", action="store_true", help="run the scene-sharded leg also on one GPU")
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="the timed region (exactly --steps steps, barrier + synchronize on both sides) is run this many times "
+                         "back to back; ms_per_step / value are the MEDIAN region, min and max are reported beside it")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -208,8 +211,12 @@ def main():
             self.h.solve_batch_device(m * B, 1, *ptrs, self.stream.cuda_stream)
 
         def host_step(self, m=1, first=0):
-            """The same call through the host-pointer entry point (H2D / D2H of the per-instance data included)."""
-            return self.h.solve_batch(*[a[first * B:(first + m) * B] for a in self.host])
+            """The same call through the host-pointer entry point (H2D / D2H of the per-instance data included); the result
+            arrays are the lane's own, kept from call to call like its device buffers."""
+            if getattr(self, "host_out", None) is None:
+                n = self.host[1].shape[0]
+                self.host_out = (np.empty((n, ndof, T)), np.empty((n, ndof, T - 1)), np.empty(n), np.empty(n, np.int32), np.empty(n, np.int32))
+            return self.h.solve_batch(*[a[first * B:(first + m) * B] for a in self.host], out=tuple(a[first * B:(first + m) * B] for a in self.host_out))
 
     lanes = [Lane()]
     lanes += [Lane(lanes[0]) for _ in range(D - 1)]
@@ -259,20 +266,31 @@ def main():
     pipe = BatchPipeline(lanes)
     run_steps(pipe, args.warmup * D * M)  # every lane sees >= W warmup launches
     barrier()
-    # ---- timed region: exactly K steps (batches), up to D x M of them in flight
-    t0, c0 = time.perf_counter(), time.process_time()
-    run_steps(pipe, args.steps)
-    barrier()
-    elapsed, host_cpu = time.perf_counter() - t0, time.process_time() - c0
+    R = max(1, args.repeats)
+
+    def timed_regions(method):
+        """R timed regions back to back, each exactly K steps (batches) with up to D x M of them in flight, each bracketed
+        by barrier + synchronize; every rank takes the same decisions (the times are reduced over the ranks below)."""
+        out, cpu = [], []
+        for _ in range(R):
+            barrier()
+            t0, c0 = time.perf_counter(), time.process_time()
+            run_steps(pipe, args.steps, method)
+            barrier()
+            out.append(time.perf_counter() - t0)
+            cpu.append(time.process_time() - c0)
+        return np.array(out), np.array(cpu)
+
+    # ---- timed regions, device-resident entry point (inputs in HBM when the region starts): `value`
+    el_all, cpu_all = timed_regions("step")
     # ---- SURVEY.md 8d's literal metric: the same K steps through the host-pointer entry point on the same lanes
-    host_pipe_rate = None
+    host_all = None
     if not args.merged_launches_only:
-        run_steps(pipe, min(args.steps, D * M), "host_step")
-        barrier()
-        th = time.perf_counter()
-        run_steps(pipe, args.steps, "host_step")
-        barrier()
-        host_pipe_rate = B * args.steps / (time.perf_counter() - th)
+        # warm-up of the host-pointer path: its staging buffers are allocated by the first call, and one of the first few
+        # calls after that takes 5-10 ms longer (measured, once per process; not in the library's own code path)
+        for _ in range(max(1, min(args.warmup, 3))):
+            run_steps(pipe, min(args.steps, D * M), "host_step")
+        host_all, _ = timed_regions("host_step")
     pipe.close()
     ln0 = lanes[0]
     # a lane's results do not depend on what the other lanes do: lane 0 solves lane 1's batches again, alone on the GPU
@@ -341,7 +359,7 @@ def main():
     status = d_st.cpu().numpy()
     cost = d_cost.cpu().numpy()
     Qsol = d_Q.cpu().numpy()
-    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    el = torch.tensor(np.concatenate([el_all, host_all if host_all is not None else np.zeros(0)]), dtype=torch.float64, device=dev)
     # iterations done inside the timed region: a call of m steps solves a lane's batches 0 .. m-1 (lane 0's counts stand
     # for the other lanes' grasp sets of the same scene)
     per_batch_it = iters.reshape(M, B).sum(axis=1)
@@ -350,7 +368,12 @@ def main():
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         dist.all_reduce(it_sum, op=dist.ReduceOp.SUM)
-    elapsed = float(el.item())
+    el_np = el.cpu().numpy()  # per region: the slowest rank's time
+    el_all = el_np[:R]
+    host_all = el_np[R:] if host_all is not None else None
+    elapsed = float(np.median(el_all))
+    host_cpu = float(np.median(cpu_all))
+    host_pipe_rate = None if host_all is None else B * args.steps / float(np.median(host_all))
     total_traj = world * B * args.steps
     value = total_traj / elapsed
     iters_per_s = float(it_sum.item()) / elapsed
@@ -511,6 +534,19 @@ def main():
             "metric": "grasp trajectories/sec", "value": round(value, 2), "unit": "trajectories/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            # the timed region (exactly `steps` steps, barrier + synchronize on both sides) is run `repeats` times; value and
+            # ms_per_step are the median region
+            "timed_regions": {"repeats": R, "what": "median", "ms_per_step_all": [round(1e3 * float(x) / args.steps, 3) for x in el_all],
+                              "value_min": round(total_traj / float(el_all.max()), 1), "value_max": round(total_traj / float(el_all.min()), 1),
+                              "spread_rel": round(float((el_all.max() - el_all.min()) / np.median(el_all)), 4)},
+            # SURVEY.md 8d's literal metric, same regions through the host-pointer entry point (H2D / D2H of the per-instance
+            # data inside the timing)
+            "host_api": None if host_all is None else {
+                "trajectories_per_s": round(world * B * args.steps / float(np.median(host_all)), 2),
+                "ms_per_step": round(1e3 * float(np.median(host_all)) / args.steps, 3),
+                "ms_per_step_all": [round(1e3 * float(x) / args.steps, 3) for x in host_all],
+                "vs_device_resident": round(float(np.median(el_all) / np.median(host_all)), 4),
+                "spread_rel": round(float((host_all.max() - host_all.min()) / np.median(host_all)), 4)},
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": (f"BASELINE configs[4]: Fetch on a planar base ({desc.n_opt} optimised joints), 1 scene x {B} goal grasps per GPU, T={int(T)}, " if mobile else
                                     f"BASELINE configs[2]: Fetch arm, {'shelf' if args.shelf else 'table-top'} scene x {B} goal grasps per GPU, T={int(T)}, " if fetch else

@@ -265,7 +265,10 @@ class SolverHandle:
         self.scenes.pop(scene_id, None)
 
     # -------------------------------------------------------------- solve
-    def solve_batch(self, scene_id, qc, goals, n_goals, standoff, base_pos, Q0):
+    def solve_batch(self, scene_id, qc, goals, n_goals, standoff, base_pos, Q0, out=None):
+        """gto_solve_batch through host arrays.  ``out``: optional tuple (Q, dQ, cost, iters, status) of C-contiguous arrays
+        to write into (shapes (B,ndof,T) f64, (B,ndof,T-1) f64, (B,) f64, (B,) i32, (B,) i32): a caller that solves batch
+        after batch keeps its result arrays instead of having fresh pages mapped and faulted in on every call."""
         d, T = self.desc, self.T
         qc = _f64(qc).reshape(-1, d.ndof)
         B = qc.shape[0]
@@ -279,11 +282,18 @@ class SolverHandle:
         so = None if standoff is None else _f64(np.broadcast_to(_f64(standoff).reshape(-1, 16), (B, 16)))
         base = _f64(np.broadcast_to(_f64(base_pos).reshape(-1, 3), (B, 3)))
         Q0 = _f64(Q0).reshape(B, d.ndof, T)
-        Q = np.empty((B, d.ndof, T))
-        dQ = np.empty((B, d.ndof, T - 1))
-        cost = np.empty(B)
-        iters = np.empty(B, dtype=np.int32)
-        status = np.empty(B, dtype=np.int32)
+        if out is not None:
+            Q, dQ, cost, iters, status = out
+            want = (((B, d.ndof, T), np.float64), ((B, d.ndof, T - 1), np.float64), ((B,), np.float64), ((B,), np.int32), ((B,), np.int32))
+            for a, (shp, dt) in zip(out, want):
+                if a.shape != shp or a.dtype != dt or not a.flags.c_contiguous:
+                    raise ValueError(f"solve_batch(out=): expected a C-contiguous {np.dtype(dt).name} array of shape {shp}, got {a.dtype} {a.shape}")
+        else:
+            Q = np.empty((B, d.ndof, T))
+            dQ = np.empty((B, d.ndof, T - 1))
+            cost = np.empty(B)
+            iters = np.empty(B, dtype=np.int32)
+            status = np.empty(B, dtype=np.int32)
         vp = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
         rc = self.lib.gto_solve_batch(self._h, B, n_max, vp(scene_id), vp(qc), vp(goals), vp(n_goals),
                                       vp(so), vp(base), vp(Q0), vp(Q), vp(dQ), vp(cost), vp(iters), vp(status))
