@@ -113,9 +113,15 @@ def main():
                     help="skip the one-batch-per-launch passes (serial latency, host API): every launch of the run then has the "
                          "timed region's size, which is what the per-launch PMC averages of tools/pmc_pass.sh need")
     ap.add_argument("--cpu-seconds", type=float, default=16.0, help="target duration of the CPU-baseline sample")
-    ap.add_argument("--scenes-per-gpu", type=int, default=32,
-                    help="scene-sharded leg (N > 1, or --scene-sharded): scenes per GPU, 8 grasps each (BASELINE configs[3] is 256 per GPU)")
+    ap.add_argument("--scenes-per-gpu", type=int, default=0,
+                    help="scene-sharded leg (N > 1, or --scene-sharded): scenes per GPU, 8 grasps each; 0 = 256 with --gpus 8 "
+                         "(BASELINE configs[3]: 2048 scenes over 8 GPUs, 37.9 GB of fields resident per GPU), else 32")
     ap.add_argument("--scene-sharded", action="store_true", help="run the scene-sharded leg also on one GPU")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="torch.distributed backend of the N > 1 run: nccl = RCCL (one GPU per rank); gloo = host-side collectives, "
+                         "for dry runs of the multi-rank code on a box with fewer GPUs than ranks")
+    ap.add_argument("--same-device", action="store_true",
+                    help="every rank uses device 0 (with --backend gloo: the N > 1 code path on ONE GPU; the rates then say nothing)")
     ap.add_argument("--repeats", type=int, default=5,
                     help="the timed region (exactly --steps steps, barrier + synchronize on both sides) is run this many times "
                          "back to back; ms_per_step / value are the MEDIAN region, min and max are reported beside it")
@@ -137,17 +143,25 @@ def main():
         print(f"[bench] WORLD_SIZE={world} != --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the GTO solve path has no CPU fallback")
+    if args.same_device:
+        if args.backend == "nccl":
+            raise SystemExit("--same-device needs --backend gloo: RCCL refuses two ranks on one device")
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    comm_dev = dev if args.backend == "nccl" else torch.device("cpu")  # where the tensors of the (few, tiny) collectives live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     import __graft_entry__ as g
     if not os.path.exists(g.HIP_LIB):
         g.build()
     from grasptrajopt_amd import _capi, synthetic as syn
-    from grasptrajopt_amd.parallel import BatchPipeline, shard_by_scene, shard_range, solve_sharded
+    from grasptrajopt_amd.parallel import BatchPipeline, shard_by_scene, shard_range, solve_local_shard
     from grasptrajopt_amd.robot_desc import load_builtin
 
     fetch = args.robot.startswith("fetch")  # BASELINE configs[2]: --robot fetch --batch 256 (shelf-height table)
@@ -359,12 +373,12 @@ def main():
     status = d_st.cpu().numpy()
     cost = d_cost.cpu().numpy()
     Qsol = d_Q.cpu().numpy()
-    el = torch.tensor(np.concatenate([el_all, host_all if host_all is not None else np.zeros(0)]), dtype=torch.float64, device=dev)
+    el = torch.tensor(np.concatenate([el_all, host_all if host_all is not None else np.zeros(0)]), dtype=torch.float64, device=comm_dev)
     # iterations done inside the timed region: a call of m steps solves a lane's batches 0 .. m-1 (lane 0's counts stand
     # for the other lanes' grasp sets of the same scene)
     per_batch_it = iters.reshape(M, B).sum(axis=1)
     it_timed = float(sum(per_batch_it[:m].sum() for m in plan))
-    it_sum = torch.tensor([it_timed], dtype=torch.float64, device=dev)
+    it_sum = torch.tensor([it_timed], dtype=torch.float64, device=comm_dev)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         dist.all_reduce(it_sum, op=dist.ReduceOp.SUM)
@@ -382,14 +396,18 @@ def main():
     # host-pointer API, results all_gathered (RCCL); every instance of a call reads a different field
     scene_sharded = None
     if world > 1 or args.scene_sharded:
-        SG, SP = 8, args.scenes_per_gpu
+        SG = 8
+        SP = args.scenes_per_gpu if args.scenes_per_gpu > 0 else (256 if world == 8 else 32)
         n_sc = SP * world
+        nI = n_sc * SG
         sid_all = np.repeat(np.arange(n_sc, dtype=np.int32), SG)
         owner = shard_by_scene(sid_all, world)
-        mine_sc = np.unique(sid_all[owner == rank])
+        mine = np.nonzero(owner == rank)[0]            # this rank's instances (global indices), grouped by scene
+        mine_sc = np.unique(sid_all[mine])
         hs_ = _capi.SolverHandle(desc, cfg["link_ee"], cfg["link_gripper"], opts, device=local_rank, n_gripper_points=100)
         hs_.set_mode(mode)
-        rng_goal = {}
+        free0 = torch.cuda.mem_get_info(dev)[0]
+        RTl, qgl = np.empty((len(mine), 4, 4)), np.empty((len(mine), ndof))  # arguments of THIS rank's instances only
         for s_ in mine_sc:
             scs = make_scene(100 + int(s_))
             hs_.set_scene(int(s_), scs.c_all, scs.c_obs, scs.shape, scs.origin, scs.res)
@@ -397,30 +415,30 @@ def main():
             def cc(q, s_=int(s_)):
                 _, _, val, _ = hs_.eval_points(s_, q, [0.0, 0.0, 0.0], use_obs=True)
                 return (val * moving[None, :]).sum(axis=1)
-            rng_goal[int(s_)] = syn.make_goals(desc, hs_.eval_fk, cfg["link_ee"], SG, seed=7000 + int(s_), collision_cost=cc, zlim=zlim)
-        # every rank needs the arguments of the whole list only for its own shard: the others' rows are never read
-        nI = n_sc * SG
-        RTa, qga = np.tile(np.eye(4), (nI, 1, 1)), np.tile(default_pose, (nI, 1))
-        for s_, (r_, q_) in rng_goal.items():
-            RTa[s_ * SG:(s_ + 1) * SG], qga[s_ * SG:(s_ + 1) * SG] = r_, q_
-        qca = np.tile(default_pose, (nI, 1))
-        Q0a = np.stack([syn.make_seed(qca[i], qga[i], T, desc.param_index) for i in range(nI)])
-        Sa = syn.standoff_pose(-0.1, cfg["axis_standoff"])
-        sargs = (sid_all, qca, RTa.reshape(nI, 1, 16), 1, Sa, [0.0, 0.0, 0.0], Q0a)
-        solve_sharded(hs_.solve_batch, *sargs, rank=rank, world=world, assignment=owner)  # warm-up
+            rows = np.nonzero(sid_all[mine] == s_)[0]
+            RTl[rows], qgl[rows] = syn.make_goals(desc, hs_.eval_fk, cfg["link_ee"], SG, seed=7000 + int(s_), collision_cost=cc, zlim=zlim)
+        resident_gb = (free0 - torch.cuda.mem_get_info(dev)[0]) / 1e9
+        qcl = np.tile(default_pose, (len(mine), 1))
+        Q0l = np.stack([syn.make_seed(qcl[i], qgl[i], T, desc.param_index) for i in range(len(mine))])
+        Sl = np.tile(syn.standoff_pose(-0.1, cfg["axis_standoff"]).reshape(1, 16), (len(mine), 1))
+        sargs = (mine, sid_all[mine], qcl, RTl.reshape(len(mine), 1, 16), np.ones(len(mine), np.int32), Sl, np.zeros((len(mine), 3)), Q0l)
+        solve_local_shard(hs_.solve_batch, *sargs, B=nI, rank=rank, world=world, assignment=owner)  # warm-up
         barrier()
         tss = time.perf_counter()
-        idx, Qa, _, ca, ia, sa = solve_sharded(hs_.solve_batch, *sargs, rank=rank, world=world, assignment=owner)
+        idx, Qa, _, ca, ia, sa = solve_local_shard(hs_.solve_batch, *sargs, B=nI, rank=rank, world=world, assignment=owner)
         barrier()
-        els = torch.tensor([time.perf_counter() - tss], dtype=torch.float64, device=dev)
+        els = torch.tensor([time.perf_counter() - tss], dtype=torch.float64, device=comm_dev)
         if world > 1:
             dist.all_reduce(els, op=dist.ReduceOp.MAX)
         oi_ = desc.opt_index
-        scene_sharded = {"workload": f"BASELINE configs[3]: {n_sc} scenes x {SG} grasps, grouped by scene onto {world} GPU(s) "
-                                     f"({SP} scenes, {SP * 0.148 * (args.grid / 128) ** 3:.1f} GB of fields per GPU), host-pointer API, results "
-                                     + ("all_gathered over RCCL" if world > 1 else "kept on the one rank"),
+        scene_sharded = {"workload": f"BASELINE configs[3]: {n_sc} scenes x {SG} grasps, grouped by scene onto {world} rank(s) "
+                                     f"({SP} scenes per rank), host-pointer API, every rank builds and solves its own instances only, results "
+                                     + (f"all_gathered over {'RCCL' if args.backend == 'nccl' else 'gloo'}" if world > 1 else "kept on the one rank"),
                          "instances": int(nI), "trajectories_per_s": round(nI / float(els.item()), 1),
-                         "all_instances_returned": bool(len(idx) == nI), "iters_mean": round(float(ia.mean()), 2),
+                         "scenes_per_rank": int(SP), "fields_resident_gb_this_rank": round(resident_gb, 2),
+                         "all_instances_returned": bool(len(idx) == nI and np.array_equal(idx, np.arange(nI))),
+                         "own_shard_round_trip_exact": bool(np.array_equal(Qa[mine], solve_local_shard(hs_.solve_batch, *sargs, B=nI, rank=rank, world=world, assignment=owner, gather=False)[1])),
+                         "iters_mean": round(float(ia.mean()), 2), "status_counts": {str(k): int((sa == k).sum()) for k in np.unique(sa)},
                          "max_joint_limit_violation": float(np.maximum(desc.lower[oi_][None, :, None] - Qa[:, oi_], Qa[:, oi_] - desc.upper[oi_][None, :, None]).max())}
         hs_.close()
 
@@ -554,7 +572,8 @@ def main():
                                    f"{P} surface points, {args.grid}^3 f32 SDF cost field",
                        "batch_per_gpu": B, "T": int(T), "surface_points": int(P), "grid": args.grid,
                        "max_iter": args.max_iter, "steps_per_call": M, "lanes": D, "solver_mode": args.mode,
-                       "parallelism": f"instances sharded over {world} GPU(s), no collective"},
+                       "parallelism": f"instances sharded over {world} GPU(s), no collective"
+                                      + (f" (dry run: {world} ranks on ONE device, backend {args.backend})" if args.same_device else "")},
             "pipeline": {"lanes": D, "steps_per_call": M, "slots_per_lane": slots,
                          "calls_in_steps": sorted(set(plan)),
                          "what": "per GPU: `lanes` solver handles (HIP stream + host thread each, every lane its own grasp sets); every "

@@ -36,44 +36,30 @@ def shard_by_scene(scene_id: Sequence[int], world: int) -> np.ndarray:
     return np.array([owner[int(s)] for s in scene_id], dtype=np.int32)
 
 
-def solve_sharded(solve_fn: Callable[..., tuple], scene_id, qc, goals, n_goals, standoff, base_pos, Q0,
-                  rank: int, world: int, group=None, gather: bool = True, assignment: Optional[np.ndarray] = None):
-    """Solve this rank's shard with `solve_fn` (SolverHandle.solve_batch signature) and, if `gather`,
-    all_gather the results so every rank returns the full batch in the original order.
-
-    The caller is responsible for having uploaded the scenes its shard refers to on this rank.
-    """
-    scene_id = np.asarray(scene_id, dtype=np.int32)
-    B = scene_id.shape[0]
-    qc = np.asarray(qc, dtype=np.float64).reshape(B, -1)
-    goals = np.asarray(goals, dtype=np.float64).reshape(B, -1, 16)
-    n_goals = np.broadcast_to(np.asarray(n_goals, dtype=np.int32), (B,))
-    base_pos = np.broadcast_to(np.asarray(base_pos, dtype=np.float64).reshape(-1, 3), (B, 3))
-    Q0 = np.asarray(Q0, dtype=np.float64)
-    so = None if standoff is None else np.broadcast_to(np.asarray(standoff, dtype=np.float64).reshape(-1, 16), (B, 16))
+def _shard_indices(B: int, world: int, assignment: Optional[np.ndarray]):
+    """Global instance indices of every rank's shard (ascending inside a shard)."""
     if assignment is None:
-        lo, hi = shard_range(B, rank, world)
-        mine = np.arange(lo, hi)
-    else:
-        mine = np.nonzero(np.asarray(assignment) == rank)[0]
-    ndof, T = Q0.shape[1], Q0.shape[2]
-    if len(mine):
-        Q, dQ, cost, iters, status = solve_fn(scene_id[mine], qc[mine], goals[mine], n_goals[mine],
-                                              None if so is None else so[mine], base_pos[mine], Q0[mine])
-    else:
-        Q, dQ = np.empty((0, ndof, T)), np.empty((0, ndof, T - 1))
-        cost, iters, status = np.empty(0), np.empty(0, np.int32), np.empty(0, np.int32)
-    if not gather or world == 1:
-        return mine, Q, dQ, cost, iters, status
+        return [np.arange(*shard_range(B, r, world)) for r in range(world)]
+    assignment = np.asarray(assignment)
+    return [np.nonzero(assignment == r)[0] for r in range(world)]
 
+
+def gather_results(mine: np.ndarray, result: tuple, B: int, rank: int, world: int, group=None,
+                   assignment: Optional[np.ndarray] = None):
+    """all_gather the solved shards (Q, dQ, cost, iters, status of the instances `mine`) so that every rank holds the
+    full batch of B instances in the original order: the ONLY collective of the multi-GPU path, outside the solve.
+    One fixed-size float64 payload per rank (padded to the largest shard; iteration counts and status travel as exact
+    small integers), on the device for RCCL (`backend="nccl"`), on the host for gloo."""
     import torch
     import torch.distributed as dist
+    Q, dQ, cost, iters, status = result
+    ndof, T = Q.shape[1], Q.shape[2]
+    shards = _shard_indices(B, world, assignment)
+    if not np.array_equal(np.asarray(mine), shards[rank]):
+        raise ValueError("gather_results: `mine` is not this rank's shard under the given assignment")
     backend = dist.get_backend(group)
     dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
-    # fixed-size payload per rank (pad to the largest shard) so a plain all_gather suffices
-    counts = [len(np.nonzero(np.asarray(assignment) == r)[0]) if assignment is not None
-              else shard_range(B, r, world)[1] - shard_range(B, r, world)[0] for r in range(world)]
-    mx = max(counts)
+    mx = max(len(ix) for ix in shards)
     width = ndof * T + ndof * (T - 1) + 3
     payload = np.zeros((mx, width))
     n = len(mine)
@@ -85,14 +71,54 @@ def solve_sharded(solve_fn: Callable[..., tuple], scene_id, qc, goals, n_goals, 
     dist.all_gather(recv, send, group=group)
     Qa, dQa = np.empty((B, ndof, T)), np.empty((B, ndof, T - 1))
     ca, ia, sa = np.empty(B), np.empty(B, np.int32), np.empty(B, np.int32)
-    for r in range(world):
-        idx = (np.nonzero(np.asarray(assignment) == r)[0] if assignment is not None
-               else np.arange(*shard_range(B, r, world)))
+    for r, idx in enumerate(shards):
         blk = recv[r].cpu().numpy()[: len(idx)]
         Qa[idx] = blk[:, : ndof * T].reshape(-1, ndof, T)
         dQa[idx] = blk[:, ndof * T: ndof * T + ndof * (T - 1)].reshape(-1, ndof, T - 1)
         ca[idx], ia[idx], sa[idx] = blk[:, -3], blk[:, -2].astype(np.int32), blk[:, -1].astype(np.int32)
     return np.arange(B), Qa, dQa, ca, ia, sa
+
+
+def solve_local_shard(solve_fn: Callable[..., tuple], mine, scene_id, qc, goals, n_goals, standoff, base_pos, Q0,
+                      B: int, rank: int, world: int, group=None, gather: bool = True,
+                      assignment: Optional[np.ndarray] = None):
+    """Like solve_sharded, but the argument arrays hold ONLY this rank's instances (rows in the order of `mine`, the
+    global indices of the shard): a rank never materialises the inputs of instances it does not solve.  B is the size of
+    the whole batch."""
+    mine = np.asarray(mine)
+    n = len(mine)
+    scene_id = np.broadcast_to(np.asarray(scene_id, dtype=np.int32), (n,))
+    Q0 = np.asarray(Q0, dtype=np.float64)
+    ndof, T = Q0.shape[-2], Q0.shape[-1]
+    if n:
+        result = solve_fn(scene_id, np.asarray(qc, dtype=np.float64).reshape(n, -1), np.asarray(goals, dtype=np.float64).reshape(n, -1, 16),
+                          n_goals, standoff, base_pos, Q0.reshape(n, ndof, T))
+    else:
+        result = (np.empty((0, ndof, T)), np.empty((0, ndof, T - 1)), np.empty(0), np.empty(0, np.int32), np.empty(0, np.int32))
+    if not gather or world == 1:
+        return (mine,) + tuple(result)
+    return gather_results(mine, result, B, rank, world, group, assignment)
+
+
+def solve_sharded(solve_fn: Callable[..., tuple], scene_id, qc, goals, n_goals, standoff, base_pos, Q0,
+                  rank: int, world: int, group=None, gather: bool = True, assignment: Optional[np.ndarray] = None):
+    """Solve this rank's shard with `solve_fn` (SolverHandle.solve_batch signature) and, if `gather`,
+    all_gather the results so every rank returns the full batch in the original order.
+
+    The argument arrays cover the WHOLE batch (every rank picks its rows); solve_local_shard takes a rank's rows only.
+    The caller is responsible for having uploaded the scenes its shard refers to on this rank.
+    """
+    scene_id = np.asarray(scene_id, dtype=np.int32)
+    B = scene_id.shape[0]
+    qc = np.asarray(qc, dtype=np.float64).reshape(B, -1)
+    goals = np.asarray(goals, dtype=np.float64).reshape(B, -1, 16)
+    n_goals = np.broadcast_to(np.asarray(n_goals, dtype=np.int32), (B,))
+    base_pos = np.broadcast_to(np.asarray(base_pos, dtype=np.float64).reshape(-1, 3), (B, 3))
+    Q0 = np.asarray(Q0, dtype=np.float64)
+    so = None if standoff is None else np.broadcast_to(np.asarray(standoff, dtype=np.float64).reshape(-1, 16), (B, 16))
+    mine = _shard_indices(B, world, assignment)[rank]
+    return solve_local_shard(solve_fn, mine, scene_id[mine], qc[mine], goals[mine], n_goals[mine],
+                             None if so is None else so[mine], base_pos[mine], Q0[mine], B, rank, world, group, gather, assignment)
 
 
 def merge_batches(batches: Sequence[tuple]):

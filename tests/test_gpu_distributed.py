@@ -1,6 +1,8 @@
-"""GPU: the multi-rank path over RCCL.  One GPU box has one device, so the two ranks of this smoke test share it;
-RCCL may refuse two ranks on one device, in which case the test is skipped with its message (the 8-GPU run is the
-driver's)."""
+"""GPU: the multi-rank path.  One GPU box has one device, so the ranks of these tests share it: with gloo as the backend
+of the (single, out-of-the-solve) collective the whole N > 1 path runs with the HIP solver on every rank -- scene-grouped
+shards, one SolverHandle per rank, all_gather of the results -- and must reproduce a single-process solve bit for bit.
+The RCCL smoke test needs one device per rank: RCCL refuses two ranks on one device, in which case that test is skipped
+with RCCL's message (the 8-GPU run is the driver's)."""
 import os
 import subprocess
 import sys
@@ -61,3 +63,84 @@ def test_two_ranks_all_gather_over_rccl(tmp_path):
     import json
     r = json.loads(line[7:])
     assert r["n"] == 12 and r["equal"]
+
+
+WORKER_GLOO = textwrap.dedent('''
+    import os, sys, json
+    import numpy as np
+    sys.path.insert(0, os.environ["GTO_ROOT"]); sys.path.insert(0, os.path.join(os.environ["GTO_ROOT"], "tests"))
+    import torch, torch.distributed as dist
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from grasptrajopt_amd import _capi, synthetic as syn
+    from grasptrajopt_amd.parallel import shard_by_scene, solve_sharded
+    from helpers import Problem
+    from oracle import oracle
+    n_sc, SG = 16, 8
+    B = n_sc * SG
+    prob = Problem("panda", B=B, scene_seed=2, n=40, res=0.056)
+    opts = oracle.reference_opts(max_iter=14)
+    h = _capi.SolverHandle(prob.desc, prob.cfg["link_ee"], prob.cfg["link_gripper"], opts, device=0)   # this rank's own handle
+    prob.finish(h.eval_fk)
+    scenes = [syn.make_scene(50 + s, n=40, res=0.056) for s in range(n_sc)]
+    sid = np.repeat(np.arange(n_sc, dtype=np.int32), SG)
+    owner = shard_by_scene(sid, world)
+    for s in np.unique(sid[owner == rank]):          # a scene's field lives on exactly one rank
+        sc = scenes[int(s)]
+        h.set_scene(int(s), sc.c_all, sc.c_obs, sc.shape, sc.origin, sc.res)
+    idx, Q, dQ, f, it, st = solve_sharded(h.solve_batch, sid, prob.qc, prob.goals, 1, prob.S, prob.base, prob.Q0, rank=rank,
+                                          world=world, assignment=owner)
+    scenes_here = int(len(np.unique(sid[owner == rank])))
+    if rank == 0:
+        for s in range(n_sc):
+            sc = scenes[s]
+            h.set_scene(s, sc.c_all, sc.c_obs, sc.shape, sc.origin, sc.res)
+        ref = h.solve_batch(sid, prob.qc, prob.goals, 1, prob.S, prob.base, prob.Q0)
+        eq = all(bool(np.array_equal(a, b)) for a, b in zip((Q, dQ, f, it, st), ref))
+        print("RESULT", json.dumps({"n": int(len(idx)), "equal": eq, "scenes_on_rank0": scenes_here, "iters_distinct": int(len(set(it.tolist()))),
+                                    "world": world}))
+    dist.barrier()
+    h.close()
+    dist.destroy_process_group()
+''')
+
+
+def _run_ranks(script, nproc, port, timeout=600, extra_env=None):
+    env = dict(os.environ, GTO_ROOT=ROOT, MASTER_ADDR="127.0.0.1", **(extra_env or {}))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(script)]
+    return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_ranks_on_one_device_hip_solver_equals_single_process(tmp_path, world):
+    """The N > 1 path with the HIP solver on every rank: `world` processes share the one device, gloo carries the single
+    all_gather, 16 scenes x 8 grasps are grouped by scene onto the ranks (every field on exactly one rank, its own handle);
+    every rank's gathered result equals rank 0's single-process solve of all 128 instances bit for bit."""
+    script = tmp_path / "worker_gloo.py"
+    script.write_text(WORKER_GLOO)
+    res = _run_ranks(script, world, 29741 + world)
+    out = res.stdout + res.stderr
+    assert res.returncode == 0, out[-3000:]
+    import json
+    r = json.loads([l for l in out.splitlines() if l.startswith("RESULT")][0][7:])
+    assert r["world"] == world and r["n"] == 128 and r["equal"]
+    assert 0 < r["scenes_on_rank0"] < 16 and r["iters_distinct"] > 1
+
+
+def test_bench_two_ranks_dry_run_on_one_device():
+    """bench.py's N > 1 code path (rank environment, barrier + max-over-ranks timing, scene-sharded leg with its gather),
+    run as the driver would launch it but with gloo and both ranks on the one device: the JSON line says n_gpus 2, the
+    scene-sharded leg returned every instance in order, the lanes' results are reproducible."""
+    import json
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--same-device", "--steps", "8", "--warmup", "1",
+           "--merge", "2", "--repeats", "2", "--scenes-per-gpu", "6", "--no-cpu-baseline"]
+    res = subprocess.run(cmd, env=dict(os.environ, MASTER_ADDR="127.0.0.1"), capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, (res.stdout + res.stderr)[-3000:]
+    d = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["steps"] == 8 and d["scaling"] == "weak"
+    ss = d["scene_sharded"]
+    assert ss["instances"] == 2 * 6 * 8 and ss["all_instances_returned"] and ss["own_shard_round_trip_exact"]
+    assert ss["max_joint_limit_violation"] <= 1e-8
+    assert d["pipeline"]["lane_results_reproducible_alone"] and d["quality"]["gate"] == "pass"

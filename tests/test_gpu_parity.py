@@ -870,6 +870,76 @@ def _invariants(desc, qc, Q0, Q, dQ):
     np.testing.assert_allclose(Q[:, :, :-1] + (10.0 / (T - 1)) * dQ, Q[:, :, 1:], atol=1e-15)
 
 
+def test_baseline_config3_one_gpus_share_256_scenes_resident(capi, oracle_mod):
+    """BASELINE configs[3] at the size ONE of its eight GPUs carries: 256 different 128^3 scenes resident at once (fields,
+    voxel records and distance fields of every scene: 148 MB each, 37.9 GB in all -- one field per scene as in
+    gto/gto_models.py:155-171), 8 grasps per scene = 2048 instances of the Panda-5k workload in ONE solve call through
+    solve_local_shard, every instance of a call reading another field.  Resident memory against hipMemGetInfo, invariants
+    and the objective recomputed on all 2048, the oracle on a sample of six instances from six scenes."""
+    import torch
+    from grasptrajopt_amd import synthetic as syn
+    from grasptrajopt_amd.parallel import shard_by_scene, solve_local_shard
+    from grasptrajopt_amd.robot_desc import load_builtin
+    cfg = cfg_of("panda")
+    d = load_builtin("panda_5k")
+    opts = oracle_mod.reference_opts(max_iter=100)
+    h = capi.SolverHandle(d, cfg["link_ee"], cfg["link_gripper"], opts, device=0, n_gripper_points=100)
+    NS, G, T, N = 256, 8, 50, 128
+    free0 = torch.cuda.mem_get_info(0)[0]
+    moving = d.link_is_moving()[d.point_link]
+    RT, qg, keep = [], [], {}
+    sel = [5, 411, 1000, 1337, 1799, 2047]
+    for s in range(NS):
+        sc = syn.make_scene(100 + s, n=N, res=2.24 / N)
+        h.set_scene(s, sc.c_all, sc.c_obs, sc.shape, sc.origin, sc.res)
+        if s in [i // G for i in sel]:
+            keep[s] = sc
+
+        def cc(q, s=s):
+            _, _, val, _ = h.eval_points(s, q, [0.0, 0.0, 0.0], use_obs=True)
+            return (val * moving[None, :]).sum(axis=1)
+        r, q = syn.make_goals(d, h.eval_fk, cfg["link_ee"], G, seed=7000 + s, collision_cost=cc)
+        RT.append(r)
+        qg.append(q)
+    resident = free0 - torch.cuda.mem_get_info(0)[0]
+    per_scene = 2 * (N ** 3) * (4 + 32 + 1)  # c_all / c_obs: float32 field + 32-B voxel record + distance byte per voxel
+    assert NS * per_scene <= resident <= 1.08 * NS * per_scene + (1 << 30), (resident / 1e9, NS * per_scene / 1e9)
+    assert 37.0 <= NS * per_scene / 1e9 <= 40.5
+    RT, qg = np.concatenate(RT), np.concatenate(qg)
+    nI = NS * G
+    sid = np.repeat(np.arange(NS, dtype=np.int32), G)
+    qc = np.tile(np.array(cfg["default_pose"], dtype=np.float64), (nI, 1))
+    Q0 = np.stack([syn.make_seed(qc[i], qg[i], T, d.param_index) for i in range(nI)])
+    S = np.tile(syn.standoff_pose(-0.1, cfg["axis_standoff"]).reshape(1, 16), (nI, 1))
+    base = np.zeros((nI, 3))
+    owner = shard_by_scene(sid, 1)
+    idx, Q, dQ, f, it, st = solve_local_shard(h.solve_batch, np.arange(nI), sid, qc, RT.reshape(nI, 1, 16), np.ones(nI, np.int32), S, base, Q0,
+                                              B=nI, rank=0, world=1, assignment=owner)
+    np.testing.assert_array_equal(idx, np.arange(nI))
+    _invariants(d, qc, Q0, Q, dQ)
+    assert set(np.unique(st).tolist()) <= {0, 1} and (st == 0).mean() > 0.98
+    # the objective the solver reports is the objective of the trajectory it returns, on every instance; never above the seed's
+    for lo in range(0, nI, 512):
+        sl = slice(lo, lo + 512)
+        fg, fo_, fv, _ = h.eval_objective(sid[sl], RT[sl].reshape(-1, 1, 16), 1, S[sl], base[sl], Q[sl])
+        np.testing.assert_allclose(fg + fo_ + fv, f[sl], rtol=1e-9, atol=1e-12)
+        seed = Q0[sl].copy()
+        oi = d.opt_index
+        seed[:, oi] = np.clip(seed[:, oi], d.lower[oi][None, :, None], d.upper[oi][None, :, None])
+        seed[:, :, :2] = qc[sl][:, :, None]
+        sg, so_, sv, _ = h.eval_objective(sid[sl], RT[sl].reshape(-1, 1, 16), 1, S[sl], base[sl], seed)
+        assert (f[sl] <= (sg + so_ + sv) * (1 + 1e-12)).all()
+    o = oracle_mod.Oracle(d, cfg["link_ee"], cfg["link_gripper"], opts, n_gripper_points=100)
+    for s, sc in keep.items():
+        o.set_scene(s, sc.c_all, sc.c_obs, sc.shape, sc.origin, sc.res)
+    Qo, _, fo, ito, sto = o.solve_batch(sid[sel], qc[sel], RT[sel].reshape(-1, 1, 16), 1, S[sel], base[sel], Q0[sel])
+    np.testing.assert_array_equal(it[sel], ito)
+    np.testing.assert_array_equal(st[sel], sto)
+    np.testing.assert_allclose(Q[sel], Qo, rtol=0, atol=1e-6)
+    np.testing.assert_allclose(f[sel], fo, rtol=1e-7)
+    h.close()
+
+
 @pytest.mark.parametrize("mode", [0, 1])
 def test_fetch_shelf_256_instances(capi, oracle_mod, mode):
     """BASELINE configs[2]: Fetch arm, shelf scene, 256 (scene, grasp) instances, T = 50.  Shelf scenes are planned from
