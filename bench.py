@@ -109,6 +109,7 @@ def main():
     ap.add_argument("--shelf", action="store_true", help="shelf scene (boards and walls around the objects) instead of a table top")
     ap.add_argument("--mode", choices=["rounds", "single"], default="rounds", help="solver mode (include/gto_solver.h GTO_MODE_*)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-next-rows", action="store_true", help="skip the next_rows object (IK, depth field, seed scoring, base placement, one plan_goalset call)")
     ap.add_argument("--merged-launches-only", action="store_true",
                     help="skip the one-batch-per-launch passes (serial latency, host API): every launch of the run then has the "
                          "timed region's size, which is what the per-launch PMC averages of tools/pmc_pass.sh need")
@@ -548,6 +549,17 @@ def main():
                             "quality": quality_block(desc, cfg, h, 0, Qo, RT[:B], Q0[:B], ito.astype(np.int64), sto, args.max_iter),
                             "quality_gpu_same_instances": quality_block(desc, cfg, h, 0, Qsol[:B], RT[:B], Q0[:B], iters[:B], status[:B], args.max_iter)}
 
+        # ---- the rows SURVEY.md 8(f) marks "next" and one plan_goalset call, with an oracle spot check each (N = 1 only)
+        next_rows = None
+        if not args.no_cpu_baseline and world == 1 and not args.no_next_rows:
+            import importlib.util
+            spec = importlib.util.spec_from_file_location("gto_next_rows", os.path.join(ROOT, "tools", "next_rows.py"))
+            nr = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(nr)
+            t_nr = time.perf_counter()
+            next_rows = nr.measure(device=local_rank, scene=sc if (args.grid == 128 and not fetch and not args.shelf) else None)
+            next_rows["seconds"] = round(time.perf_counter() - t_nr, 2)
+
         out = {
             "metric": "grasp trajectories/sec", "value": round(value, 2), "unit": "trajectories/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -592,7 +604,7 @@ def main():
             "status_counts": {str(k): int((status == k).sum()) for k in np.unique(status)},
             "quality": quality,
             "reference_published": "0.098 trajectories/s (Panda tabletop, IPOPT on unknown CPU; BASELINE.md section 1)",
-            "roofline": roofline, "cpu_baseline": cpu_baseline, "scene_sharded": scene_sharded,
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "scene_sharded": scene_sharded, "next_rows": next_rows,
         }
         print(json.dumps(out))
     for ln in reversed(lanes):  # the owner of the shared scene goes last

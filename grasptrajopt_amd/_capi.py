@@ -110,8 +110,13 @@ def _preload_hip_runtime():
     """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so with the SONAME of the system
     copy (libamdhip64.so.7) but link it by file name: if libgto_hip.so pulls in /opt/rocm's copy first and torch is
     imported afterwards, a second runtime is mapped next to it and finds no devices ("No HIP GPUs are available").
-    Mapping torch's copy first (when there is a torch) makes every later lookup, by SONAME or by file, land on it."""
+    Mapping torch's copy first (when a torch is installed) makes every later lookup, by SONAME or by file, land on it.
+    Only done if the bundled copy has the SONAME of the runtime the library was linked against (same ABI; otherwise a
+    warning and the system runtime); GTO_PRELOAD_TORCH_HIP=0 switches it off for processes that never import torch and
+    want /opt/rocm's own copy."""
     import importlib.util
+    if os.environ.get("GTO_PRELOAD_TORCH_HIP") == "0":
+        return None
     try:
         spec = importlib.util.find_spec("torch")
     except (ImportError, ValueError):
@@ -119,9 +124,31 @@ def _preload_hip_runtime():
     for loc in (spec.submodule_search_locations if spec and spec.submodule_search_locations else []):
         cand = os.path.join(loc, "lib", "libamdhip64.so")
         if os.path.exists(cand):
+            if not _same_soname(cand, "/opt/rocm/lib/libamdhip64.so"):
+                import warnings
+                warnings.warn(f"torch bundles a HIP runtime ({cand}) with another SONAME than /opt/rocm's: not preloading it; "
+                              "import torch AFTER grasptrajopt_amd may then fail to find the GPU")
+                return None
             C.CDLL(cand, mode=C.RTLD_GLOBAL)
             return cand
     return None
+
+
+def _soname(path):
+    """DT_SONAME of an ELF shared object (None if it cannot be read)."""
+    try:
+        import re
+        import subprocess
+        out = subprocess.run(["readelf", "-d", os.path.realpath(path)], capture_output=True, text=True, timeout=10).stdout
+        m = re.search(r"SONAME\)\s+Library soname: \[([^\]]+)\]", out)
+        return m.group(1) if m else None
+    except Exception:
+        return None
+
+
+def _same_soname(a, b):
+    sa, sb = _soname(a), _soname(b)
+    return sa is None or sb is None or sa == sb  # unreadable: do as before
 
 
 def load_library(path: Optional[str] = None):

@@ -161,19 +161,24 @@ static int validate_opts(const gto_solver_opts* o, std::string& why) {
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is process-wide per kernel: a handle for a smaller robot or goal set must
 // never lower what an earlier handle launches with.  One high-water mark per kernel, only ever raised.
+// The attribute belongs to the (function, device) pair of the CURRENT device: the marks are kept per device, and every
+// caller has done hipSetDevice(h->device) before.
 static hipError_t raise_dynamic_lds(const void* kernel, size_t bytes) {
+  struct Mark { int device; const void* kernel; size_t bytes; };
   static std::mutex mu;
-  static std::vector<std::pair<const void*, size_t>> marks;
+  static std::vector<Mark> marks;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
   std::lock_guard<std::mutex> lock(mu);
   for (auto& m : marks)
-    if (m.first == kernel) {
-      if (bytes <= m.second) return hipSuccess;
+    if (m.kernel == kernel && m.device == dev) {
+      if (bytes <= m.bytes) return hipSuccess;
       const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-      if (e == hipSuccess) m.second = bytes;
+      if (e == hipSuccess) m.bytes = bytes;
       return e;
     }
   const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-  if (e == hipSuccess) marks.emplace_back(kernel, bytes);
+  if (e == hipSuccess) marks.push_back({dev, kernel, bytes});
   return e;
 }
 
@@ -910,11 +915,7 @@ static int check_scene_ids_host(gto_handle* h, const int32_t* ids, int B) {
 // task, the largest that keeps two workgroups of eight waves (one of sixteen) on a CU.
 template <int NW>
 static int launch_traj_nw(gto_handle* h, hipStream_t st, const TrajArgs& a, const SolveParams& sp, size_t lds) {
-  static size_t attr_set = 0;  // process-wide per instantiation: only ever raised
-  if (lds > attr_set) {
-    HIPCHK(h, hipFuncSetAttribute((const void*)k_traj_solve<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = lds;
-  }
+  HIPCHK(h, raise_dynamic_lds((const void*)k_traj_solve<NW>, lds));
   const int grid = 8 * ((a.B + 7) / 8);
   hipLaunchKernelGGL(k_traj_solve<NW>, dim3(grid), dim3(64 * NW), lds, st, h->d_rb, h->d_px, h->d_py, h->d_pz, h->d_chunks,
                      h->d_scenes, a, sp);
@@ -1293,6 +1294,7 @@ int gto_eval_base_objective(gto_handle* h, int32_t B, int32_t n_max, const int32
   if (!h) return GTO_ERR_INVALID_ARG;
   if (B < 0) return fail(h, GTO_ERR_INVALID_ARG, "B must be >= 0");
   if (n_max < 1 || n_max > GTO_MAX_BASE_GOALS) return fail(h, GTO_ERR_UNSUPPORTED, "n_max must be in [1, 32]");
+  if (h->np != GTO_NB) return fail(h, GTO_ERR_UNSUPPORTED, "gto_eval_base_objective handles up to eight optimised joints");
   if (B == 0) return GTO_OK;
   if (!n_goals || !y || !q || !goals || !cost_out) return fail(h, GTO_ERR_INVALID_ARG, "null input array");
   for (int b = 0; b < B; ++b)
@@ -1706,10 +1708,10 @@ int gto_depth_sdf_cost(int device, const float* depth, int32_t H, int32_t W, con
     const int tx = (W + GTO_BVH_TILE_W - 1) / GTO_BVH_TILE_W, ty = (H + GTO_BVH_TILE_H - 1) / GTO_BVH_TILE_H;
     int P = 1;
     while (P < tx || P < ty) P <<= 1;
-    if (P > 1024) {
-      cleanup();
-      return fail(nullptr, GTO_ERR_UNSUPPORTED, "gto_depth_sdf_cost: depth image larger than 8192 x 4096");
-    }
+    if (P > 1024) {  // more tiles per side than k_bvh_up's single workgroup builds: the exhaustive search serves such images
+      hipLaunchKernelGGL(k_depth_sdf, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, 0, d_px, d_py, d_pz, (int)N, d_depth, H, W,
+                         d_mats, d_mats + 34, d_q, (long)nq, epsilon, w_inside, d_sdf, d_in, d_cost);
+    } else {
     double* d_boxes = (double*)dalloc((size_t)(2 * P * P) * 6 * sizeof(double));
     if (!d_boxes) {
       cleanup();
@@ -1749,6 +1751,7 @@ int gto_depth_sdf_cost(int device, const float* depth, int32_t H, int32_t W, con
       DCHK(hipMemcpy(st, d_stats, sizeof st, hipMemcpyDeviceToHost));
       fprintf(stderr, "[gto] depth field search: %lld queries, nodes popped per query %.1f, leaves per query %.1f, loop iterations per wave %.1f\n",
               (long long)nq, (double)st[0] / nq, (double)st[1] / nq, (double)st[2] / ((nq + 63) / 64));
+    }
     }
   }
   DCHK(hipGetLastError());

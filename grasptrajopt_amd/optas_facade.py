@@ -245,13 +245,17 @@ class CasADiSolver(Solver):
     def ensure_scene(self) -> int:
         """Upload the cost fields of the current parameters (once per reset_parameters) and return the scene id:
         seed scoring (gto/gto_planner.py:208) and the solve read the same resident scene."""
-        if getattr(self, "_scene_dirty", True):
+        # the handle (and its scene 0) is shared by every solver with the same role / links / T on this robot model: another
+        # planner's upload replaces the field under this solver, so "already uploaded" is only true while this solver was the
+        # last one to write the scene
+        if getattr(self, "_scene_dirty", True) or getattr(self._handle, "_scene0_owner", None) is not self:
             robot, p = self.opt.robot, self._p_dict
             shape, origin, res = robot.field_geometry()
             # parameters that were never set are zeros (optas/mx_container.py:121): plan() leaves sdf_cost_all out
             c_all = p.get("sdf_cost_all", np.zeros(int(np.prod(shape))))
             c_obs = p.get("sdf_cost_obstacle", np.zeros(int(np.prod(shape))))
             self._handle.set_scene(self.SCENE_ID, c_all, c_obs, shape, origin, res)
+            self._handle._scene0_owner = self
             self._scene_dirty = False
         return self.SCENE_ID
 

@@ -1121,6 +1121,20 @@ def test_mobile_fetch_ten_joints_matches_oracle(capi, oracle_mod, T, off, n_goal
     # the entry points that only exist for up to eight optimised joints say so
     with pytest.raises(capi.GTOError, match="eight"):
         h.solve_ik_batch(None, prob.qc, prob.goals[:, 0], None, 5)
+    with pytest.raises(capi.GTOError, match="eight"):
+        h.solve_base_batch(prob.qc, prob.goals[:, :1].reshape(-1, 1, 4, 4))
+    with pytest.raises(capi.GTOError, match="eight"):  # ... the evaluation twin of the base solve as well (8-joint LDS layout)
+        h.eval_base_objective(np.zeros((6, 3)), prob.qc.reshape(6, 1, -1), prob.goals[:, :1].reshape(-1, 1, 4, 4), effort_weight=0.0)
+    # seed scoring and point look-ups run the kinematics of all ten joints (screw table sized for the 16-wide blocks)
+    pc_g, dist_g = h.plan_cost(0, prob.Q0, prob.base[0])
+    pc_o, dist_o = o.plan_cost(0, prob.Q0, prob.base[0])
+    np.testing.assert_allclose(pc_g, pc_o, rtol=1e-12, atol=1e-300)
+    np.testing.assert_allclose(dist_g, dist_o, rtol=1e-14)
+    xg, og, vg, _ = h.eval_points(0, prob.qgoal[:, 0], prob.base[0], use_obs=True)
+    xo, oo, vo, _ = o.eval_points(0, prob.qgoal[:, 0], prob.base[0], use_obs=True)
+    np.testing.assert_allclose(xg, xo, rtol=0, atol=1e-12)
+    np.testing.assert_array_equal(og, oo)
+    np.testing.assert_array_equal(vg, vo)
     h.set_mode(1)
     with pytest.raises(capi.GTOError, match="eight"):
         h.solve_batch(*prob.solve_args())
