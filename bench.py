@@ -475,6 +475,49 @@ def main():
         gate_ok = gate_ok and (quality["stopping_tolerance_check"]["f_excess_rel_max_converged"] or 0.0) <= 1e-4
         if not args.shelf:
             gate_ok = gate_ok and quality["plan_cost_le_seed_frac"] >= 0.95
+        # ---- what the north star's gradient choice buys: the first batch again with GTO_GRAD_ZERO, the reference-faithful
+        # obstacle gradient (CasADi differentiates neither floor() nor the parametric gather: SURVEY.md Appendix B-1), same
+        # statistics on the same 64 instances next to the shipped GTO_GRAD_CENTRAL_DIFF
+        gm0 = opts.grad_mode
+        same = (0, qc[:B], RT[:B].reshape(B, 1, 16), 1, S[:B], base[:B], Q0[:B])
+        by_grad = {}
+        for name_, gm in (("central_diff", _capi.GTO_GRAD_CENTRAL_DIFF), ("zero", _capi.GTO_GRAD_ZERO)):
+            h.set_opts(grad_mode=gm)
+            Qg_, _, fg_, itg_, stg_ = h.solve_batch(*same)
+            qb_ = quality_block(desc, cfg, h, 0, Qg_, RT[:B], Q0[:B], itg_.astype(np.int64), stg_, args.max_iter)
+            by_grad[name_] = {k_: qb_[k_] for k_ in ("goal_ok_frac", "goal_err_pos_max_m", "goal_err_rot_max_deg", "plans_in_collision_frac",
+                                                      "plan_cost_le_seed_frac", "max_joint_limit_violation")}
+            by_grad[name_].update({"f_mean": round(float(fg_.mean()), 5), "iters_mean": round(float(itg_.mean()), 2)})
+        h.set_opts(grad_mode=gm0)
+        quality["by_obstacle_gradient"] = dict(by_grad, what="first batch (64 instances) solved with each grad_mode; `zero` is what reaches IPOPT "
+                                                             "in the reference (value only), `central_diff` is shipped (gto/sdf_callback.py:90-114 numerics)")
+        gate_ok = gate_ok and by_grad["central_diff"]["plans_in_collision_frac"] <= by_grad["zero"]["plans_in_collision_frac"]
+        # ---- goal sets of eight, what plan_goalset is called with (examples/pybullet_gto_planning.py:291): instance b gets
+        # eight grasps of the lane's list, its seed is the least colliding / shortest of the eight interpolated plans
+        # (gto/gto_planner.py:197-213), the goal error is taken against the goal the solver ends at (arg-min of the set)
+        G8 = 8
+        if NB >= B * G8 and not args.shelf:
+            RT8 = RT[:B * G8].reshape(B, G8, 4, 4)
+            seeds8 = Q0[:B * G8].reshape(B, G8, ndof, T)
+            pick = np.zeros(B, dtype=np.int64)
+            for b_ in range(B):
+                pc_, pd_ = h.plan_cost(0, seeds8[b_], [0.0, 0.0, 0.0])
+                pick[b_] = int(np.lexsort((pd_, pc_))[0])
+            Q08 = seeds8[np.arange(B), pick]
+            args8 = (0, qc[:B], RT8.reshape(B, G8, 16), G8, S[:B], base[:B], Q08)
+            h.solve_batch(*args8)
+            t8 = time.perf_counter()
+            Q8, _, f8, it8, st8 = h.solve_batch(*args8)
+            t8 = time.perf_counter() - t8
+            _, _, _, am8 = h.eval_objective(0, RT8.reshape(B, G8, 16), G8, S[0].reshape(4, 4), [0.0, 0.0, 0.0], Q8)
+            qb8 = quality_block(desc, cfg, h, 0, Q8, RT8[np.arange(B), am8], Q08, it8.astype(np.int64), st8, args.max_iter)
+            quality["goal_sets_of_8"] = dict({k_: qb8[k_] for k_ in ("goal_ok_frac", "goal_err_pos_max_m", "goal_err_rot_max_deg", "plans_in_collision_frac",
+                                                                       "plan_cost_le_seed_frac", "max_joint_limit_violation")},
+                                             instances=B, goals_per_instance=G8, iters_mean=round(float(it8.mean()), 2), iters_max=int(it8.max()),
+                                             f_mean=round(float(f8.mean()), 5), ms_one_call_host_api=round(1e3 * t8, 3),
+                                             trajectories_per_s_one_call=round(B / t8, 1), goals_reached_distinct=int(len(np.unique(am8))),
+                                             what="64 instances x goal sets of 8 grasps (plan_goalset's call shape), one solver call through the host-pointer API")
+            gate_ok = gate_ok and qb8["max_joint_limit_violation"] <= 1e-8
         quality["gate"] = "pass" if gate_ok else "FAIL"
         if not gate_ok:
             rc = 3

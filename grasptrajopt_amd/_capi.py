@@ -103,6 +103,10 @@ def pack_robot_desc(desc: RobotDesc, link_ee: str, link_gripper: str,
     return c, keep
 
 
+# include/gto_solver.h
+GTO_GRAD_CENTRAL_DIFF, GTO_GRAD_ZERO = 0, 1
+GTO_STATUS_CONVERGED, GTO_STATUS_MAX_ITER, GTO_STATUS_NUMERICAL = 0, 1, 2
+
 _lib = None
 
 
