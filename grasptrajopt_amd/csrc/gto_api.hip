@@ -21,6 +21,9 @@
 #include "gto_traj.h"
 
 #define GTO_VERSION 1000
+#ifndef GTO_OBS_DEEP_PD
+#define GTO_OBS_DEEP_PD 8
+#endif
 
 static std::string g_create_error;
 
@@ -65,6 +68,7 @@ struct gto_handle {
   // launches with few instances in flight (more work, fewer dependent rounds); after an accepted evaluation once at most
   // `spec_deep` instances are in flight (the GPU is nearly idle then: every candidate is free)
   int spec_rej = 4, spec_acc = 3, spec_deep = 6, spec_kmax = 1;
+  int obs_deep = 1;   // GTO_OBS_DEEP: launches with few instances in flight use the obstacle kernel variant with deep gather batches
   int spec_few = 16;  // GTO_SPEC_FEW: speculation starts once at most this many instances are in flight: before that the GPU is full and every extra evaluation costs time
   int dbg_cut = 0;
   int dist_relax = 0;  // GTO_DIST_RELAX: build the distance fields by relaxation sweeps instead of the separable passes
@@ -215,6 +219,7 @@ int gto_create(const gto_robot_desc* d, const gto_solver_opts* opts, int device,
   if (const char* e = getenv("GTO_SPEC_ACC")) h->spec_acc = std::max(1, std::min(GTO_KSPEC, atoi(e)));
   if (const char* e = getenv("GTO_SPEC_DEEP")) h->spec_deep = std::max(0, atoi(e));
   if (const char* e = getenv("GTO_SPEC_FEW")) h->spec_few = std::max(0, atoi(e));
+  if (const char* e = getenv("GTO_OBS_DEEP")) h->obs_deep = atoi(e) ? 1 : 0;
   if (const char* e = getenv("GTO_OBS_INTERLEAVE")) h->obs_interleave = std::max(0, std::min(2, atoi(e)));
   if (const char* e = getenv("GTO_DIST_RELAX")) h->dist_relax = atoi(e) ? 1 : 0;
   if (const char* e = getenv("GTO_DEBUG_CUT")) h->dbg_cut = atoi(e);
@@ -483,6 +488,7 @@ int gto_create(const gto_robot_desc* d, const gto_solver_opts* opts, int device,
     const size_t lds = std::min<size_t>((size_t)lay.total_doubles * sizeof(double) + h->dbg_extra_lds, 160 * 1024);
     if ((size_t)lay.total_doubles * sizeof(double) > 150 * 1024) { gto_destroy(h); return fail(nullptr, GTO_ERR_UNSUPPORTED, "robot too large for the obstacle kernel's LDS"); }
     hipError_t e1 = raise_dynamic_lds(w ? (const void*)k_obstacle_gram<16> : (const void*)k_obstacle_gram<GTO_NB>, lds);
+    if (!w && e1 == hipSuccess) e1 = raise_dynamic_lds((const void*)k_obstacle_gram<GTO_NB, GTO_OBS_DEEP_PD>, lds);
     hipError_t e2 = w ? raise_dynamic_lds((const void*)k_lm_step_wide<16>, h->lm_lds) : raise_dynamic_lds((const void*)k_lm_step<4, 1>, h->lm_lds);
     if (!w && e2 == hipSuccess) e2 = raise_dynamic_lds((const void*)k_lm_step<8, GTO_KSPEC>, lm_lds_bytes(opts->T, h->spec_kmax));
     if (e1 != hipSuccess || e2 != hipSuccess) {
@@ -864,7 +870,7 @@ static BatchPtrs make_ptrs(gto_handle* h, const int32_t* scene_id, const double*
 static inline int obstacle_grid(int B, int nG) { return 8 * ((B + 7) / 8) * nG; }
 
 static int launch_obstacle(gto_handle* h, hipStream_t st, const BatchPtrs& bp, const SolveParams& sp, int B, int t_begin,
-                           int nT, int fixed_mode, bool timed, bool with_goal_terms = false, int n_jobs = 0, int tg = 0) {
+                           int nT, int fixed_mode, bool timed, bool with_goal_terms = false, int n_jobs = 0, int tg = 0, bool deep = false) {
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (timed) {
     size_t need = (size_t)(h->last_launches + 1) * 2;
@@ -885,8 +891,11 @@ static int launch_obstacle(gto_handle* h, hipStream_t st, const BatchPtrs& bp, c
   const int cap_active = TG * h->rb.n_chunks;
   const ObsLds lay(TG, h->rb.n_frames, h->rb.n_links, cap_active, h->np);
   const size_t lds = (size_t)lay.total_doubles * sizeof(double) + h->dbg_extra_lds;
-  const dim3 grid(n_regular + (with_goal_terms ? (nb + 3) / 4 : 0));
-  if (h->np == GTO_NB)
+  const dim3 grid(n_regular + (with_goal_terms ? (nb + 3) / 4 : 0));  // goal-term jobs: four to a workgroup
+  if (h->np == GTO_NB && deep)  // few instances in flight: the variant that keeps a wave's record gathers in flight together
+    hipLaunchKernelGGL((k_obstacle_gram<GTO_NB, GTO_OBS_DEEP_PD>), grid, dim3(256), lds, st, h->d_rb, h->d_px, h->d_py, h->d_pz, h->d_chunks, h->d_scenes,
+                       bp, sp, B, t_begin, nT, fixed_mode, n_regular, TG, cap_active);
+  else if (h->np == GTO_NB)
     hipLaunchKernelGGL(k_obstacle_gram<GTO_NB>, grid, dim3(256), lds, st, h->d_rb, h->d_px, h->d_py, h->d_pz, h->d_chunks, h->d_scenes, bp, sp,
                        B, t_begin, nT, fixed_mode, n_regular, TG, cap_active);
   else
@@ -1103,7 +1112,7 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
     sp.parity = k & 1;
     // the goal workgroups skip fresh instances themselves: k_lm_init already produced the seed's goal terms
     sp.k_eval = k_prev;
-    if ((rc = launch_obstacle(h, st, bp, sp, B, 2, T - 2, 0, h->profiling, true, in_flight * k_prev, tg))) { rc_loop = rc; break; }
+    if ((rc = launch_obstacle(h, st, bp, sp, B, 2, T - 2, 0, h->profiling, true, in_flight * k_prev, tg, few && h->obs_deep))) { rc_loop = rc; break; }
     if (h->np == GTO_NB) {
       if (few && h->step_nw_few == 8) {
         // few instances in flight: eight waves per instance and candidate trial points ahead of their evaluation
@@ -1133,6 +1142,9 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
             t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3], t[5] - t[4], t[6] - t[5], t[7] - t[6], t[9]);
     fprintf(stderr, "[gto dbg] P2 split (cycles): loads+barrier %lld | b-vector+masks %lld | blocks %lld | e,y+barrier %lld\n", t[28] - t[1], t[29] - t[28], t[30] - t[29], t[2] - t[30]);
     fprintf(stderr, "[gto dbg] fk_mfma_tree (cycles): local %lld | rounds %lld %lld %lld %lld | outputs %lld\n", t[21] - t[20], t[22] - t[21], t[23] - t[22], t[24] - t[23], t[25] - t[24], t[27] - t[25]);
+    // (only with -DGTO_DEBUG_LONGEST_WG: the extra clocks cost the tuned obstacle kernel registers)
+    fprintf(stderr, "[gto dbg] longest regular obstacle workgroup of the call: %lld cycles with %lld surviving chunks | goal-term wavefront of instance 0: %lld cycles\n",
+            t[40] >> 16, t[40] & 0xffff, t[32] - t[31]);
     fprintf(stderr, "[gto dbg] obstacle WG (b=0,t=T-1) cycles: prologue %lld | broad %lld | loop %lld | epilogue %lld | active chunks %lld | prologue up to the chain %lld\n",
             t[11] - t[10], t[12] - t[11], t[13] - t[12], t[14] - t[13], t[15], t[16] - t[10]);
   }

@@ -277,7 +277,8 @@ def test_slots_hand_over_to_waiting_instances(capi, oracle_mod, monkeypatch, slo
                                         ("GTO_STEP_NW_FEW", "4"), ("GTO_DIST_RELAX", "1"), ("GTO_FEW_INSTANCES", "0"),
                                         ("GTO_FEW_INSTANCES", "8"), ("GTO_SPEC_REJ", "1"), ("GTO_SPEC_REJ", "2"), ("GTO_SPEC_REJ", "3"),
                                         ("GTO_SPEC_ACC,GTO_SPEC_DEEP", "4,100000"), ("GTO_SPEC_ACC,GTO_SPEC_DEEP,GTO_SPEC_REJ", "2,100000,1"),
-                                        ("GTO_SPEC_ACC,GTO_SPEC_DEEP,GTO_SPEC_REJ", "1,0,1")])
+                                        ("GTO_SPEC_ACC,GTO_SPEC_DEEP,GTO_SPEC_REJ", "1,0,1"), ("GTO_OBS_DEEP", "0"),
+                                        ("GTO_SPEC_FEW,GTO_SPEC_REJ", "100000,4"), ("GTO_SPEC_FEW", "0")])
 def test_launch_geometry_does_not_change_results(capi, oracle_mod, monkeypatch, knob, value):
     """How the waypoints are dealt to the workgroups of the obstacle kernel (group size, consecutive or interleaved), how
     far the host runs ahead of the GPU, when a call switches to the launches for few instances in flight, and how many
