@@ -323,13 +323,13 @@ int gto_create(const gto_robot_desc* d, const gto_solver_opts* opts, int device,
     for (int i = 0; i < F; ++i) {
       const double* u = rb.axis_unit[i];
       const double K[3][3] = {{0, -u[2], u[1]}, {u[2], 0, -u[0]}, {-u[1], u[0], 0}};
-      double* tab = rb.fk_tab + 64 * i;
+      double* tab = rb.fk_tab + GTO_FK_STRIDE * i;
       for (int a = 0; a < 4; ++a)
         for (int c = 0; c < 4; ++c) {
-          const int e = 4 * a + c;
+          const int e = (4 * a + c) ^ (5 * (i & 3));  // bank placement of the frame's entries (gto_device.h, fkx)
           const double uu = (a < 3 && c < 3) ? u[a] * u[c] : 0.0;
           const double dl = (a == c && a < 3) ? 1.0 : 0.0, hh = (a == 3 && c == 3) ? 1.0 : 0.0;
-          tab[e] = hom(rb.origin[i], a, c);
+          tab[e] = hom(rb.origin[i], c, a);  // transposed: a row-pattern read gives the B operand O^T (gto_device.h, fkx)
           tab[16 + e] = hh + uu;  // M = c0 + cos c1 + sin K
           tab[32 + e] = dl - uu;
           if (rb.joint_type[i] == GTO_JOINT_PRISMATIC) tab[48 + e] = (a < 3 && c == 3) ? u[a] : 0.0;
@@ -338,16 +338,16 @@ int gto_create(const gto_robot_desc* d, const gto_solver_opts* opts, int device,
       if (rb.opt_of_frame[i] >= 0) {
         const int j = rb.opt_of_frame[i];
         rb.opt_frame[j] = i;
-        double* tu = rb.fk_tab + 64 * F + 16 * L + 16 * j;
-        for (int a = 0; a < 3; ++a) tu[4 * a] = u[a];
-        tu[4 * 3 + 1] = 1.0;
+        double* tu = rb.fk_tab + GTO_FK_STRIDE * F + 16 * L;
+        for (int a = 0; a < 3; ++a) tu[fkx(j, 4 * a)] = u[a];
+        tu[fkx(j, 4 * 3 + 1)] = 1.0;
       }
     }
     for (int l = 0; l < L; ++l)
       for (int a = 0; a < 4; ++a)
-        for (int c = 0; c < 4; ++c) rb.fk_tab[64 * F + 16 * l + 4 * a + c] = hom(rb.vis_origin[l], a, c);
+        for (int c = 0; c < 4; ++c) rb.fk_tab[GTO_FK_STRIDE * F + fkx(l, 4 * a + c)] = hom(rb.vis_origin[l], a, c);
     const int n = d->n_opt;
-    double* tI = rb.fk_tab + 64 * F + 16 * L + 16 * n;
+    double* tI = rb.fk_tab + GTO_FK_STRIDE * F + 16 * L + 16 * n;
     for (int l = 0; l < L; ++l) tI[l] = rb.link_frame[l];
     for (int j = 0; j < n; ++j) {
       tI[L + j] = rb.opt_frame[j];

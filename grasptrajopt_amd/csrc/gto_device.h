@@ -17,6 +17,17 @@
 #define GTO_NB 8            // padded block size of the per-waypoint normal-equation blocks
 #define GTO_GRAM 28         // 21 (6x6 symmetric wrench Gram) + 6 (c * wrench) + 1 (c^2)
 #define GTO_WAVE 64
+// LDS bank layout of the forward kinematics (fk_mfma_tree).  A wavefront works on four frames at once, one per 16-lane
+// block of the matrix-core instruction, and every lane reads or writes ONE entry of its frame's 4x4 matrix (entry
+// e = 4 row + col).  The LDS serves an 8-byte access 16 lanes at a time (32 banks x 4 B): sixteen consecutive lanes touch
+// one ROW of four matrices, or -- the transposed read that turns a result into an A operand -- one COLUMN.  With 16
+// doubles per frame every frame starts on bank 0 and both patterns are four-way conflicts (97 % of the obstacle kernel's
+// bank-conflict cycles were here).  Frame f therefore keeps entry e at e ^ 5 (f & 3): the row r of the four frames of a
+// wave then lands on four different quarters of the banks, and so does the column c (XOR with 0, 5, 10, 15 moves both the
+// row bits and the column bits of e).  The operand tables (per frame O^T, c0, c1, K; per link Vo; per joint U) use the
+// same placement, and hold the origin transposed so that all their reads are row reads.
+#define GTO_FK_STRIDE 64
+__host__ __device__ inline int fkx(int f, int e) { return 16 * f + (e ^ (5 * (f & 3))); }
 
 struct RobotDev {
   int32_t n_frames, ndof, n_opt, n_links, n_points, n_chunks, n_gripper_points;
@@ -27,7 +38,7 @@ struct RobotDev {
   // per frame the origin O, c0 = h + u u^T, c1 = delta - u u^T, K = [u]x (prismatic: the axis in the
   // translation column); then per link its visual origin; then per optimised joint U = [u;0 | e4]
   // ... then link_frame [L], opt_frame [n], prismatic flag [n], parent [F] as doubles (packed for the actual F, L, n)
-  double fk_tab[65 * GTO_MAX_FRAMES + 17 * GTO_MAX_LINKS + 18 * GTO_MAX_OPT];
+  double fk_tab[(GTO_FK_STRIDE + 1) * GTO_MAX_FRAMES + 17 * GTO_MAX_LINKS + 18 * GTO_MAX_OPT];
   int32_t parent[GTO_MAX_FRAMES];
   int32_t joint_type[GTO_MAX_FRAMES];
   int32_t q_index[GTO_MAX_FRAMES];

@@ -212,7 +212,7 @@ __global__ __launch_bounds__(64 * NW, 4) void k_traj_solve(
     fdesc = (rb->parent[lane0] + 1) | ((rb->xst_slot[lane0] + 1) << 6) | ((rb->link_of_frame[lane0] + 1) << 12) |
             ((rb->opt_of_frame[lane0] + 1) << 18) | (rb->joint_type[lane0] << 23) | ((rb->q_index[lane0] + 1) << 25);
   if (lane0 < L) ldesc = rb->link_anc[lane0];
-  const double* __restrict__ tVo = tab + 64 * F;
+  const double* __restrict__ tVo = tab + GTO_FK_STRIDE * F;
   const double* __restrict__ tU = tVo + 16 * L;
   const bool grad_on = sp.grad_mode == GTO_GRAD_CENTRAL_DIFF;
 
@@ -315,14 +315,15 @@ __global__ __launch_bounds__(64 * NW, 4) void k_traj_solve(
         const bool bvalid = myw.t >= 0;
         {
           double Xprev = ident;
-          double Ot = tab[fet], c0 = tab[16 + fe], c1 = tab[32 + fe], Kk = tab[48 + fe];
+          double Ot = tab[fe], c0 = tab[16 + fe], c1 = tab[32 + fe], Kk = tab[48 + fe];  // frame 0: placement e ^ 0; the table holds the origin transposed
           for (int fq = 0; fq < F; ++fq) {
             const double sn = s_sc[2 * (blk * F + fq)], cs = s_sc[2 * (blk * F + fq) + 1];
             const double Me = fma(sn, Kk, fma(cs, c1, c0));
             const double Lf = __builtin_amdgcn_mfma_f64_4x4x4f64(Ot, Me, 0.0, 0, 0, 0);
             if (fq + 1 < F) {  // operands of the next frame
-              const double* kt = tab + 64 * (fq + 1);
-              Ot = kt[fet], c0 = kt[16 + fe], c1 = kt[32 + fe], Kk = kt[48 + fe];
+              const double* kt = tab + GTO_FK_STRIDE * (fq + 1);
+              const int fes = fe ^ (5 * ((fq + 1) & 3));  // bank placement of the table entries (gto_device.h, fkx)
+              Ot = kt[fes], c0 = kt[16 + fes], c1 = kt[32 + fes], Kk = kt[48 + fes];
             }
             const int dsc = __builtin_amdgcn_readlane(fdesc, fq);
             const int p = (dsc & 63) - 1;
@@ -336,12 +337,12 @@ __global__ __launch_bounds__(64 * NW, 4) void k_traj_solve(
             }
             const int l = ((dsc >> 12) & 63) - 1;
             if (l >= 0 && kind != 0) {  // visual transform V^T = Vo^T X (gto/gto_models.py:92-100)
-              const double V = __builtin_amdgcn_mfma_f64_4x4x4f64(tVo[16 * l + fe], X, 0.0, 0, 0, 0);
+              const double V = __builtin_amdgcn_mfma_f64_4x4x4f64(tVo[fkx(l, fe)], X, 0.0, 0, 0, 0);
               if (bvalid && blk < G && rc < 3) s_V[(blk * L + l) * 12 + 4 * rc + ra] = V;
             }
             const int j = ((dsc >> 18) & 31) - 1;
             if (j >= 0) {  // world screw of optimised joint j: (a ; o x a), (0 ; a) for a prismatic joint
-              const double S = __builtin_amdgcn_mfma_f64_4x4x4f64(tU[16 * j + fe], X, 0.0, 0, 0, 0);
+              const double S = __builtin_amdgcn_mfma_f64_4x4x4f64(tU[fkx(j, fe)], X, 0.0, 0, 0, 0);
               const bool prism = ((dsc >> 23) & 3) == GTO_JOINT_PRISMATIC;
               const double av = S, ov = __shfl(S, (lane + 16) & 63, 64);
               const double a1 = quad_perm<1, 2, 0, 3>(av), a2 = quad_perm<2, 0, 1, 3>(av);

@@ -1,14 +1,10 @@
 #!/bin/bash
-# one PMC pass of tools/dbg_run.py: usage: B=2048 tools/pmc_one.sh <outdir> COUNTER...
-out=$GRAFT_REPO_ROOT/gpurun_out/$1; shift
+# ONE rocprofv3 PMC pass of chosen counters on bench.py (one lane, calls of the timed region's size), per-kernel means.
+# usage: tools/pmc_one.sh <outdir-under-gpurun_out> <steps> <merge> COUNTER [COUNTER ...]      (<= 8 SQ counters per pass)
+out=$GRAFT_REPO_ROOT/gpurun_out/$1; steps=$2; merge=$3; shift 3
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-REPS=1 timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $out/one -o p -- python $GRAFT_REPO_ROOT/tools/dbg_run.py > $out/one.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $out/one -o p -- python $GRAFT_REPO_ROOT/bench.py --pipeline 1 --steps $steps --merge $merge --warmup 1 --no-cpu-baseline --merged-launches-only --repeats 1 > $out/one.log 2>&1
 cd $GRAFT_REPO_ROOT
-python tools/pmc_summary.py $out
-python - <<PY
-import csv,glob
-for f in glob.glob("$out/one/**/*kernel_trace.csv", recursive=True):
-    for r in csv.DictReader(open(f)):
-        if "traj" in r["Kernel_Name"]: print("kernel ns", int(r["End_Timestamp"])-int(r["Start_Timestamp"]), "LDS", r.get("LDS_Block_Size"), "scratch", r.get("Scratch_Size"), "vgpr", r.get("VGPR_Count"))
-PY
+python tools/pmc_summary.py $out | grep -v "^launches" 
+rm -rf $out/one

@@ -18,3 +18,5 @@ pass grbm GRBM_GUI_ACTIVE
 cd $GRAFT_REPO_ROOT
 python tools/pmc_summary.py $out
 python tools/rocprof_summary.py $out/sq1 > $out/kernel_stats.md 2>/dev/null || true
+# the raw per-dispatch CSVs are tens of MiB: only the summaries travel back from the GPU box (gpurun_out is capped at 64 MiB)
+if [ -z "$GTO_PMC_KEEP_RAW" ]; then for d in sq1 sq2 tcc fetch write grbm; do rm -rf $out/$d; done; fi
