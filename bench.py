@@ -549,6 +549,11 @@ def main():
                     "chunk_tests_per_launch": round(tested / max(kern_launches, 1)) if tested else None,
                     "avg_launch_us": round(avg_launch_us, 2), "launches": kern_launches,
                     "instances_per_call": B * max(plan), "slots": slots,
+                    # the kernel is bound by instruction issue and latency, not by HBM: the same PMC passes give the share of the
+                    # time the FP64 vector units are busy (a second roofline axis: 1.0 = every SIMD issuing vector work every cycle)
+                    "valu_fp64_frac": None if not issue else issue.get("fp64_valu_busy_frac"),
+                    "waves_waiting_frac": None if not issue else issue.get("waves_waiting_frac"),
+                    "lds_bank_conflict_cycles_per_lds_inst": None if not issue else issue.get("lds_bank_conflict_cycles_per_lds_inst"),
                     "issue": issue,
                     "measured": "HIP events on the launch stream around every launch of the kernel while ONE lane repeats the timed "
                                 "region's solver calls right after it, so that launches of other lanes do not stretch the durations; "
