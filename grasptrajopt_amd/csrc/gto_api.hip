@@ -236,7 +236,7 @@ int gto_create(const gto_robot_desc* d, const gto_solver_opts* opts, int device,
   if (const char* e = getenv("GTO_TRAJ_FEW")) h->traj_few = atoi(e);
   if (const char* e = getenv("GTO_TRAJ_G")) h->traj_g = std::max(0, std::min(4, atoi(e)));
   if (const char* e = getenv("GTO_MODE")) h->mode = atoi(e) == GTO_MODE_SINGLE_LAUNCH ? GTO_MODE_SINGLE_LAUNCH : GTO_MODE_ROUNDS;
-  if (getenv("GTO_DEBUG_TIMING")) { (void)hipMalloc((void**)&h->dbg, 48 * sizeof(long long)); (void)hipMemset(h->dbg, 0, 48 * sizeof(long long)); }
+  if (getenv("GTO_DEBUG_TIMING")) { (void)hipMalloc((void**)&h->dbg, 128 * sizeof(long long)); (void)hipMemset(h->dbg, 0, 128 * sizeof(long long)); }
   RobotDev& rb = h->rb;
   memset(&rb, 0, sizeof rb);
   rb.n_frames = d->n_frames;
@@ -826,7 +826,7 @@ static int ensure_workspace(gto_handle* h, int B) {
   if ((rc = ensure(h, h->ssfixed, (size_t)B * 4 * sizeof(double)))) return rc;
   if ((rc = ensure(h, h->ndone, 64))) return rc;
   if ((rc = ensure(h, h->qf, (size_t)B * T * rb.n_frames * sizeof(double)))) return rc;
-  if ((rc = ensure(h, h->livebuf, (2 * (1 + kcap) * (size_t)std::min(B, h->slots) + 16) * sizeof(int32_t)))) return rc;
+  if ((rc = ensure(h, h->livebuf, (2 * (1 + kcap) * (size_t)std::min(B, h->slots) + 32) * sizeof(int32_t)))) return rc;
   if ((rc = ensure(h, h->qfs, 2 * (size_t)std::min(B, h->slots) * kcap * T * rb.n_frames * sizeof(double)))) return rc;
   if (!h->h_ndone) HIPCHK(h, hipHostMalloc((void**)&h->h_ndone, 64));
   if (!h->h_progress) {
@@ -885,22 +885,25 @@ static int launch_obstacle(gto_handle* h, hipStream_t st, const BatchPtrs& bp, c
   }
   // waypoints per workgroup: groups of h->obs_tg (the two pinned waypoints form one group)
   const int TG = fixed_mode ? 1 : std::max(1, std::min(tg > 0 ? tg : h->obs_tg, nT));  // the init pass has 4 virtual waypoints
-  const int nG = (nT + TG - 1) / TG;
+  const ObsGeom geo(h->rb.n_frames, h->rb.n_links, h->rb.n_opt, h->rb.n_chunks, TG, nT, h->np);
+  const int nG = geo.nG;
   const int nb = n_jobs > 0 ? n_jobs : B;  // workgroups are laid out for the evaluation jobs there can be; B stays the batch (strides)
   const int n_regular = obstacle_grid(nb, nG);
-  const int cap_active = TG * h->rb.n_chunks;
-  const ObsLds lay(TG, h->rb.n_frames, h->rb.n_links, cap_active, h->np);
-  const size_t lds = (size_t)lay.total_doubles * sizeof(double) + h->dbg_extra_lds;
+  const size_t lds = (size_t)geo.lay.total_doubles * sizeof(double) + h->dbg_extra_lds;
   const dim3 grid(n_regular + (with_goal_terms ? (nb + 3) / 4 : 0));  // goal-term jobs: four to a workgroup
+  // this round's job list and its length (the kernel's first, preloaded, arguments); null outside the solve loop
+  const bool listed = bp.live != nullptr && !fixed_mode;
+  const int32_t* jobs_par = listed ? bp.jobs + (size_t)sp.parity * bp.cap * sp.kcap : nullptr;
+  const int32_t* njobs_par = listed ? bp.nlive + 2 + sp.parity : nullptr;
   if (h->np == GTO_NB && deep)  // few instances in flight: the variant that keeps a wave's record gathers in flight together
-    hipLaunchKernelGGL((k_obstacle_gram<GTO_NB, GTO_OBS_DEEP_PD>), grid, dim3(256), lds, st, h->d_rb, h->d_px, h->d_py, h->d_pz, h->d_chunks, h->d_scenes,
-                       bp, sp, B, t_begin, nT, fixed_mode, n_regular, TG, cap_active);
+    hipLaunchKernelGGL((k_obstacle_gram<GTO_NB, GTO_OBS_DEEP_PD>), grid, dim3(256), lds, st, jobs_par, njobs_par, geo.nG, geo.m_nG, n_regular, B, h->d_rb, h->d_px, h->d_py, h->d_pz, h->d_chunks, h->d_scenes,
+                       bp, sp, t_begin, nT, fixed_mode, geo);
   else if (h->np == GTO_NB)
-    hipLaunchKernelGGL(k_obstacle_gram<GTO_NB>, grid, dim3(256), lds, st, h->d_rb, h->d_px, h->d_py, h->d_pz, h->d_chunks, h->d_scenes, bp, sp,
-                       B, t_begin, nT, fixed_mode, n_regular, TG, cap_active);
+    hipLaunchKernelGGL(k_obstacle_gram<GTO_NB>, grid, dim3(256), lds, st, jobs_par, njobs_par, geo.nG, geo.m_nG, n_regular, B, h->d_rb, h->d_px, h->d_py, h->d_pz, h->d_chunks, h->d_scenes, bp, sp,
+                       t_begin, nT, fixed_mode, geo);
   else
-    hipLaunchKernelGGL(k_obstacle_gram<16>, grid, dim3(256), lds, st, h->d_rb, h->d_px, h->d_py, h->d_pz, h->d_chunks, h->d_scenes, bp, sp, B,
-                       t_begin, nT, fixed_mode, n_regular, TG, cap_active);
+    hipLaunchKernelGGL(k_obstacle_gram<16>, grid, dim3(256), lds, st, jobs_par, njobs_par, geo.nG, geo.m_nG, n_regular, B, h->d_rb, h->d_px, h->d_py, h->d_pz, h->d_chunks, h->d_scenes, bp, sp,
+                       t_begin, nT, fixed_mode, geo);
   if (timed) {
     HIPCHK(h, hipEventRecord(e1, st));
     h->last_launches++;
@@ -1013,6 +1016,7 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
   if (!h) return GTO_ERR_INVALID_ARG;
   if (B < 0 || n_max < 1) return fail(h, GTO_ERR_INVALID_ARG, "B must be >= 0 and n_max >= 1");
   if (B == 0) return GTO_OK;
+  if (B > GTO_JOB_MASK) return fail(h, GTO_ERR_UNSUPPORTED, "more than 16.7 million instances in one call");
   if (!scene_id || !qc || !goals || !n_goals || !base_pos || !Q0) return fail(h, GTO_ERR_INVALID_ARG, "null input array");
   if (h->scenes.empty()) return fail(h, GTO_ERR_NO_SCENE, "no scene has been set");
   HIPCHK(h, hipSetDevice(h->device));
@@ -1032,7 +1036,7 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
   const int T = sp.T;
   h->last_launches = 0;
   h->last_ms = 0.0;
-  if (h->dbg) HIPCHK(h, hipMemsetAsync(h->dbg + 40, 0, 8 * sizeof(long long), st));
+  if (h->dbg) HIPCHK(h, hipMemsetAsync(h->dbg + 40, 0, 88 * sizeof(long long), st));
 
   // At most W instances are in flight; the step kernel of an instance that finishes puts the next one of the call that
   // has not started into the next round's live list, so every round works on a full house until the batch runs out,
@@ -1136,7 +1140,7 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
   HIPCHK(h, hipGetLastError());
   if (h->dbg) {
     HIPCHK(h, hipStreamSynchronize(st));
-    long long t[48];
+    long long t[128];
     HIPCHK(h, hipMemcpy(t, h->dbg, sizeof t, hipMemcpyDeviceToHost));
     fprintf(stderr, "[gto dbg] step-kernel phases (cycles) P0+P1 %lld | P2 %lld | diag %lld | dense %lld | back %lld | P4 %lld | P5 %lld | s_dense %lld\n",
             t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3], t[5] - t[4], t[6] - t[5], t[7] - t[6], t[9]);
@@ -1145,6 +1149,13 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
     // (only with -DGTO_DEBUG_LONGEST_WG: the extra clocks cost the tuned obstacle kernel registers)
     fprintf(stderr, "[gto dbg] longest regular obstacle workgroup of the call: %lld cycles with %lld surviving chunks | goal-term wavefront of instance 0: %lld cycles\n",
             t[40] >> 16, t[40] & 0xffff, t[32] - t[31]);
+    if (t[64] || t[65]) {  // -DGTO_DEBUG_LONGEST_WG
+      long long tot_ = 0;
+      for (int i = 64; i < 128; ++i) tot_ += t[i];
+      fprintf(stderr, "[gto dbg] regular obstacle workgroups of the call: %lld, none of whose keys got a contribution: %lld | surviving chunks per workgroup (0,1,2,...,63+):", tot_, t[48]);
+      for (int i = 64; i < 128; ++i) fprintf(stderr, " %lld", t[i]);
+      fprintf(stderr, "\n");
+    }
     fprintf(stderr, "[gto dbg] obstacle WG (b=0,t=T-1) cycles: prologue %lld | broad %lld | loop %lld | epilogue %lld | active chunks %lld | prologue up to the chain %lld\n",
             t[11] - t[10], t[12] - t[11], t[13] - t[12], t[14] - t[13], t[15], t[16] - t[10]);
   }
