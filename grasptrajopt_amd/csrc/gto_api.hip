@@ -890,7 +890,7 @@ static int launch_obstacle(gto_handle* h, hipStream_t st, const BatchPtrs& bp, c
   const int nb = n_jobs > 0 ? n_jobs : B;  // workgroups are laid out for the evaluation jobs there can be; B stays the batch (strides)
   const int n_regular = obstacle_grid(nb, nG);
   const size_t lds = (size_t)geo.lay.total_doubles * sizeof(double) + h->dbg_extra_lds;
-  const dim3 grid(n_regular + (with_goal_terms ? (nb + 3) / 4 : 0));  // goal-term jobs: four to a workgroup
+  const dim3 grid(n_regular + (with_goal_terms ? 8 * ((nb + 31) / 32) : 0));  // goal-term jobs: four to a workgroup, in front, a multiple of eight workgroups
   // this round's job list and its length (the kernel's first, preloaded, arguments); null outside the solve loop
   const bool listed = bp.live != nullptr && !fixed_mode;
   const int32_t* jobs_par = listed ? bp.jobs + (size_t)sp.parity * bp.cap * sp.kcap : nullptr;
