@@ -236,7 +236,7 @@ int gto_create(const gto_robot_desc* d, const gto_solver_opts* opts, int device,
   if (const char* e = getenv("GTO_TRAJ_FEW")) h->traj_few = atoi(e);
   if (const char* e = getenv("GTO_TRAJ_G")) h->traj_g = std::max(0, std::min(4, atoi(e)));
   if (const char* e = getenv("GTO_MODE")) h->mode = atoi(e) == GTO_MODE_SINGLE_LAUNCH ? GTO_MODE_SINGLE_LAUNCH : GTO_MODE_ROUNDS;
-  if (getenv("GTO_DEBUG_TIMING")) { (void)hipMalloc((void**)&h->dbg, 128 * sizeof(long long)); (void)hipMemset(h->dbg, 0, 128 * sizeof(long long)); }
+  if (getenv("GTO_DEBUG_TIMING")) { (void)hipMalloc((void**)&h->dbg, 192 * sizeof(long long)); (void)hipMemset(h->dbg, 0, 192 * sizeof(long long)); }
   RobotDev& rb = h->rb;
   memset(&rb, 0, sizeof rb);
   rb.n_frames = d->n_frames;
@@ -1036,7 +1036,7 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
   const int T = sp.T;
   h->last_launches = 0;
   h->last_ms = 0.0;
-  if (h->dbg) HIPCHK(h, hipMemsetAsync(h->dbg + 40, 0, 88 * sizeof(long long), st));
+  if (h->dbg) HIPCHK(h, hipMemsetAsync(h->dbg + 40, 0, 152 * sizeof(long long), st));
 
   // At most W instances are in flight; the step kernel of an instance that finishes puts the next one of the call that
   // has not started into the next round's live list, so every round works on a full house until the batch runs out,
@@ -1140,7 +1140,7 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
   HIPCHK(h, hipGetLastError());
   if (h->dbg) {
     HIPCHK(h, hipStreamSynchronize(st));
-    long long t[128];
+    long long t[192];
     HIPCHK(h, hipMemcpy(t, h->dbg, sizeof t, hipMemcpyDeviceToHost));
     fprintf(stderr, "[gto dbg] step-kernel phases (cycles) P0+P1 %lld | P2 %lld | diag %lld | dense %lld | back %lld | P4 %lld | P5 %lld | s_dense %lld\n",
             t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3], t[5] - t[4], t[6] - t[5], t[7] - t[6], t[9]);
@@ -1154,6 +1154,11 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
       for (int i = 64; i < 128; ++i) tot_ += t[i];
       fprintf(stderr, "[gto dbg] regular obstacle workgroups of the call: %lld, none of whose keys got a contribution: %lld | surviving chunks per workgroup (0,1,2,...,63+):", tot_, t[48]);
       for (int i = 64; i < 128; ++i) fprintf(stderr, " %lld", t[i]);
+      fprintf(stderr, "\n");
+    }
+    {
+      fprintf(stderr, "[gto dbg] workgroups without a surviving chunk by the index shift their closest chunk tolerates (0,1,2,...,63+):");
+      for (int i = 128; i < 192; ++i) fprintf(stderr, " %lld", t[i]);
       fprintf(stderr, "\n");
     }
     fprintf(stderr, "[gto dbg] obstacle WG (b=0,t=T-1) cycles: prologue %lld | broad %lld | loop %lld | epilogue %lld | active chunks %lld | prologue up to the chain %lld\n",

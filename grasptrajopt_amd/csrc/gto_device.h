@@ -15,6 +15,13 @@
 #include "../../include/gto_solver.h"
 
 #define GTO_NB 8            // padded block size of the per-waypoint normal-equation blocks
+// Broad phase: a chunk whose bounding sphere has radius rho voxels cannot put a point more than ceil(rho) voxel indices
+// away from its centre's voxel on any axis (floor(x + t) <= floor(x) + ceil(t)), so it is culled when the Chebyshev
+// distance from the centre's voxel to the nearest non-zero record exceeds R = ceil(rho + 1e-6) + GTO_BROAD_MARGIN.  The
+// margin was 2 until round 3 ("floor of the centre, index rounding": both are inside the ceil already).
+#ifndef GTO_BROAD_MARGIN
+#define GTO_BROAD_MARGIN 0
+#endif
 #define GTO_GRAM 28         // 21 (6x6 symmetric wrench Gram) + 6 (c * wrench) + 1 (c^2)
 #define GTO_WAVE 64
 // LDS bank layout of the forward kinematics (fk_mfma_tree).  A wavefront works on four frames at once, one per 16-lane

@@ -592,7 +592,7 @@ __global__ __launch_bounds__(64 * NW, 4) void k_traj_solve(
                 const double u0 = (V[0] * cc.cx + V[1] * cc.cy + V[2] * cc.cz + V[3] + bx - sc.ox) * sc.rinv;
                 const double u1 = (V[4] * cc.cx + V[5] * cc.cy + V[6] * cc.cz + V[7] + by - sc.oy) * sc.rinv;
                 const double u2 = (V[8] * cc.cx + V[9] * cc.cy + V[10] * cc.cz + V[11] + bz - sc.oz) * sc.rinv;
-                const int R = (int)ceil(cc.r * sc.rinv) + 2;
+                const int R = (int)ceil(cc.r * sc.rinv + 1e-6) + GTO_BROAD_MARGIN;
                 const int k0 = (int)floor(u0), k1 = (int)floor(u1), k2 = (int)floor(u2);
                 Rr[u] = R;
                 int sl = -1000;
