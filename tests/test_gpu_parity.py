@@ -215,6 +215,26 @@ def test_full_solve_matches_oracle(capi, oracle_mod, robot, n_goals, standoff, g
     h.close()
 
 
+@pytest.mark.parametrize("origin,n,res", [((0.15, -0.6, -0.1), 32, 0.04),      # the base and the first links are outside, low side of x
+                                          ((-1.5, -1.4, -0.2), 32, 0.05),     # the arm reaches out of the grid on the high side of x
+                                          ((0.2, -0.3, 0.05), 24, 0.03),      # a small grid in the middle of the workspace: most spheres outside
+                                          ((-0.4, -1.12, 0.12), 48, 0.0467)])  # the table and the lower links are below the grid
+@pytest.mark.parametrize("mode", [0, 1])
+def test_robot_partly_outside_the_grid_matches_oracle(capi, oracle_mod, origin, n, res, mode):
+    """The broad phase culls a bounding sphere by the distance field at the CLIPPED voxel of its centre (round 3; before,
+    spheres that stick out of the grid were never culled): robots that are partly or mostly outside the field, where the
+    reference's lookups clip every index (gto/sdf_callback.py:90-114), must still match the oracle, which culls nothing."""
+    prob = Problem("panda", B=6, scene_seed=3, n=n, res=res, n_goals=2, scene_origin=origin)
+    h, o = make_pair(capi, oracle_mod, prob, mode=mode, max_iter=40)
+    Qg, dQg, fg, itg, stg = h.solve_batch(*prob.solve_args())
+    Qo, dQo, fo, ito, sto = o.solve_batch(*prob.solve_args())
+    np.testing.assert_array_equal(itg, ito)
+    np.testing.assert_array_equal(stg, sto)
+    np.testing.assert_allclose(Qg, Qo, rtol=0, atol=1e-6)
+    np.testing.assert_allclose(fg, fo, rtol=1e-7)
+    h.close()
+
+
 @pytest.mark.parametrize("mode", [0, 1])
 def test_ragged_batches_and_scene_table(capi, oracle_mod, mode):
     """B not a multiple of 8, several scenes, per-instance goal counts, then the empty batch."""
