@@ -294,8 +294,9 @@ int gto_create(const gto_robot_desc* d, const gto_solver_opts* opts, int device,
       depth[i] = rb.parent[i] < 0 ? 0 : depth[rb.parent[i]] + 1;
       maxd = std::max(maxd, depth[i]);
     }
+    // a frame at depth d is the product of d + 1 local transforms, and r rounds of pointer jumping compose 2^r of them
     rb.fk_rounds = 0;
-    while ((1 << rb.fk_rounds) < maxd) ++rb.fk_rounds;
+    while ((1 << rb.fk_rounds) < maxd + 1) ++rb.fk_rounds;
   }
   for (int l = 0; l < d->n_links; ++l) {
     int f = d->link_frame[l];
@@ -316,44 +317,99 @@ int gto_create(const gto_robot_desc* d, const gto_solver_opts* opts, int device,
     const int p = rb.parent[i];
     if (p >= 0 && p != i - 1 && rb.xst_slot[p] < 0) rb.xst_slot[p] = rb.n_xst++;
   }
-  {  // operand table of fk_mfma_tree
-    std::memset(rb.fk_tab, 0, sizeof rb.fk_tab);
-    const int F = d->n_frames, L = d->n_links;
+  {  // operand tables of fk_mfma_tree: the full tree, and the compact tree of the obstacle kernel (gto_device.h)
+    const int F = d->n_frames, L = d->n_links, n = d->n_opt;
     auto hom = [](const double* aff, int a, int c) { return a < 3 ? aff[4 * a + c] : (c == 3 ? 1.0 : 0.0); };
-    for (int i = 0; i < F; ++i) {
-      const double* u = rb.axis_unit[i];
-      const double K[3][3] = {{0, -u[2], u[1]}, {u[2], 0, -u[0]}, {-u[1], u[0], 0}};
-      double* tab = rb.fk_tab + GTO_FK_STRIDE * i;
-      for (int a = 0; a < 4; ++a)
-        for (int c = 0; c < 4; ++c) {
-          const int e = (4 * a + c) ^ (5 * (i & 3));  // bank placement of the frame's entries (gto_device.h, fkx)
-          const double uu = (a < 3 && c < 3) ? u[a] * u[c] : 0.0;
-          const double dl = (a == c && a < 3) ? 1.0 : 0.0, hh = (a == 3 && c == 3) ? 1.0 : 0.0;
-          tab[e] = hom(rb.origin[i], c, a);  // transposed: a row-pattern read gives the B operand O^T (gto_device.h, fkx)
-          tab[16 + e] = hh + uu;  // M = c0 + cos c1 + sin K
-          tab[32 + e] = dl - uu;
-          if (rb.joint_type[i] == GTO_JOINT_PRISMATIC) tab[48 + e] = (a < 3 && c == 3) ? u[a] : 0.0;
-          else tab[48 + e] = (a < 3 && c < 3) ? K[a][c] : 0.0;
+    // one table: nf frames (origin affine, unit axis, joint type, parent, optimised-joint slot), the links' frames and
+    // visual origins, the optimised joints' frames
+    auto build = [&](double* T0, int nf, const double (*org)[12], const double (*axu)[3], const int* jtype, const int* par,
+                     const int* optj, const int* lframe, const double (*vorg)[12], int* opt_frame_out) {
+      std::memset(T0, 0, sizeof rb.fk_tab);
+      for (int i = 0; i < nf; ++i) {
+        const double* u = axu[i];
+        const double K[3][3] = {{0, -u[2], u[1]}, {u[2], 0, -u[0]}, {-u[1], u[0], 0}};
+        double* tab = T0 + GTO_FK_STRIDE * i;
+        for (int a = 0; a < 4; ++a)
+          for (int c = 0; c < 4; ++c) {
+            const int e = (4 * a + c) ^ (5 * (i & 3));  // bank placement of the frame's entries (gto_device.h, fkx)
+            const double uu = (a < 3 && c < 3) ? u[a] * u[c] : 0.0;
+            const double dl = (a == c && a < 3) ? 1.0 : 0.0, hh = (a == 3 && c == 3) ? 1.0 : 0.0;
+            tab[e] = hom(org[i], c, a);  // transposed: a row-pattern read gives the B operand O^T (gto_device.h, fkx)
+            tab[16 + e] = hh + uu;  // M = c0 + cos c1 + sin K
+            tab[32 + e] = dl - uu;
+            if (jtype[i] == GTO_JOINT_PRISMATIC) tab[48 + e] = (a < 3 && c == 3) ? u[a] : 0.0;
+            else tab[48 + e] = (a < 3 && c < 3) ? K[a][c] : 0.0;
+          }
+        if (optj[i] >= 0) {
+          const int j = optj[i];
+          opt_frame_out[j] = i;
+          double* tu = T0 + GTO_FK_STRIDE * nf + 16 * L;
+          for (int a = 0; a < 3; ++a) tu[fkx(j, 4 * a)] = u[a];
+          tu[fkx(j, 4 * 3 + 1)] = 1.0;
         }
-      if (rb.opt_of_frame[i] >= 0) {
-        const int j = rb.opt_of_frame[i];
-        rb.opt_frame[j] = i;
-        double* tu = rb.fk_tab + GTO_FK_STRIDE * F + 16 * L;
-        for (int a = 0; a < 3; ++a) tu[fkx(j, 4 * a)] = u[a];
-        tu[fkx(j, 4 * 3 + 1)] = 1.0;
       }
+      for (int l = 0; l < L; ++l)
+        for (int a = 0; a < 4; ++a)
+          for (int c = 0; c < 4; ++c) T0[GTO_FK_STRIDE * nf + fkx(l, 4 * a + c)] = hom(vorg[l], a, c);
+      double* tI = T0 + GTO_FK_STRIDE * nf + 16 * L + 16 * n;
+      for (int l = 0; l < L; ++l) tI[l] = lframe[l];
+      for (int j = 0; j < n; ++j) {
+        tI[L + j] = opt_frame_out[j];
+        tI[L + n + j] = jtype[opt_frame_out[j]] == GTO_JOINT_PRISMATIC ? 1.0 : 0.0;
+      }
+      for (int i = 0; i < nf; ++i) tI[L + 2 * n + i] = par[i];
+    };
+    build(rb.fk_tab, F, rb.origin, rb.axis_unit, rb.joint_type, rb.parent, rb.opt_of_frame, rb.link_frame, rb.vis_origin, rb.opt_frame);
+    // the compact tree
+    static_assert(sizeof rb.fk_tab == sizeof rb.fk_tab_c, "one layout for both tables");
+    int cf[GTO_MAX_FRAMES], nc = 0;
+    double corg[GTO_MAX_FRAMES][12], caxu[GTO_MAX_FRAMES][3], cvis[GTO_MAX_LINKS][12];
+    int cpar[GTO_MAX_FRAMES], coptj[GTO_MAX_FRAMES], clf[GTO_MAX_LINKS], copt_frame[GTO_MAX_OPT];
+    for (int f = 0; f < F; ++f) cf[f] = rb.joint_type[f] != GTO_JOINT_FIXED ? nc++ : -1;
+    for (int f = 0; f < F; ++f) {
+      if (cf[f] < 0) continue;
+      const int k = cf[f];
+      double A[12];
+      std::memcpy(A, rb.origin[f], sizeof A);
+      int p = rb.parent[f];
+      for (; p >= 0 && rb.joint_type[p] == GTO_JOINT_FIXED; p = rb.parent[p]) aff_mul(rb.origin[p], A, A);
+      std::memcpy(corg[k], A, sizeof A);
+      std::memcpy(caxu[k], rb.axis_unit[f], sizeof caxu[k]);
+      cpar[k] = p >= 0 ? cf[p] : -1;
+      coptj[k] = rb.opt_of_frame[f];
+      rb.cf_orig[k] = f;
+      rb.cf_type[k] = rb.joint_type[f];
     }
-    for (int l = 0; l < L; ++l)
-      for (int a = 0; a < 4; ++a)
-        for (int c = 0; c < 4; ++c) rb.fk_tab[GTO_FK_STRIDE * F + fkx(l, 4 * a + c)] = hom(rb.vis_origin[l], a, c);
-    const int n = d->n_opt;
-    double* tI = rb.fk_tab + GTO_FK_STRIDE * F + 16 * L + 16 * n;
-    for (int l = 0; l < L; ++l) tI[l] = rb.link_frame[l];
-    for (int j = 0; j < n; ++j) {
-      tI[L + j] = rb.opt_frame[j];
-      tI[L + n + j] = rb.joint_type[rb.opt_frame[j]] == GTO_JOINT_PRISMATIC ? 1.0 : 0.0;
+    bool need_world = false;
+    for (int l = 0; l < L; ++l) {
+      double V[12];
+      std::memcpy(V, rb.vis_origin[l], sizeof V);
+      int g = rb.link_frame[l];
+      for (; g >= 0 && rb.joint_type[g] == GTO_JOINT_FIXED; g = rb.parent[g]) aff_mul(rb.origin[g], V, V);
+      std::memcpy(cvis[l], V, sizeof V);
+      clf[l] = g >= 0 ? cf[g] : -2;
+      need_world = need_world || g < 0;
     }
-    for (int i = 0; i < F; ++i) tI[L + 2 * n + i] = rb.parent[i];
+    if (need_world || nc == 0) {  // links that hang on fixed frames only: a frame that is the world
+      const int k = nc++;
+      const double I12[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+      std::memcpy(corg[k], I12, sizeof I12);
+      caxu[k][0] = caxu[k][1] = caxu[k][2] = 0.0;
+      cpar[k] = -1, coptj[k] = -1;
+      rb.cf_orig[k] = -1;
+      rb.cf_type[k] = GTO_JOINT_FIXED;
+      for (int l = 0; l < L; ++l)
+        if (clf[l] == -2) clf[l] = k;
+    }
+    build(rb.fk_tab_c, nc, corg, caxu, rb.cf_type, cpar, coptj, clf, cvis, copt_frame);
+    rb.n_cframes = nc;
+    int depth[GTO_MAX_FRAMES], maxd = 1;
+    for (int i = 0; i < nc; ++i) {
+      depth[i] = cpar[i] < 0 ? 0 : depth[cpar[i]] + 1;
+      maxd = std::max(maxd, depth[i]);
+    }
+    rb.fk_rounds_c = 0;
+    while ((1 << rb.fk_rounds_c) < maxd + 1) ++rb.fk_rounds_c;
   }
   // moments of the gripper point cloud
   rb.grip_count = (double)d->n_gripper_points;
@@ -885,7 +941,7 @@ static int launch_obstacle(gto_handle* h, hipStream_t st, const BatchPtrs& bp, c
   }
   // waypoints per workgroup: groups of h->obs_tg (the two pinned waypoints form one group)
   const int TG = fixed_mode ? 1 : std::max(1, std::min(tg > 0 ? tg : h->obs_tg, nT));  // the init pass has 4 virtual waypoints
-  const ObsGeom geo(h->rb.n_frames, h->rb.n_links, h->rb.n_opt, h->rb.n_chunks, TG, nT, h->np);
+  const ObsGeom geo(h->rb.n_cframes, h->rb.n_frames, h->rb.fk_rounds_c, h->rb.n_links, h->rb.n_opt, h->rb.n_chunks, TG, nT, h->np);
   const int nG = geo.nG;
   const int nb = n_jobs > 0 ? n_jobs : B;  // workgroups are laid out for the evaluation jobs there can be; B stays the batch (strides)
   const int n_regular = obstacle_grid(nb, nG);

@@ -46,6 +46,15 @@ struct RobotDev {
   // translation column); then per link its visual origin; then per optimised joint U = [u;0 | e4]
   // ... then link_frame [L], opt_frame [n], prismatic flag [n], parent [F] as doubles (packed for the actual F, L, n)
   double fk_tab[(GTO_FK_STRIDE + 1) * GTO_MAX_FRAMES + 17 * GTO_MAX_LINKS + 18 * GTO_MAX_OPT];
+  // The same table for the COMPACT tree the obstacle kernel walks (gto_api.hip, build_fk_tables): frames with fixed joints
+  // are folded into the origins of the moving frames below them and into the visual origins of their links (a "world"
+  // frame is appended when a link hangs on fixed frames only), so the pointer jumping has fewer frames and fewer levels
+  // (Panda: 12 frames / 4 rounds -> 10 / 3).  Link transforms and joint screws are the same up to the order of the
+  // products; the other kernels, which also read frames, keep the full table.
+  double fk_tab_c[(GTO_FK_STRIDE + 1) * GTO_MAX_FRAMES + 17 * GTO_MAX_LINKS + 18 * GTO_MAX_OPT];
+  int32_t n_cframes, fk_rounds_c;
+  int32_t cf_orig[GTO_MAX_FRAMES];  // frame whose joint value a compact frame takes (-1: the world frame)
+  int32_t cf_type[GTO_MAX_FRAMES];  // its joint type
   int32_t parent[GTO_MAX_FRAMES];
   int32_t joint_type[GTO_MAX_FRAMES];
   int32_t q_index[GTO_MAX_FRAMES];
