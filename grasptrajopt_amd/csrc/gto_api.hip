@@ -47,7 +47,7 @@ struct gto_handle {
   SceneDev* d_scenes = nullptr;
   size_t d_scenes_cap = 0;
   // solve workspace (grown on demand)
-  DevBuf state, Qcur, Qtry, vis, screw, blocks, goalblk, ssfixed, ndone, qf, livebuf, qfs;
+  DevBuf state, Qcur, Qtry, vis, screw, blocks, goalblk, ssfixed, ndone, qf, livebuf, qfs, roombuf, itembuf;
   DevBuf trajws, evterms, evblocks, counters;  // k_traj_solve: block workspace, evaluation outputs, work counters
   int traj_nw = 8;        // wavefronts per workgroup (instance) of k_traj_solve: 4, 8 or 16 (GTO_TRAJ_NW)
   int traj_nw_few = 16;   // ... when a call has few instances (latency matters more than occupancy)
@@ -76,6 +76,8 @@ struct gto_handle {
   // the obstacles (neighbours in time) land in different workgroups: 0 never, 1 always, 2 (default) in launches with few
   // instances in flight, where the longest workgroup decides the round (+5 % for one batch at a time, -2 % at saturation)
   int obs_interleave = 2;
+  int certify = 1;  // GTO_CERTIFY=0: every (job, group) is looked at in every round
+  int cert_from = 4;  // GTO_CERT_FROM: first round with certificates of a call all of whose instances start together
   size_t dbg_extra_lds = 0;  // GTO_DEBUG_EXTRA_LDS: occupancy experiments  // GTO_DEBUG_CUT: timing experiments only, results are garbage
   int obs_tg_few = 2;  // ... when few instances are in flight (one small batch, the tail of a call): lower latency per round; results do not depend on the group size
   int few_instances = 64;
@@ -220,6 +222,8 @@ int gto_create(const gto_robot_desc* d, const gto_solver_opts* opts, int device,
   if (const char* e = getenv("GTO_SPEC_DEEP")) h->spec_deep = std::max(0, atoi(e));
   if (const char* e = getenv("GTO_SPEC_FEW")) h->spec_few = std::max(0, atoi(e));
   if (const char* e = getenv("GTO_OBS_DEEP")) h->obs_deep = atoi(e) ? 1 : 0;
+  if (const char* e = getenv("GTO_CERTIFY")) h->certify = atoi(e) != 0;
+  if (const char* e = getenv("GTO_CERT_FROM")) h->cert_from = std::max(1, atoi(e));
   if (const char* e = getenv("GTO_OBS_INTERLEAVE")) h->obs_interleave = std::max(0, std::min(2, atoi(e)));
   if (const char* e = getenv("GTO_DIST_RELAX")) h->dist_relax = atoi(e) ? 1 : 0;
   if (const char* e = getenv("GTO_DEBUG_CUT")) h->dbg_cut = atoi(e);
@@ -430,6 +434,8 @@ int gto_create(const gto_robot_desc* d, const gto_solver_opts* opts, int device,
       maxpt[d->point_link[i]] = std::max(maxpt[d->point_link[i]], std::sqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]));
     }
     for (int j = 0; j < d->n_opt; ++j) rb.reach[j] = 0.0;
+    for (int l = 0; l < GTO_MAX_LINKS; ++l)
+      for (int j = 0; j < GTO_MAX_OPT; ++j) rb.reach_link[l][j] = 0.0;
     bool ok = true;
     for (int l = 0; l < d->n_links; ++l) {
       const double* vx = d->visual_xyz + 3 * l;
@@ -437,6 +443,7 @@ int gto_create(const gto_robot_desc* d, const gto_solver_opts* opts, int device,
       for (int f = d->link_frame[l]; f >= 0; f = d->parent[f]) {
         const int j = rb.opt_of_frame[f];
         if (j >= 0) rb.reach[j] = std::max(rb.reach[j], rb.joint_type[f] == GTO_JOINT_PRISMATIC ? 1.0 : below);
+        if (j >= 0) rb.reach_link[l][j] = rb.joint_type[f] == GTO_JOINT_PRISMATIC ? 1.0 : below;
         if (rb.joint_type[f] == GTO_JOINT_PRISMATIC) {
           // travel of this joint moves everything below it further from the joints above
           double travel = 1e9;
@@ -450,6 +457,9 @@ int gto_create(const gto_robot_desc* d, const gto_solver_opts* opts, int device,
       }
     }
     if (!ok) for (int j = 0; j < d->n_opt; ++j) rb.reach[j] = -1.0;
+    if (!ok)
+      for (int l = 0; l < GTO_MAX_LINKS; ++l)
+        for (int j = 0; j < GTO_MAX_OPT; ++j) rb.reach_link[l][j] = -1.0;
   }
   // points sorted by link (stable), chunk table of <= 64 link-uniform points
   const int P = d->n_points;
@@ -579,7 +589,7 @@ void gto_destroy(gto_handle* h) {
   (void)hipFree(h->d_plink);
   (void)hipFree(h->d_perm);
   (void)hipFree(h->d_chunks);
-  DevBuf* bufs[] = {&h->zws, &h->trajws, &h->evterms, &h->evblocks, &h->counters, &h->state, &h->Qcur, &h->Qtry, &h->vis, &h->screw, &h->blocks, &h->goalblk, &h->ssfixed, &h->ndone, &h->qf, &h->livebuf, &h->qfs};
+  DevBuf* bufs[] = {&h->zws, &h->trajws, &h->evterms, &h->evblocks, &h->counters, &h->state, &h->Qcur, &h->Qtry, &h->vis, &h->screw, &h->blocks, &h->goalblk, &h->ssfixed, &h->ndone, &h->qf, &h->livebuf, &h->qfs, &h->roombuf, &h->itembuf};
   if (h->h_ndone) (void)hipHostFree(h->h_ndone);
   if (h->h_progress) (void)hipHostFree(h->h_progress);
   for (DevBuf* b : bufs) (void)hipFree(b->p);
@@ -861,6 +871,7 @@ static SolveParams make_params(const gto_handle* h, int n_max, bool use_standoff
   sp.lambda0 = o.lambda0;
   sp.dbg_cut = h->dbg_cut;
   sp.interleave = h->obs_interleave == 1;
+  sp.certify = 0, sp.cert_tg = 1, sp.cert_ng = 1;
   sp.round = sp.parity = 0;
   sp.kcap = h->np == GTO_NB ? GTO_KSPEC : 1;  // candidate copies of the workspace (the wide step kernel generates one)
   sp.k_acc = sp.k_rej = sp.k_eval = 1;
@@ -884,6 +895,8 @@ static int ensure_workspace(gto_handle* h, int B) {
   if ((rc = ensure(h, h->qf, (size_t)B * T * rb.n_frames * sizeof(double)))) return rc;
   if ((rc = ensure(h, h->livebuf, (2 * (1 + kcap) * (size_t)std::min(B, h->slots) + 32) * sizeof(int32_t)))) return rc;
   if ((rc = ensure(h, h->qfs, 2 * (size_t)std::min(B, h->slots) * kcap * T * rb.n_frames * sizeof(double)))) return rc;
+  if ((rc = ensure(h, h->roombuf, (size_t)(kcap + 1) * B * T * rb.n_links))) return rc;
+  if ((rc = ensure(h, h->itembuf, 2 * ((size_t)std::min(B, h->slots) * kcap * (T - 2) + 64) * sizeof(int2)))) return rc;
   if (!h->h_ndone) HIPCHK(h, hipHostMalloc((void**)&h->h_ndone, 64));
   if (!h->h_progress) {
     HIPCHK(h, hipHostMalloc((void**)&h->h_progress, 64, hipHostMallocMapped));
@@ -916,6 +929,9 @@ static BatchPtrs make_ptrs(gto_handle* h, const int32_t* scene_id, const double*
   bp.nlive = nullptr;
   bp.next = nullptr;
   bp.qfs = nullptr;
+  bp.room = nullptr;
+  bp.items = nullptr;
+  bp.scenes = h->d_scenes;
   bp.cap = 0;
   bp.n_total = 0;
   bp.dbg = h->dbg;
@@ -926,7 +942,8 @@ static BatchPtrs make_ptrs(gto_handle* h, const int32_t* scene_id, const double*
 static inline int obstacle_grid(int B, int nG) { return 8 * ((B + 7) / 8) * nG; }
 
 static int launch_obstacle(gto_handle* h, hipStream_t st, const BatchPtrs& bp, const SolveParams& sp, int B, int t_begin,
-                           int nT, int fixed_mode, bool timed, bool with_goal_terms = false, int n_jobs = 0, int tg = 0, bool deep = false) {
+                           int nT, int fixed_mode, bool timed, bool with_goal_terms = false, int n_jobs = 0, int tg = 0, bool deep = false,
+                           bool itemized = false) {
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (timed) {
     size_t need = (size_t)(h->last_launches + 1) * 2;
@@ -951,14 +968,18 @@ static int launch_obstacle(gto_handle* h, hipStream_t st, const BatchPtrs& bp, c
   const bool listed = bp.live != nullptr && !fixed_mode;
   const int32_t* jobs_par = listed ? bp.jobs + (size_t)sp.parity * bp.cap * sp.kcap : nullptr;
   const int32_t* njobs_par = listed ? bp.nlive + 2 + sp.parity : nullptr;
+  // rounds with emptiness certificates: the regular workgroups are laid out over k_certify's list of (job, group) pairs
+  const size_t items_cap = (size_t)bp.cap * sp.kcap * (sp.T - 2) + 64;
+  const int2* items_par = listed && itemized ? bp.items + (size_t)sp.parity * items_cap : nullptr;
+  const int32_t* nitems_par = listed && itemized ? bp.nlive + 8 + sp.parity : nullptr;
   if (h->np == GTO_NB && deep)  // few instances in flight: the variant that keeps a wave's record gathers in flight together
-    hipLaunchKernelGGL((k_obstacle_gram<GTO_NB, GTO_OBS_DEEP_PD>), grid, dim3(256), lds, st, jobs_par, njobs_par, geo.nG, geo.m_nG, n_regular, B, h->d_rb, h->d_px, h->d_py, h->d_pz, h->d_chunks, h->d_scenes,
+    hipLaunchKernelGGL((k_obstacle_gram<GTO_NB, GTO_OBS_DEEP_PD>), grid, dim3(256), lds, st, jobs_par, njobs_par, items_par, nitems_par, geo.nG, geo.m_nG, n_regular, B, h->d_rb, h->d_px, h->d_py, h->d_pz, h->d_chunks, h->d_scenes,
                        bp, sp, t_begin, nT, fixed_mode, geo);
   else if (h->np == GTO_NB)
-    hipLaunchKernelGGL(k_obstacle_gram<GTO_NB>, grid, dim3(256), lds, st, jobs_par, njobs_par, geo.nG, geo.m_nG, n_regular, B, h->d_rb, h->d_px, h->d_py, h->d_pz, h->d_chunks, h->d_scenes, bp, sp,
+    hipLaunchKernelGGL(k_obstacle_gram<GTO_NB>, grid, dim3(256), lds, st, jobs_par, njobs_par, items_par, nitems_par, geo.nG, geo.m_nG, n_regular, B, h->d_rb, h->d_px, h->d_py, h->d_pz, h->d_chunks, h->d_scenes, bp, sp,
                        t_begin, nT, fixed_mode, geo);
   else
-    hipLaunchKernelGGL(k_obstacle_gram<16>, grid, dim3(256), lds, st, jobs_par, njobs_par, geo.nG, geo.m_nG, n_regular, B, h->d_rb, h->d_px, h->d_py, h->d_pz, h->d_chunks, h->d_scenes, bp, sp,
+    hipLaunchKernelGGL(k_obstacle_gram<16>, grid, dim3(256), lds, st, jobs_par, njobs_par, items_par, nitems_par, geo.nG, geo.m_nG, n_regular, B, h->d_rb, h->d_px, h->d_py, h->d_pz, h->d_chunks, h->d_scenes, bp, sp,
                        t_begin, nT, fixed_mode, geo);
   if (timed) {
     HIPCHK(h, hipEventRecord(e1, st));
@@ -1103,6 +1124,9 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
   bp.nlive = bp.jobs + 2 * W * sp.kcap;
   bp.next = bp.nlive + 4;
   bp.qfs = (double*)h->qfs.p;
+  const bool certify_call = h->certify && h->np == GTO_NB && h->rb.reach_link[0][0] >= 0.0 && h->rb.n_links <= 16;
+  bp.room = certify_call ? (int8_t*)h->roombuf.p : nullptr;
+  bp.items = certify_call ? (int2*)h->itembuf.p : nullptr;
   bp.cap = W;
   bp.n_total = B;
   HIPCHK(h, hipMemsetAsync(bp.n_done, 0, sizeof(int32_t), st));
@@ -1129,6 +1153,17 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
   const int max_rounds = ((B + W - 1) / W + 1) * (sp.max_iter + 2);
   int known_done = 0, seen_round = -1;
   int k_prev = 1;  // candidates per instance the last step launch may have generated
+  // emptiness certificates in the rounds that fill the GPU: k_certify settles the groups it can and lists the others
+  const int cert_tg = std::max(1, std::min(h->obs_tg, T - 2)), cert_ng = (T - 2 + cert_tg - 1) / cert_tg;
+  const bool cert_ok = bp.items != nullptr && cert_ng <= 64 && cert_tg * h->rb.n_links <= 64 && h->obs_interleave != 1;
+  const int cert_verify = h->dbg_cut == 10;
+  bool items_ready = false;
+  auto launch_certify = [&](int pn, int n_jobs) {
+    hipLaunchKernelGGL(k_certify, dim3(n_jobs), dim3(256), 0, st, h->d_rb, bp, sp, B, pn, cert_tg, cert_ng,
+                       (int)((size_t)W * sp.kcap * (T - 2) + 64), cert_verify);
+    items_ready = true;
+  };
+  if (cert_ok && std::min(W, B) > h->few_instances && B > W) launch_certify(0, std::min(W, B));
   auto read_progress = [&]() {
     const unsigned long long p0 = __atomic_load_n(h->h_progress, __ATOMIC_RELAXED), p1 = __atomic_load_n(h->h_progress + 1, __ATOMIC_RELAXED);
     if ((unsigned)(p0 >> 32) == h->progress_tag) known_done = std::max(known_done, (int)(p0 & 0xffffffffull));
@@ -1168,11 +1203,15 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
     few = in_flight <= h->few_instances;
     const int tg = few ? h->obs_tg_few : h->obs_tg;
     sp.interleave = h->obs_interleave == 1 || (h->obs_interleave == 2 && few);
+    const bool itemized = items_ready && !few;
+    sp.certify = cert_ok && !few;  // the looks of the rounds that fill the GPU leave their rooms
+    sp.cert_tg = cert_tg, sp.cert_ng = cert_ng;
+    items_ready = false;
     sp.round = k;
     sp.parity = k & 1;
     // the goal workgroups skip fresh instances themselves: k_lm_init already produced the seed's goal terms
     sp.k_eval = k_prev;
-    if ((rc = launch_obstacle(h, st, bp, sp, B, 2, T - 2, 0, h->profiling, true, in_flight * k_prev, tg, few && h->obs_deep))) { rc_loop = rc; break; }
+    if ((rc = launch_obstacle(h, st, bp, sp, B, 2, T - 2, 0, h->profiling, true, in_flight * k_prev, tg, few && h->obs_deep, itemized))) { rc_loop = rc; break; }
     if (h->np == GTO_NB) {
       if (few && h->step_nw_few == 8) {
         // few instances in flight: eight waves per instance and candidate trial points ahead of their evaluation
@@ -1185,6 +1224,8 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
         sp.k_acc = sp.k_rej = 1;
         hipLaunchKernelGGL((k_lm_step<4, 1>), dim3(in_flight), dim3(256), h->lm_lds, st, h->d_rb, bp, sp, B);
         k_prev = 1;
+        // (a call without waiting instances is young in its first rounds: steps too long for any room)
+        if (cert_ok && !few && (B > W || k + 1 >= h->cert_from)) launch_certify((k + 1) & 1, in_flight);
       }
     } else {
       hipLaunchKernelGGL(k_lm_step_wide<16>, dim3(in_flight), dim3(256), h->lm_lds, st, h->d_rb, bp, sp, B, (double*)h->zws.p);
@@ -1212,6 +1253,7 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
       for (int i = 64; i < 128; ++i) fprintf(stderr, " %lld", t[i]);
       fprintf(stderr, "\n");
     }
+    fprintf(stderr, "[gto dbg] emptiness certificates (GTO_DEBUG_CUT=10, -DGTO_DEBUG_LONGEST_WG: certified groups are looked at anyway): %lld groups claimed, %lld of them with a surviving chunk, %lld (waypoint, link) rooms below the promise\n", t[49], t[50], t[51]);
     {
       fprintf(stderr, "[gto dbg] workgroups without a surviving chunk by the index shift their closest chunk tolerates (0,1,2,...,63+):");
       for (int i = 128; i < 192; ++i) fprintf(stderr, " %lld", t[i]);

@@ -75,6 +75,9 @@ struct RobotDev {
   // reach[j]: upper bound on |dx/dq_j| over every surface point and configuration (metres per radian,
   // or 1 for a prismatic joint); < 0 disables temporal culling
   double reach[GTO_MAX_OPT];
+  // reach_link[l][j]: the same bound for the points of link l alone (0 if joint j does not move it): what a step dq moves
+  // a bounding sphere of link l by, at most (emptiness certificates, k_certify in gto_kernels.h)
+  double reach_link[GTO_MAX_LINKS][GTO_MAX_OPT];
   // moments of the gripper point cloud p_k (gto/gto_planner.py:37): K, mu = sum p, M = sum p p^T
   double grip_count, grip_mu[3], grip_M[9];
 };

@@ -292,6 +292,35 @@ def test_slots_hand_over_to_waiting_instances(capi, oracle_mod, monkeypatch, slo
     h.close()
 
 
+@pytest.mark.parametrize("env", [{"GTO_CERTIFY": "0"}, {"GTO_CERT_FROM": "1"}, {"GTO_SLOTS": "96"}, {"GTO_SLOTS": "96", "GTO_CERTIFY": "0"},
+                                 {"GTO_OBS_TG": "2"}, {"GTO_FEW_INSTANCES": "16"}])
+def test_emptiness_certificates_do_not_change_results(capi, oracle_mod, monkeypatch, env):
+    """In the rounds that fill the GPU, k_certify settles the (job, group) pairs whose bounding spheres provably stay clear
+    of every non-zero voxel record (room found by the last look at the iterate, less what the step can move a sphere by)
+    without a workgroup of the obstacle kernel: exact zeros either way, so switching the certificates off, starting them
+    in the first round, refilling positions mid-call (96 positions for 160 instances) or changing the group size gives
+    bit-for-bit the same trajectories, costs and iteration counts; and they match the oracle, which culls nothing."""
+    prob = Problem("panda_5k", B=160, scene_seed=5, n=64, res=0.035, n_goals=1)
+    h, o = make_pair(capi, oracle_mod, prob, max_iter=40)
+    ref = h.solve_batch(*prob.solve_args())
+    for kn, va in env.items():
+        monkeypatch.setenv(kn, va)
+    h2 = capi.SolverHandle(prob.desc, prob.cfg["link_ee"], prob.cfg["link_gripper"], oracle_mod.reference_opts(max_iter=40), device=0)
+    h2.set_mode(0)
+    h2.set_scene(*prob.scene_args())
+    got = h2.solve_batch(*prob.solve_args())
+    for a, b in zip(ref, got):
+        np.testing.assert_array_equal(a, b)
+    sub = slice(0, 12)
+    args = list(prob.solve_args())
+    args_sub = (args[0], args[1][sub], args[2][sub], args[3], args[4], args[5][sub], args[6][sub])
+    Qo, dQo, fo, ito, sto = o.solve_batch(*args_sub)
+    np.testing.assert_array_equal(ref[3][sub], ito)
+    np.testing.assert_allclose(ref[0][sub], Qo, rtol=0, atol=1e-6)
+    h2.close()
+    h.close()
+
+
 @pytest.mark.parametrize("knob,value", [("GTO_OBS_TG", "1"), ("GTO_OBS_TG", "2"), ("GTO_OBS_TG", "4"), ("GTO_OBS_INTERLEAVE", "0"),
                                         ("GTO_OBS_INTERLEAVE", "1"), ("GTO_AHEAD", "1"), ("GTO_AHEAD", "24"),
                                         ("GTO_STEP_NW_FEW", "4"), ("GTO_DIST_RELAX", "1"), ("GTO_FEW_INSTANCES", "0"),
