@@ -77,6 +77,7 @@ struct gto_handle {
   // instances in flight, where the longest workgroup decides the round (+5 % for one batch at a time, -2 % at saturation)
   int obs_interleave = 2;
   int certify = 1;  // GTO_CERTIFY=0: every (job, group) is looked at in every round
+  int cert_kernel = 0;  // GTO_CERT_KERNEL=1: the certificates by a kernel of their own (k_certify) instead of the step kernel's tail
   int cert_from = 4;  // GTO_CERT_FROM: first round with certificates of a call all of whose instances start together
   size_t dbg_extra_lds = 0;  // GTO_DEBUG_EXTRA_LDS: occupancy experiments  // GTO_DEBUG_CUT: timing experiments only, results are garbage
   int obs_tg_few = 2;  // ... when few instances are in flight (one small batch, the tail of a call): lower latency per round; results do not depend on the group size
@@ -224,6 +225,7 @@ int gto_create(const gto_robot_desc* d, const gto_solver_opts* opts, int device,
   if (const char* e = getenv("GTO_OBS_DEEP")) h->obs_deep = atoi(e) ? 1 : 0;
   if (const char* e = getenv("GTO_CERTIFY")) h->certify = atoi(e) != 0;
   if (const char* e = getenv("GTO_CERT_FROM")) h->cert_from = std::max(1, atoi(e));
+  if (const char* e = getenv("GTO_CERT_KERNEL")) h->cert_kernel = atoi(e) != 0;
   if (const char* e = getenv("GTO_OBS_INTERLEAVE")) h->obs_interleave = std::max(0, std::min(2, atoi(e)));
   if (const char* e = getenv("GTO_DIST_RELAX")) h->dist_relax = atoi(e) ? 1 : 0;
   if (const char* e = getenv("GTO_DEBUG_CUT")) h->dbg_cut = atoi(e);
@@ -871,7 +873,7 @@ static SolveParams make_params(const gto_handle* h, int n_max, bool use_standoff
   sp.lambda0 = o.lambda0;
   sp.dbg_cut = h->dbg_cut;
   sp.interleave = h->obs_interleave == 1;
-  sp.certify = 0, sp.cert_tg = 1, sp.cert_ng = 1;
+  sp.certify = 0, sp.cert_tg = 1, sp.cert_ng = 1, sp.cert_next = 0;
   sp.round = sp.parity = 0;
   sp.kcap = h->np == GTO_NB ? GTO_KSPEC : 1;  // candidate copies of the workspace (the wide step kernel generates one)
   sp.k_acc = sp.k_rej = sp.k_eval = 1;
@@ -1140,6 +1142,15 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
     bp.work = (unsigned long long*)h->counters.p;
     HIPCHK(h, hipMemsetAsync(bp.work, 0, 64 * sizeof(unsigned long long), st));
   }
+  // emptiness certificates in the rounds that fill the GPU: the step kernel (or, GTO_CERT_KERNEL=1 and the verification
+  // mode, k_certify) settles the groups it can and lists the others
+  const int cert_tg = std::max(1, std::min(h->obs_tg, T - 2)), cert_ng = (T - 2 + cert_tg - 1) / cert_tg;
+  const bool cert_ok = bp.items != nullptr && cert_ng <= 64 && cert_tg * h->rb.n_links <= 64 && h->obs_interleave != 1;
+  const int cert_verify = h->dbg_cut == 10;
+  const bool cert_fused = cert_ok && !cert_verify && !h->cert_kernel;
+  sp.cert_tg = cert_tg, sp.cert_ng = cert_ng;
+  // round 0 of a call with waiting instances: every group of every seed is on the list (k_lm_init writes it)
+  sp.cert_next = cert_fused && std::min(W, B) > h->few_instances && B > W;
   if (h->np == GTO_NB) hipLaunchKernelGGL(k_lm_init<GTO_NB>, dim3(B), dim3(256), 0, st, h->d_rb, bp, sp, B, 0);
   else hipLaunchKernelGGL(k_lm_init<16>, dim3(B), dim3(256), 0, st, h->d_rb, bp, sp, B, 0);
   {
@@ -1153,17 +1164,13 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
   const int max_rounds = ((B + W - 1) / W + 1) * (sp.max_iter + 2);
   int known_done = 0, seen_round = -1;
   int k_prev = 1;  // candidates per instance the last step launch may have generated
-  // emptiness certificates in the rounds that fill the GPU: k_certify settles the groups it can and lists the others
-  const int cert_tg = std::max(1, std::min(h->obs_tg, T - 2)), cert_ng = (T - 2 + cert_tg - 1) / cert_tg;
-  const bool cert_ok = bp.items != nullptr && cert_ng <= 64 && cert_tg * h->rb.n_links <= 64 && h->obs_interleave != 1;
-  const int cert_verify = h->dbg_cut == 10;
-  bool items_ready = false;
+  bool items_ready = sp.cert_next != 0;
   auto launch_certify = [&](int pn, int n_jobs) {
     hipLaunchKernelGGL(k_certify, dim3(n_jobs), dim3(256), 0, st, h->d_rb, bp, sp, B, pn, cert_tg, cert_ng,
                        (int)((size_t)W * sp.kcap * (T - 2) + 64), cert_verify);
     items_ready = true;
   };
-  if (cert_ok && std::min(W, B) > h->few_instances && B > W) launch_certify(0, std::min(W, B));
+  if (cert_ok && !cert_fused && std::min(W, B) > h->few_instances && B > W) launch_certify(0, std::min(W, B));
   auto read_progress = [&]() {
     const unsigned long long p0 = __atomic_load_n(h->h_progress, __ATOMIC_RELAXED), p1 = __atomic_load_n(h->h_progress + 1, __ATOMIC_RELAXED);
     if ((unsigned)(p0 >> 32) == h->progress_tag) known_done = std::max(known_done, (int)(p0 & 0xffffffffull));
@@ -1218,14 +1225,18 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
         sp.k_rej = in_flight <= h->spec_few ? std::min(h->spec_rej, h->spec_kmax) : 1;
         sp.k_acc = in_flight <= std::min(h->spec_deep, h->spec_few) ? std::min(h->spec_acc, h->spec_kmax) : 1;
         const int kl = std::max(sp.k_acc, sp.k_rej);
+        sp.cert_next = 0;
         hipLaunchKernelGGL((k_lm_step<8, GTO_KSPEC>), dim3(in_flight), dim3(512), lm_lds_bytes(T, kl), st, h->d_rb, bp, sp, B);
         k_prev = kl;
       } else {
         sp.k_acc = sp.k_rej = 1;
+        // (a call without waiting instances is young in its first rounds: steps too long for any room)
+        const bool cert_now = cert_ok && !few && (B > W || k + 1 >= h->cert_from);
+        sp.cert_next = cert_now && cert_fused;
         hipLaunchKernelGGL((k_lm_step<4, 1>), dim3(in_flight), dim3(256), h->lm_lds, st, h->d_rb, bp, sp, B);
         k_prev = 1;
-        // (a call without waiting instances is young in its first rounds: steps too long for any room)
-        if (cert_ok && !few && (B > W || k + 1 >= h->cert_from)) launch_certify((k + 1) & 1, in_flight);
+        if (cert_now && !cert_fused) launch_certify((k + 1) & 1, in_flight);
+        else if (cert_now) items_ready = true;
       }
     } else {
       hipLaunchKernelGGL(k_lm_step_wide<16>, dim3(in_flight), dim3(256), h->lm_lds, st, h->d_rb, bp, sp, B, (double*)h->zws.p);
