@@ -78,6 +78,7 @@ struct gto_handle {
   int obs_interleave = 2;
   int certify = 1;  // GTO_CERTIFY=0: every (job, group) is looked at in every round
   int cert_kernel = 0;  // GTO_CERT_KERNEL=1: the certificates by a kernel of their own (k_certify) instead of the step kernel's tail
+  double cert_min_gain = 0.10;  // GTO_CERT_MIN_GAIN: a call whose certificates settle less than this share of the groups stops asking for them
   int cert_from = 4;  // GTO_CERT_FROM: first round with certificates of a call all of whose instances start together
   size_t dbg_extra_lds = 0;  // GTO_DEBUG_EXTRA_LDS: occupancy experiments  // GTO_DEBUG_CUT: timing experiments only, results are garbage
   int obs_tg_few = 2;  // ... when few instances are in flight (one small batch, the tail of a call): lower latency per round; results do not depend on the group size
@@ -226,6 +227,7 @@ int gto_create(const gto_robot_desc* d, const gto_solver_opts* opts, int device,
   if (const char* e = getenv("GTO_CERTIFY")) h->certify = atoi(e) != 0;
   if (const char* e = getenv("GTO_CERT_FROM")) h->cert_from = std::max(1, atoi(e));
   if (const char* e = getenv("GTO_CERT_KERNEL")) h->cert_kernel = atoi(e) != 0;
+  if (const char* e = getenv("GTO_CERT_MIN_GAIN")) h->cert_min_gain = atof(e);
   if (const char* e = getenv("GTO_OBS_INTERLEAVE")) h->obs_interleave = std::max(0, std::min(2, atoi(e)));
   if (const char* e = getenv("GTO_DIST_RELAX")) h->dist_relax = atoi(e) ? 1 : 0;
   if (const char* e = getenv("GTO_DEBUG_CUT")) h->dbg_cut = atoi(e);
@@ -1164,7 +1166,7 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
   const int max_rounds = ((B + W - 1) / W + 1) * (sp.max_iter + 2);
   int known_done = 0, seen_round = -1;
   int k_prev = 1;  // candidates per instance the last step launch may have generated
-  bool items_ready = sp.cert_next != 0;
+  bool items_ready = sp.cert_next != 0, cert_off = false;
   auto launch_certify = [&](int pn, int n_jobs) {
     hipLaunchKernelGGL(k_certify, dim3(n_jobs), dim3(256), 0, st, h->d_rb, bp, sp, B, pn, cert_tg, cert_ng,
                        (int)((size_t)W * sp.kcap * (T - 2) + 64), cert_verify);
@@ -1211,7 +1213,7 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
     const int tg = few ? h->obs_tg_few : h->obs_tg;
     sp.interleave = h->obs_interleave == 1 || (h->obs_interleave == 2 && few);
     const bool itemized = items_ready && !few;
-    sp.certify = cert_ok && !few;  // the looks of the rounds that fill the GPU leave their rooms
+    sp.certify = cert_ok && !cert_off && !few;  // the looks of the rounds that fill the GPU leave their rooms
     sp.cert_tg = cert_tg, sp.cert_ng = cert_ng;
     items_ready = false;
     sp.round = k;
@@ -1231,7 +1233,16 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
       } else {
         sp.k_acc = sp.k_rej = 1;
         // (a call without waiting instances is young in its first rounds: steps too long for any room)
-        const bool cert_now = cert_ok && !few && (B > W || k + 1 >= h->cert_from);
+        // ... and a call where they settle next to nothing (a robot inside a shelf) stops asking for them: the last itemized
+    // round the host has seen listed more than GTO_CERT_MIN_GAIN of its (job, group) pairs
+    if (cert_ok && !cert_off) {
+      const unsigned long long p2 = __atomic_load_n(h->h_progress + 2, __ATOMIC_RELAXED);
+      if ((unsigned)(p2 >> 32) == h->progress_tag) {
+        const double jobs_seen = (double)((p2 >> 20) & 0xfffull), items_seen = (double)(p2 & 0xfffffull);
+        if (jobs_seen > 0 && items_seen > 0 && k >= 12 && items_seen > (1.0 - h->cert_min_gain) * jobs_seen * cert_ng) cert_off = true;
+      }
+    }
+    const bool cert_now = cert_ok && !cert_off && !few && (B > W || k + 1 >= h->cert_from);
         sp.cert_next = cert_now && cert_fused;
         hipLaunchKernelGGL((k_lm_step<4, 1>), dim3(in_flight), dim3(256), h->lm_lds, st, h->d_rb, bp, sp, B);
         k_prev = 1;
