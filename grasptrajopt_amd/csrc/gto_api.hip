@@ -1235,7 +1235,7 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
         // (a call without waiting instances is young in its first rounds: steps too long for any room)
         // ... and a call where they settle next to nothing (a robot inside a shelf) stops asking for them: the last itemized
     // round the host has seen listed more than GTO_CERT_MIN_GAIN of its (job, group) pairs
-    if (cert_ok && !cert_off) {
+    if (cert_ok && !cert_off && !cert_verify) {
       const unsigned long long p2 = __atomic_load_n(h->h_progress + 2, __ATOMIC_RELAXED);
       if ((unsigned)(p2 >> 32) == h->progress_tag) {
         const double jobs_seen = (double)((p2 >> 20) & 0xfffull), items_seen = (double)(p2 & 0xfffffull);
