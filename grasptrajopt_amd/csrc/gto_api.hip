@@ -68,6 +68,7 @@ struct gto_handle {
   // launches with few instances in flight (more work, fewer dependent rounds); after an accepted evaluation once at most
   // `spec_deep` instances are in flight (the GPU is nearly idle then: every candidate is free)
   int spec_rej = 4, spec_acc = 3, spec_deep = 6, spec_kmax = 1;
+  int obs_deep_max = 32;  // GTO_OBS_DEEP_MAX: ... only up to this many instances in flight (two workgroups per CU: beyond that the five-per-CU variant gets through a launch faster)
   int obs_deep = 1;   // GTO_OBS_DEEP: launches with few instances in flight use the obstacle kernel variant with deep gather batches
   int spec_few = 16;  // GTO_SPEC_FEW: speculation starts once at most this many instances are in flight: before that the GPU is full and every extra evaluation costs time
   int dbg_cut = 0;
@@ -223,6 +224,7 @@ int gto_create(const gto_robot_desc* d, const gto_solver_opts* opts, int device,
   if (const char* e = getenv("GTO_SPEC_ACC")) h->spec_acc = std::max(1, std::min(GTO_KSPEC, atoi(e)));
   if (const char* e = getenv("GTO_SPEC_DEEP")) h->spec_deep = std::max(0, atoi(e));
   if (const char* e = getenv("GTO_SPEC_FEW")) h->spec_few = std::max(0, atoi(e));
+  if (const char* e = getenv("GTO_OBS_DEEP_MAX")) h->obs_deep_max = std::max(0, atoi(e));
   if (const char* e = getenv("GTO_OBS_DEEP")) h->obs_deep = atoi(e) ? 1 : 0;
   if (const char* e = getenv("GTO_CERTIFY")) h->certify = atoi(e) != 0;
   if (const char* e = getenv("GTO_CERT_FROM")) h->cert_from = std::max(1, atoi(e));
@@ -1220,7 +1222,7 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
     sp.parity = k & 1;
     // the goal workgroups skip fresh instances themselves: k_lm_init already produced the seed's goal terms
     sp.k_eval = k_prev;
-    if ((rc = launch_obstacle(h, st, bp, sp, B, 2, T - 2, 0, h->profiling, true, in_flight * k_prev, tg, few && h->obs_deep, itemized))) { rc_loop = rc; break; }
+    if ((rc = launch_obstacle(h, st, bp, sp, B, 2, T - 2, 0, h->profiling, true, in_flight * k_prev, tg, few && h->obs_deep && in_flight <= h->obs_deep_max, itemized))) { rc_loop = rc; break; }
     if (h->np == GTO_NB) {
       if (few && h->step_nw_few == 8) {
         // few instances in flight: eight waves per instance and candidate trial points ahead of their evaluation
