@@ -70,7 +70,7 @@ struct gto_handle {
   int spec_rej = 4, spec_acc = 3, spec_deep = 6, spec_kmax = 1;
   int obs_deep_max = 32;  // GTO_OBS_DEEP_MAX: ... only up to this many instances in flight (two workgroups per CU: beyond that the five-per-CU variant gets through a launch faster)
   int obs_deep = 1;   // GTO_OBS_DEEP: launches with few instances in flight use the obstacle kernel variant with deep gather batches
-  int spec_few = 16;  // GTO_SPEC_FEW: speculation starts once at most this many instances are in flight: before that the GPU is full and every extra evaluation costs time
+  int spec_few = 32;  // GTO_SPEC_FEW: speculation starts once at most this many instances are in flight: before that the GPU is full and every extra evaluation costs time
   int dbg_cut = 0;
   int dist_relax = 0;  // GTO_DIST_RELAX: build the distance fields by relaxation sweeps instead of the separable passes
   // GTO_OBS_INTERLEAVE: waypoints of an obstacle workgroup nG apart instead of consecutive, so that the waypoints next to
