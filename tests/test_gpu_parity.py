@@ -321,6 +321,30 @@ def test_emptiness_certificates_do_not_change_results(capi, oracle_mod, monkeypa
     h.close()
 
 
+@pytest.mark.parametrize("robot,shelf", [("fetch", False), ("fetch", True)])
+def test_emptiness_certificates_other_robot(capi, oracle_mod, monkeypatch, robot, shelf):
+    """The same on a robot with another link count, collision links on fixed frames (the world frame of the obstacle kernel's
+    compact tree, static links in the room bookkeeping) and, in the shelf, next to nothing to certify (the call switches the
+    certificates off after round 12): bit-identical with and without them, and equal to the oracle."""
+    prob = Problem(robot, B=130, scene_seed=4, n=64, res=0.035, n_goals=1, shelf=shelf)
+    h, o = make_pair(capi, oracle_mod, prob, max_iter=30)
+    ref = h.solve_batch(*prob.solve_args())
+    monkeypatch.setenv("GTO_CERTIFY", "0")
+    h2 = capi.SolverHandle(prob.desc, prob.cfg["link_ee"], prob.cfg["link_gripper"], oracle_mod.reference_opts(max_iter=30), device=0)
+    h2.set_mode(0)
+    h2.set_scene(*prob.scene_args())
+    got = h2.solve_batch(*prob.solve_args())
+    for a, b in zip(ref, got):
+        np.testing.assert_array_equal(a, b)
+    sub = slice(0, 10)
+    args = list(prob.solve_args())
+    Qo, dQo, fo, ito, sto = o.solve_batch(args[0], args[1][sub], args[2][sub], args[3], args[4], args[5][sub], args[6][sub])
+    np.testing.assert_array_equal(ref[3][sub], ito)
+    np.testing.assert_allclose(ref[0][sub], Qo, rtol=0, atol=1e-6)
+    h2.close()
+    h.close()
+
+
 @pytest.mark.parametrize("knob,value", [("GTO_OBS_TG", "1"), ("GTO_OBS_TG", "2"), ("GTO_OBS_TG", "4"), ("GTO_OBS_INTERLEAVE", "0"),
                                         ("GTO_OBS_INTERLEAVE", "1"), ("GTO_AHEAD", "1"), ("GTO_AHEAD", "24"),
                                         ("GTO_STEP_NW_FEW", "4"), ("GTO_DIST_RELAX", "1"), ("GTO_FEW_INSTANCES", "0"),
