@@ -93,7 +93,19 @@ def quality_block(desc, cfg, h, sid, Q, RT, Q0, iters, status, max_iter, in_coll
             "goal_miss_converged_frac": round(float((status[miss] == 0).mean()), 3) if miss.any() else None}
 
 
-def main():
+def lib_sha16():
+    """sha256 (first 16 hex digits) over the sources the HIP library is built from, in the order of __graft_entry__.HIP_DEPS:
+    ties a bench line (and every file under profiles/ that carries it) to the code it measured."""
+    import hashlib
+    import __graft_entry__ as g
+    hsh = hashlib.sha256()
+    for d in g.HIP_DEPS:
+        with open(d if os.path.isabs(d) else os.path.join(g.CSRC, d), "rb") as fh:
+            hsh.update(fh.read())
+    return hsh.hexdigest()[:16]
+
+
+def main(argv=None, emit=True):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=512)
@@ -126,9 +138,15 @@ def main():
     ap.add_argument("--repeats", type=int, default=5,
                     help="the timed region (exactly --steps steps, barrier + synchronize on both sides) is run this many times "
                          "back to back; ms_per_step / value are the MEDIAN region, min and max are reported beside it")
-    args = ap.parse_args()
+    ap.add_argument("--light", action="store_true",
+                    help="a second workload inside another bench line (other_configs): timed regions, roofline, invariants and an "
+                         "oracle spot check only")
+    ap.add_argument("--oracle-check", type=int, default=0, help="instances of the first batch solved again by the CPU oracle (iterations equal, max |dQ|)")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the other_configs object (BASELINE configs[2] and [4] at reduced step counts)")
+    args = ap.parse_args(argv)
+    child = argv is not None  # a workload measured inside another bench line: no process group, nothing printed
 
-    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1 and not child:
         raise SystemExit(spawn_ranks(args.gpus))
 
     # the HIP runtime multiplexes streams onto this many hardware queues (default 4); the pipeline lanes
@@ -137,8 +155,8 @@ def main():
     import torch
     import torch.distributed as dist
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = 0 if child else int(os.environ.get("RANK", "0"))
+    world = 1 if child else int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and rank == 0:
         print(f"[bench] WORLD_SIZE={world} != --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
@@ -159,8 +177,12 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
     import __graft_entry__ as g
-    if not os.path.exists(g.HIP_LIB):
-        g.build()
+    if "GTO_HIP_LIB" not in os.environ:  # (an A/B run names its own library)
+        if world > 1 and rank != 0:  # one node: rank 0 builds, the others wait for it
+            dist.barrier()
+        g.build()  # mtime-checked against every source: a stale library is never what gets measured
+        if world > 1 and rank == 0:
+            dist.barrier()
     from grasptrajopt_amd import _capi, synthetic as syn
     from grasptrajopt_amd.parallel import BatchPipeline, shard_by_scene, shard_range, solve_local_shard
     from grasptrajopt_amd.robot_desc import load_builtin
@@ -300,6 +322,8 @@ def main():
     el_all, cpu_all = timed_regions("step")
     # ---- SURVEY.md 8d's literal metric: the same K steps through the host-pointer entry point on the same lanes
     host_all = None
+    if args.light:
+        args.merged_launches_only = True
     if not args.merged_launches_only:
         # warm-up of the host-pointer path: its staging buffers are allocated by the first call, and one of the first few
         # calls after that takes 5-10 ms longer (measured, once per process; not in the library's own code path)
@@ -310,7 +334,7 @@ def main():
     ln0 = lanes[0]
     # a lane's results do not depend on what the other lanes do: lane 0 solves lane 1's batches again, alone on the GPU
     lanes_reproducible = None
-    if D > 1:
+    if D > 1 and not args.light:
         m1 = max(launch_plan(args.steps))
         ref_Q, ref_it = lanes[1].d_Q[:m1 * B].clone(), lanes[1].d_it[:m1 * B].clone()
         keep = [x.clone() for x in ln0.inp]
@@ -345,6 +369,7 @@ def main():
     h.set_profiling(True)
     kern_ms, kern_launches, prof_steps, gathered, tested = 0.0, 0, 0, 0, 0
     plan = launch_plan(args.steps)
+    variants = {}  # kernel variant -> [ms, launches, workgroups, points gathered] over the calls of the region
     for m in plan:
         ln0.step(m)
         ms, nl = h.last_kernel_time()
@@ -354,6 +379,11 @@ def main():
         gathered += pts
         tested += tst
         prof_steps += m
+        if args.mode == "rounds":
+            for name_, row in h.last_kernel_profile().items():
+                acc_ = variants.setdefault(name_, [0.0, 0, 0, 0])
+                for i_ in range(4):
+                    acc_[i_] += row[i_]
     barrier()
     h.set_profiling(False)
     ln0.step(M)  # full outputs again for the quality gate
@@ -426,7 +456,8 @@ def main():
         solve_local_shard(hs_.solve_batch, *sargs, B=nI, rank=rank, world=world, assignment=owner)  # warm-up
         barrier()
         tss = time.perf_counter()
-        idx, Qa, _, ca, ia, sa = solve_local_shard(hs_.solve_batch, *sargs, B=nI, rank=rank, world=world, assignment=owner)
+        gstats = {}
+        idx, Qa, _, ca, ia, sa = solve_local_shard(hs_.solve_batch, *sargs, B=nI, rank=rank, world=world, assignment=owner, stats=gstats)
         barrier()
         els = torch.tensor([time.perf_counter() - tss], dtype=torch.float64, device=comm_dev)
         if world > 1:
@@ -443,6 +474,39 @@ def main():
                          "max_joint_limit_violation": float(np.maximum(desc.lower[oi_][None, :, None] - Qa[:, oi_], Qa[:, oi_] - desc.upper[oi_][None, :, None]).max())}
         hs_.close()
 
+    # ---- N > 1: what the collectives ran on, so that the first multi-GPU record shows "RCCL saw N ranks on N distinct
+    # devices" and whether N x (lanes + polling host threads) fit the host: gathered from every rank
+    collective = None
+    if world > 1:
+        def cpu_quota():
+            try:  # cgroup v2: "max 100000" or "<quota> <period>"
+                q_, p_ = open("/sys/fs/cgroup/cpu.max").read().split()
+                return None if q_ == "max" else round(int(q_) / int(p_), 2)
+            except Exception:
+                return None
+        try:
+            bus = torch.cuda.get_device_properties(dev).pci_bus_id
+        except Exception:
+            bus = None
+        mine_ = {"rank": rank, "local_rank": local_rank, "device_index": torch.cuda.current_device(), "pci_bus_id": bus,
+                 "device_name": torch.cuda.get_device_name(dev), "host_cpu_cores_busy": round(float(np.median(cpu_all)) / float(np.median(el_all)), 2),
+                 "pid": os.getpid(), "all_gather": dict(gstats)}  # the scene-sharded leg always runs with N > 1
+        rows_ = [None] * world
+        dist.all_gather_object(rows_, mine_)
+        nccl_v = None
+        if args.backend == "nccl":
+            try:
+                nccl_v = ".".join(str(x) for x in torch.cuda.nccl.version())
+            except Exception:
+                nccl_v = None
+        collective = {"backend": dist.get_backend(), "is_rccl": args.backend == "nccl", "world_size": dist.get_world_size(),
+                      "nccl_version": nccl_v, "ranks": rows_,
+                      "distinct_devices": len({(r_["device_index"], r_["pci_bus_id"]) for r_ in rows_}),
+                      "cgroup_cpu_quota_cores": cpu_quota(), "host_hardware_threads": os.cpu_count(),
+                      "host_cpu_cores_busy_all_ranks": round(sum(r_["host_cpu_cores_busy"] for r_ in rows_), 2),
+                      "data_path_collectives": "none inside the solve; one all_gather pair (float64 trajectories, int32 iterations/status) of the "
+                                               "scene-sharded leg's results, two all_reduce of timings"}
+
     rc = 0
     if rank == 0:
         quality = quality_block(desc, cfg, h, 0, Qsol, RT, Q0, iters, status, args.max_iter)
@@ -457,67 +521,72 @@ def main():
         seedc[:, :, :2] = qc[:, :, None]
         sg_, so_, sv_, _ = h.eval_objective(0, RT.reshape(NB, 1, 16), 1, S[0].reshape(4, 4), [0.0, 0.0, 0.0], seedc)
         quality["objective_le_seed_frac"] = round(float((cost <= (sg_ + so_ + sv_) * (1 + 1e-12)).mean()), 4)
-        # what the shipped stopping tolerance (tol_rel_f) leaves on the table: the first batch again with a tolerance five
-        # orders tighter and three times the iteration cap, objective against objective
-        tol0, it0 = opts.tol_rel_f, opts.max_iter
-        h.set_opts(tol_rel_f=tol0 * 1e-5, max_iter=3 * it0)
-        _, _, f_tight, it_tight, _ = h.solve_batch(0, qc[:B], RT[:B].reshape(B, 1, 16), 1, S[:B], base[:B], Q0[:B])
-        h.set_opts(tol_rel_f=tol0, max_iter=it0)
-        gap = (cost[:B] - f_tight) / np.maximum(f_tight, 1e-300)
-        quality["stopping_tolerance_check"] = {"tol_rel_f": tol0, "tight_tol_rel_f": tol0 * 1e-5, "tight_max_iter": 3 * it0,
-                                               "f_excess_rel_max": float(gap.max()), "f_excess_rel_mean": float(gap.mean()),
-                                               "f_excess_rel_max_converged": float(gap[status[:B] == 0].max()) if (status[:B] == 0).any() else None,
-                                               "iters_mean": round(float(iters[:B].mean()), 2), "iters_mean_tight": round(float(it_tight.mean()), 2)}
-        # gate: joint limits and the objective invariant always; compute_plan_cost against the seed's where the seed is a
-        # collision-scored trajectory (interpolated seeds; the hold-and-jump seeds of shelf scenes cost nothing by construction)
-        gate_ok = quality["max_joint_limit_violation"] <= 1e-8 and quality["objective_le_seed_frac"] == 1.0
-        # ... and the stopping tolerance may not cost a converged instance more than 1e-4 of its objective
-        gate_ok = gate_ok and (quality["stopping_tolerance_check"]["f_excess_rel_max_converged"] or 0.0) <= 1e-4
-        if not args.shelf:
-            gate_ok = gate_ok and quality["plan_cost_le_seed_frac"] >= 0.95
-        # ---- what the north star's gradient choice buys: the first batch again with GTO_GRAD_ZERO, the reference-faithful
-        # obstacle gradient (CasADi differentiates neither floor() nor the parametric gather: SURVEY.md Appendix B-1), same
-        # statistics on the same 64 instances next to the shipped GTO_GRAD_CENTRAL_DIFF
-        gm0 = opts.grad_mode
-        same = (0, qc[:B], RT[:B].reshape(B, 1, 16), 1, S[:B], base[:B], Q0[:B])
-        by_grad = {}
-        for name_, gm in (("central_diff", _capi.GTO_GRAD_CENTRAL_DIFF), ("zero", _capi.GTO_GRAD_ZERO)):
-            h.set_opts(grad_mode=gm)
-            Qg_, _, fg_, itg_, stg_ = h.solve_batch(*same)
-            qb_ = quality_block(desc, cfg, h, 0, Qg_, RT[:B], Q0[:B], itg_.astype(np.int64), stg_, args.max_iter)
-            by_grad[name_] = {k_: qb_[k_] for k_ in ("goal_ok_frac", "goal_err_pos_max_m", "goal_err_rot_max_deg", "plans_in_collision_frac",
-                                                      "plan_cost_le_seed_frac", "max_joint_limit_violation")}
-            by_grad[name_].update({"f_mean": round(float(fg_.mean()), 5), "iters_mean": round(float(itg_.mean()), 2)})
-        h.set_opts(grad_mode=gm0)
-        quality["by_obstacle_gradient"] = dict(by_grad, what="first batch (64 instances) solved with each grad_mode; `zero` is what reaches IPOPT "
-                                                             "in the reference (value only), `central_diff` is shipped (gto/sdf_callback.py:90-114 numerics)")
-        gate_ok = gate_ok and by_grad["central_diff"]["plans_in_collision_frac"] <= by_grad["zero"]["plans_in_collision_frac"]
-        # ---- goal sets of eight, what plan_goalset is called with (examples/pybullet_gto_planning.py:291): instance b gets
-        # eight grasps of the lane's list, its seed is the least colliding / shortest of the eight interpolated plans
-        # (gto/gto_planner.py:197-213), the goal error is taken against the goal the solver ends at (arg-min of the set)
-        G8 = 8
-        if NB >= B * G8 and not args.shelf:
-            RT8 = RT[:B * G8].reshape(B, G8, 4, 4)
-            seeds8 = Q0[:B * G8].reshape(B, G8, ndof, T)
-            pick = np.zeros(B, dtype=np.int64)
-            for b_ in range(B):
-                pc_, pd_ = h.plan_cost(0, seeds8[b_], [0.0, 0.0, 0.0])
-                pick[b_] = int(np.lexsort((pd_, pc_))[0])
-            Q08 = seeds8[np.arange(B), pick]
-            args8 = (0, qc[:B], RT8.reshape(B, G8, 16), G8, S[:B], base[:B], Q08)
-            h.solve_batch(*args8)
-            t8 = time.perf_counter()
-            Q8, _, f8, it8, st8 = h.solve_batch(*args8)
-            t8 = time.perf_counter() - t8
-            _, _, _, am8 = h.eval_objective(0, RT8.reshape(B, G8, 16), G8, S[0].reshape(4, 4), [0.0, 0.0, 0.0], Q8)
-            qb8 = quality_block(desc, cfg, h, 0, Q8, RT8[np.arange(B), am8], Q08, it8.astype(np.int64), st8, args.max_iter)
-            quality["goal_sets_of_8"] = dict({k_: qb8[k_] for k_ in ("goal_ok_frac", "goal_err_pos_max_m", "goal_err_rot_max_deg", "plans_in_collision_frac",
-                                                                       "plan_cost_le_seed_frac", "max_joint_limit_violation")},
-                                             instances=B, goals_per_instance=G8, iters_mean=round(float(it8.mean()), 2), iters_max=int(it8.max()),
-                                             f_mean=round(float(f8.mean()), 5), ms_one_call_host_api=round(1e3 * t8, 3),
-                                             trajectories_per_s_one_call=round(B / t8, 1), goals_reached_distinct=int(len(np.unique(am8))),
-                                             what="64 instances x goal sets of 8 grasps (plan_goalset's call shape), one solver call through the host-pointer API")
-            gate_ok = gate_ok and qb8["max_joint_limit_violation"] <= 1e-8
+        light_gate = None
+        if args.light:  # a second workload inside another bench line: the invariants only
+            light_gate = quality["max_joint_limit_violation"] <= 1e-8 and quality["objective_le_seed_frac"] == 1.0
+        gate_ok = bool(light_gate)
+        if not args.light:
+            # what the shipped stopping tolerance (tol_rel_f) leaves on the table: the first batch again with a tolerance five
+            # orders tighter and three times the iteration cap, objective against objective
+            tol0, it0 = opts.tol_rel_f, opts.max_iter
+            h.set_opts(tol_rel_f=tol0 * 1e-5, max_iter=3 * it0)
+            _, _, f_tight, it_tight, _ = h.solve_batch(0, qc[:B], RT[:B].reshape(B, 1, 16), 1, S[:B], base[:B], Q0[:B])
+            h.set_opts(tol_rel_f=tol0, max_iter=it0)
+            gap = (cost[:B] - f_tight) / np.maximum(f_tight, 1e-300)
+            quality["stopping_tolerance_check"] = {"tol_rel_f": tol0, "tight_tol_rel_f": tol0 * 1e-5, "tight_max_iter": 3 * it0,
+                                                   "f_excess_rel_max": float(gap.max()), "f_excess_rel_mean": float(gap.mean()),
+                                                   "f_excess_rel_max_converged": float(gap[status[:B] == 0].max()) if (status[:B] == 0).any() else None,
+                                                   "iters_mean": round(float(iters[:B].mean()), 2), "iters_mean_tight": round(float(it_tight.mean()), 2)}
+            # gate: joint limits and the objective invariant always; compute_plan_cost against the seed's where the seed is a
+            # collision-scored trajectory (interpolated seeds; the hold-and-jump seeds of shelf scenes cost nothing by construction)
+            gate_ok = quality["max_joint_limit_violation"] <= 1e-8 and quality["objective_le_seed_frac"] == 1.0
+            # ... and the stopping tolerance may not cost a converged instance more than 1e-4 of its objective
+            gate_ok = gate_ok and (quality["stopping_tolerance_check"]["f_excess_rel_max_converged"] or 0.0) <= 1e-4
+            if not args.shelf:
+                gate_ok = gate_ok and quality["plan_cost_le_seed_frac"] >= 0.95
+            # ---- what the north star's gradient choice buys: the first batch again with GTO_GRAD_ZERO, the reference-faithful
+            # obstacle gradient (CasADi differentiates neither floor() nor the parametric gather: SURVEY.md Appendix B-1), same
+            # statistics on the same 64 instances next to the shipped GTO_GRAD_CENTRAL_DIFF
+            gm0 = opts.grad_mode
+            same = (0, qc[:B], RT[:B].reshape(B, 1, 16), 1, S[:B], base[:B], Q0[:B])
+            by_grad = {}
+            for name_, gm in (("central_diff", _capi.GTO_GRAD_CENTRAL_DIFF), ("zero", _capi.GTO_GRAD_ZERO)):
+                h.set_opts(grad_mode=gm)
+                Qg_, _, fg_, itg_, stg_ = h.solve_batch(*same)
+                qb_ = quality_block(desc, cfg, h, 0, Qg_, RT[:B], Q0[:B], itg_.astype(np.int64), stg_, args.max_iter)
+                by_grad[name_] = {k_: qb_[k_] for k_ in ("goal_ok_frac", "goal_err_pos_max_m", "goal_err_rot_max_deg", "plans_in_collision_frac",
+                                                          "plan_cost_le_seed_frac", "max_joint_limit_violation")}
+                by_grad[name_].update({"f_mean": round(float(fg_.mean()), 5), "iters_mean": round(float(itg_.mean()), 2)})
+            h.set_opts(grad_mode=gm0)
+            quality["by_obstacle_gradient"] = dict(by_grad, what="first batch (64 instances) solved with each grad_mode; `zero` is what reaches IPOPT "
+                                                                 "in the reference (value only), `central_diff` is shipped (gto/sdf_callback.py:90-114 numerics)")
+            gate_ok = gate_ok and by_grad["central_diff"]["plans_in_collision_frac"] <= by_grad["zero"]["plans_in_collision_frac"]
+            # ---- goal sets of eight, what plan_goalset is called with (examples/pybullet_gto_planning.py:291): instance b gets
+            # eight grasps of the lane's list, its seed is the least colliding / shortest of the eight interpolated plans
+            # (gto/gto_planner.py:197-213), the goal error is taken against the goal the solver ends at (arg-min of the set)
+            G8 = 8
+            if NB >= B * G8 and not args.shelf:
+                RT8 = RT[:B * G8].reshape(B, G8, 4, 4)
+                seeds8 = Q0[:B * G8].reshape(B, G8, ndof, T)
+                pick = np.zeros(B, dtype=np.int64)
+                for b_ in range(B):
+                    pc_, pd_ = h.plan_cost(0, seeds8[b_], [0.0, 0.0, 0.0])
+                    pick[b_] = int(np.lexsort((pd_, pc_))[0])
+                Q08 = seeds8[np.arange(B), pick]
+                args8 = (0, qc[:B], RT8.reshape(B, G8, 16), G8, S[:B], base[:B], Q08)
+                h.solve_batch(*args8)
+                t8 = time.perf_counter()
+                Q8, _, f8, it8, st8 = h.solve_batch(*args8)
+                t8 = time.perf_counter() - t8
+                _, _, _, am8 = h.eval_objective(0, RT8.reshape(B, G8, 16), G8, S[0].reshape(4, 4), [0.0, 0.0, 0.0], Q8)
+                qb8 = quality_block(desc, cfg, h, 0, Q8, RT8[np.arange(B), am8], Q08, it8.astype(np.int64), st8, args.max_iter)
+                quality["goal_sets_of_8"] = dict({k_: qb8[k_] for k_ in ("goal_ok_frac", "goal_err_pos_max_m", "goal_err_rot_max_deg", "plans_in_collision_frac",
+                                                                           "plan_cost_le_seed_frac", "max_joint_limit_violation")},
+                                                 instances=B, goals_per_instance=G8, iters_mean=round(float(it8.mean()), 2), iters_max=int(it8.max()),
+                                                 f_mean=round(float(f8.mean()), 5), ms_one_call_host_api=round(1e3 * t8, 3),
+                                                 trajectories_per_s_one_call=round(B / t8, 1), goals_reached_distinct=int(len(np.unique(am8))),
+                                                 what="64 instances x goal sets of 8 grasps (plan_goalset's call shape), one solver call through the host-pointer API")
+                gate_ok = gate_ok and qb8["max_joint_limit_violation"] <= 1e-8
         quality["gate"] = "pass" if gate_ok else "FAIL"
         if not gate_ok:
             rc = 3
@@ -533,6 +602,7 @@ def main():
         avg_launch_us = 1e3 * kern_ms / max(kern_launches, 1)
         achieved = gathered * 28 / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
         traffic = issue = None
+        pmc_variants = {}
         tj = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tj):  # PMC figures are quoted only for the workload, mode and call size they were measured on
             for tr in json.load(open(tj)).get("entries", []):
@@ -540,14 +610,51 @@ def main():
                                                                                  tr.get("slots"), tr.get("mode", "rounds")):
                     traffic = tr.get("hbm_bytes_per_launch")
                     issue = tr.get("issue")
+                    pmc_variants = tr.get("variants", {})
+        # the same per kernel VARIANT: launches, HIP-event time, gathered points (binned by variant on the device) and PMC traffic
+        # all belong to one population, so traffic / alg_bytes_per_launch is a valid ratio; the step kernels ride along
+        loop_ms = sum(v_[0] for v_ in variants.values()) or 1.0
+        by_variant = {}
+        for name_, (ms_, nl_, wg_, pts_) in variants.items():
+            if not nl_:
+                continue
+            row = {"launches": nl_, "avg_launch_us": round(1e3 * ms_ / nl_, 2), "workgroups_per_launch": round(wg_ / nl_, 1),
+                   "share_of_solve_loop_kernel_time": round(ms_ / loop_ms, 4)}
+            if name_.startswith("k_obstacle"):
+                ach_ = pts_ * 28 / (ms_ * 1e-3) / 1e9 if ms_ > 0 else 0.0
+                pm_ = pmc_variants.get(name_, {})
+                row.update({"points_gathered_per_launch": round(pts_ / nl_), "alg_bytes_per_launch": round(pts_ * 28 / nl_),
+                            "achieved": round(ach_, 1), "frac": round(ach_ / HBM_PEAK_GBS, 4),
+                            "traffic": pm_.get("hbm_bytes_per_launch"),
+                            "traffic_over_alg_bytes": round(pm_["hbm_bytes_per_launch"] / max(pts_ * 28 / nl_, 1.0), 2) if pm_.get("hbm_bytes_per_launch") else None})
+            else:
+                pm_ = pmc_variants.get(name_, {})
+                row.update({"traffic": pm_.get("hbm_bytes_per_launch"), "fetch_bytes_per_launch": pm_.get("fetch_bytes_per_launch"),
+                            "bound": "latency (serial chain of 8x8 block eliminations per instance: DESIGN.md section 5)"})
+            by_variant[name_] = row
+        dominant = max((n_ for n_ in by_variant if n_.startswith("k_obstacle")), key=lambda n_: variants[n_][0], default=None)
+        if dominant:  # the headline figures are the dominant VARIANT's own (one population of launches)
+            kernel_name, dv = dominant, by_variant[dominant]
+            achieved, traffic = dv["achieved"], dv["traffic"]
+            avg_launch_us, kern_launches_hl, gathered_hl = dv["avg_launch_us"], dv["launches"], variants[dominant][3]
+        else:
+            kern_launches_hl, gathered_hl = kern_launches, gathered
         roofline = {"bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "bytes_per_unit": 28, "unit_of_work": "surface point looked up in a cost field (value + 6 neighbours, SURVEY.md 8d)",
-                    "points_gathered_per_launch": round(gathered / max(kern_launches, 1)),
-                    "alg_bytes_per_launch": round(gathered * 28 / max(kern_launches, 1)),
+                    "points_gathered_per_launch": round(gathered_hl / max(kern_launches_hl, 1)),
+                    "alg_bytes_per_launch": round(gathered_hl * 28 / max(kern_launches_hl, 1)),
                     "alg_bytes_skipped_frac": round(1.0 - gathered / max(full_points, 1.0), 4),
-                    "chunk_tests_per_launch": round(tested / max(kern_launches, 1)) if tested else None,
-                    "avg_launch_us": round(avg_launch_us, 2), "launches": kern_launches,
+                    "avg_launch_us": round(avg_launch_us, 2), "launches": kern_launches_hl,
+                    "variants": by_variant,
+                    # the timed regime (all lanes in flight, where launches of different lanes stretch each other): the bytes
+                    # gathered by the region's calls over the region's wall time
+                    "timed_regime": {"alg_bytes_region": int(gathered * 28), "region_ms": round(1e3 * elapsed, 3),
+                                     "achieved": round(gathered * 28 / elapsed / 1e9, 1), "frac": round(gathered * 28 / elapsed / 1e9 / HBM_PEAK_GBS, 4),
+                                     "one_lane_kernel_ms_per_step": round(loop_ms / max(prof_steps, 1), 4),
+                                     "what": "points gathered by the region's solver calls (counted while one lane repeats them) x 28 B over the "
+                                             "median timed region; one_lane_kernel_ms_per_step = kernel time of the solve loop per step with ONE "
+                                             "lane on the GPU (it exceeds ms_per_step when the lanes overlap)"},
                     "instances_per_call": B * max(plan), "slots": slots,
                     # the kernel is bound by instruction issue and latency, not by HBM: the same PMC passes give the share of the
                     # time the FP64 vector units are busy (a second roofline axis: 1.0 = every SIMD issuing vector work every cycle)
@@ -596,6 +703,52 @@ def main():
                             # goal misses are a property of (objective and weights) shows in both
                             "quality": quality_block(desc, cfg, h, 0, Qo, RT[:B], Q0[:B], ito.astype(np.int64), sto, args.max_iter),
                             "quality_gpu_same_instances": quality_block(desc, cfg, h, 0, Qsol[:B], RT[:B], Q0[:B], iters[:B], status[:B], args.max_iter)}
+
+        # ---- oracle spot check (--oracle-check n): the first n instances of the first batch again on the CPU oracle
+        oracle_check = None
+        if args.oracle_check > 0:
+            from oracle import oracle
+            oracle.build()
+            o_ = oracle.Oracle(desc, cfg["link_ee"], cfg["link_gripper"], opts, n_gripper_points=100)
+            o_.set_scene(0, sc.c_all, sc.c_obs, sc.shape, sc.origin, sc.res)
+            nc_ = min(args.oracle_check, B)
+            tco = time.perf_counter()
+            Qo_, _, fo_, ito_, sto_ = o_.solve_batch(0, qc[:nc_], RT[:nc_].reshape(nc_, 1, 16), 1, S[:nc_], base[:nc_], Q0[:nc_], n_threads=min(nc_, o_.usable_cores()))
+            oracle_check = {"instances": nc_, "iters_equal": bool(np.array_equal(ito_, iters[:nc_])), "status_equal": bool(np.array_equal(sto_, status[:nc_])),
+                            "max_abs_dQ_vs_oracle": float(np.abs(Qo_ - Qsol[:nc_]).max()),
+                            "max_rel_dcost_vs_oracle": float(np.max(np.abs(fo_ - cost[:nc_]) / np.maximum(np.abs(fo_), 1e-300))),
+                            "iters": ito_.tolist(), "seconds": round(time.perf_counter() - tco, 2)}
+            if not (oracle_check["iters_equal"] and oracle_check["max_abs_dQ_vs_oracle"] < 1e-6):
+                quality["gate"] = "FAIL"
+                rc = 3
+
+        # ---- BASELINE configs[2] and [4] on the same record (N = 1 only): each a short run of this script's own code path
+        # (four lanes, calls of 8 steps), with its own roofline and an oracle spot check on four instances
+        other_configs = None
+        if world == 1 and not child and not args.no_other_configs and not args.no_cpu_baseline and args.robot == "panda_5k" and not args.shelf:
+            other_configs = {}
+            common = ["--gpus", "1", "--light", "--no-cpu-baseline", "--no-next-rows", "--no-other-configs", "--repeats", "3", "--warmup", "1",
+                      "--oracle-check", "4", "--pipeline", str(args.pipeline)]
+            for key_, argv_ in (("configs[2] fetch_shelf_256", ["--robot", "fetch", "--batch", "256", "--shelf", "--merge", "8", "--steps", "32"]),
+                                ("configs[4] fetch_mobile_T80_256^3", ["--robot", "fetch_mobile", "--T", "80", "--grid", "256", "--shelf", "--batch", "64",
+                                                                      "--merge", "8", "--steps", "32"])):
+                t_oc = time.perf_counter()
+                try:
+                    r_ = main(common + argv_, emit=False)
+                    other_configs[key_] = {"argv": " ".join(argv_), "trajectories_per_s": r_["value"], "ms_per_step": r_["ms_per_step"],
+                                           "timed_regions": r_["timed_regions"], "workload": r_["config"]["workload"],
+                                           "iters_mean": r_["iters_mean"], "iters_max": r_["iters_max"], "status_counts": r_["status_counts"],
+                                           "roofline": {k_: r_["roofline"][k_] for k_ in ("kernel", "achieved", "frac", "points_gathered_per_launch",
+                                                                                         "alg_bytes_per_launch", "alg_bytes_skipped_frac", "avg_launch_us", "launches",
+                                                                                         "timed_regime")},
+                                           "kernel_variants": r_["roofline"]["variants"],
+                                           "oracle_check": r_["oracle_check"], "gate": r_["quality"]["gate"],
+                                           "seconds": round(time.perf_counter() - t_oc, 2)}
+                    if r_["quality"]["gate"] != "pass":
+                        rc = 3
+                except SystemExit as e_:  # the child's gate failed
+                    other_configs[key_] = {"argv": " ".join(argv_), "error": f"exit {e_.code}"}
+                    rc = 3
 
         # ---- the rows SURVEY.md 8(f) marks "next" and one plan_goalset call, with an oracle spot check each (N = 1 only)
         next_rows = None
@@ -653,14 +806,18 @@ def main():
             "quality": quality,
             "reference_published": "0.098 trajectories/s (Panda tabletop, IPOPT on unknown CPU; BASELINE.md section 1)",
             "roofline": roofline, "cpu_baseline": cpu_baseline, "scene_sharded": scene_sharded, "next_rows": next_rows,
+            "other_configs": other_configs, "oracle_check": oracle_check, "collective": collective,
+            "lib_sha16": lib_sha16(),
         }
-        print(json.dumps(out))
+        if emit:
+            print(json.dumps(out))
     for ln in reversed(lanes):  # the owner of the shared scene goes last
         ln.h.close()
-    if world > 1:
+    if world > 1 and not child:
         dist.destroy_process_group()
-    if rc:
+    if rc and not child:
         raise SystemExit(rc)
+    return out if rank == 0 else None
 
 
 if __name__ == "__main__":

@@ -186,6 +186,9 @@ def load_library(path: Optional[str] = None):
     lib.gto_last_kernel_time.argtypes = [H, _pd, _pi]
     lib.gto_set_profiling.argtypes = [H, C.c_int32]
     lib.gto_last_kernel_work.argtypes = [H, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    if hasattr(lib, "gto_last_kernel_profile"):  # (an older build named by GTO_HIP_LIB for an A/B run lacks it)
+        lib.gto_last_kernel_profile.argtypes = [H, C.c_int32, _pd, _pi, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        lib.gto_last_kernel_profile.restype = C.c_int
     lib.gto_set_stream.argtypes = [H, C.c_void_p]
     lib.gto_set_mode.argtypes = [H, C.c_int32]
     lib.gto_share_scene.argtypes = [H, C.c_int32, H, C.c_int32]
@@ -213,7 +216,7 @@ def load_library(path: Optional[str] = None):
 EXPORTED_SYMBOLS = (
     "gto_default_opts", "gto_version", "gto_create", "gto_destroy", "gto_last_error", "gto_set_opts",
     "gto_set_scene", "gto_set_scene_values", "gto_drop_scene", "gto_solve_batch", "gto_solve_batch_device",
-    "gto_last_kernel_time", "gto_last_kernel_work", "gto_set_profiling", "gto_set_stream", "gto_set_mode", "gto_share_scene", "gto_eval_fk",
+    "gto_last_kernel_time", "gto_last_kernel_work", "gto_last_kernel_profile", "gto_set_profiling", "gto_set_stream", "gto_set_mode", "gto_share_scene", "gto_eval_fk",
     "gto_eval_points",
     "gto_eval_objective", "gto_eval_obstacle_normal_eq", "gto_plan_cost", "gto_solve_ik_batch", "gto_solve_base_batch",
     "gto_eval_base_objective", "gto_depth_sdf_cost",
@@ -370,6 +373,19 @@ class SolverHandle:
         a, b = C.c_uint64(), C.c_uint64()
         self._check(self.lib.gto_last_kernel_work(self._h, C.byref(a), C.byref(b)), "gto_last_kernel_work")
         return a.value, b.value
+
+    PROF_VARIANTS = ("k_obstacle_gram<8,1>", "k_obstacle_gram<8,8>", "k_lm_step<4,1>", "k_lm_step<8,4>")
+
+    def last_kernel_profile(self):
+        """Per kernel variant of the last profiled solve: {name: (ms, launches, workgroups, points gathered)}."""
+        out = {}
+        if not hasattr(self.lib, "gto_last_kernel_profile"):
+            return out
+        for v, name in enumerate(self.PROF_VARIANTS):
+            ms, n, wg, pts = C.c_double(), C.c_int32(), C.c_uint64(), C.c_uint64()
+            self._check(self.lib.gto_last_kernel_profile(self._h, v, C.byref(ms), C.byref(n), C.byref(wg), C.byref(pts)), "gto_last_kernel_profile")
+            out[name] = (ms.value, n.value, wg.value, pts.value)
+        return out
 
     # -------------------------------------------------------------- evaluation entry points
     def eval_fk(self, q):

@@ -43,11 +43,13 @@ struct gto_handle {
   double *d_px = nullptr, *d_py = nullptr, *d_pz = nullptr;
   int32_t *d_plink = nullptr, *d_perm = nullptr;
   Chunk* d_chunks = nullptr;
+  PbChunk* d_pbchunks = nullptr;  // bounding spheres of the chunks of moving links, with their frames (prebroad_tail)
+  int pb_C = 0;
   std::vector<SceneDev> scenes;  // host mirror, index = scene id
   SceneDev* d_scenes = nullptr;
   size_t d_scenes_cap = 0;
   // solve workspace (grown on demand)
-  DevBuf state, Qcur, Qtry, vis, screw, blocks, goalblk, ssfixed, ndone, qf, livebuf, qfs, roombuf, itembuf;
+  DevBuf state, Qcur, Qtry, vis, screw, blocks, goalblk, ssfixed, ndone, qf, livebuf, qfs, sswbuf, nzbbuf, itembuf;
   DevBuf trajws, evterms, evblocks, counters;  // k_traj_solve: block workspace, evaluation outputs, work counters
   int traj_nw = 8;        // wavefronts per workgroup (instance) of k_traj_solve: 4, 8 or 16 (GTO_TRAJ_NW)
   int traj_nw_few = 16;   // ... when a call has few instances (latency matters more than occupancy)
@@ -77,10 +79,8 @@ struct gto_handle {
   // the obstacles (neighbours in time) land in different workgroups: 0 never, 1 always, 2 (default) in launches with few
   // instances in flight, where the longest workgroup decides the round (+5 % for one batch at a time, -2 % at saturation)
   int obs_interleave = 2;
-  int certify = 1;  // GTO_CERTIFY=0: every (job, group) is looked at in every round
-  int cert_kernel = 0;  // GTO_CERT_KERNEL=1: the certificates by a kernel of their own (k_certify) instead of the step kernel's tail
-  double cert_min_gain = 0.10;  // GTO_CERT_MIN_GAIN: a call whose certificates settle less than this share of the groups stops asking for them
-  int cert_from = 4;  // GTO_CERT_FROM: first round with certificates of a call all of whose instances start together
+  int prebroad = 1;  // GTO_PREBROAD=0: every (job, group) gets a workgroup of the obstacle kernel in every round
+  double pb_min_gain = 0.10;  // GTO_PB_MIN_GAIN: a call whose step-kernel broad phase settles less than this share of the groups stops running it
   size_t dbg_extra_lds = 0;  // GTO_DEBUG_EXTRA_LDS: occupancy experiments  // GTO_DEBUG_CUT: timing experiments only, results are garbage
   int obs_tg_few = 2;  // ... when few instances are in flight (one small batch, the tail of a call): lower latency per round; results do not depend on the group size
   int few_instances = 64;
@@ -101,8 +101,14 @@ struct gto_handle {
   // profiling of the dominant kernel
   bool profiling = false;
   std::vector<hipEvent_t> ev;
+  std::vector<int> ev_variant;  // kernel variant of launch i (GTO_PROF_*: include/gto_solver.h)
+  std::vector<long long> ev_wgs;  // its workgroups
   double last_ms = 0.0;
   int last_launches = 0;
+  // per kernel variant of the last profiled solve: milliseconds, launches, workgroups launched, surface points gathered
+  double prof_ms[GTO_PROF_VARIANTS] = {0, 0, 0, 0};
+  long long prof_launches[GTO_PROF_VARIANTS] = {0, 0, 0, 0}, prof_wgs[GTO_PROF_VARIANTS] = {0, 0, 0, 0};
+  unsigned long long prof_points[GTO_PROF_VARIANTS] = {0, 0, 0, 0};
   size_t lm_lds = 0;
   int np = GTO_NB;     // block width of the normal equations: 8 (up to eight optimised joints) or 16
   DevBuf zws;          // k_lm_step_wide: block inverses [slots][T-2][np*np]
@@ -226,10 +232,8 @@ int gto_create(const gto_robot_desc* d, const gto_solver_opts* opts, int device,
   if (const char* e = getenv("GTO_SPEC_FEW")) h->spec_few = std::max(0, atoi(e));
   if (const char* e = getenv("GTO_OBS_DEEP_MAX")) h->obs_deep_max = std::max(0, atoi(e));
   if (const char* e = getenv("GTO_OBS_DEEP")) h->obs_deep = atoi(e) ? 1 : 0;
-  if (const char* e = getenv("GTO_CERTIFY")) h->certify = atoi(e) != 0;
-  if (const char* e = getenv("GTO_CERT_FROM")) h->cert_from = std::max(1, atoi(e));
-  if (const char* e = getenv("GTO_CERT_KERNEL")) h->cert_kernel = atoi(e) != 0;
-  if (const char* e = getenv("GTO_CERT_MIN_GAIN")) h->cert_min_gain = atof(e);
+  if (const char* e = getenv("GTO_PREBROAD")) h->prebroad = atoi(e) != 0;
+  if (const char* e = getenv("GTO_PB_MIN_GAIN")) h->pb_min_gain = atof(e);
   if (const char* e = getenv("GTO_OBS_INTERLEAVE")) h->obs_interleave = std::max(0, std::min(2, atoi(e)));
   if (const char* e = getenv("GTO_DIST_RELAX")) h->dist_relax = atoi(e) ? 1 : 0;
   if (const char* e = getenv("GTO_DEBUG_CUT")) h->dbg_cut = atoi(e);
@@ -534,6 +538,10 @@ int gto_create(const gto_robot_desc* d, const gto_solver_opts* opts, int device,
     i = j;
   }
   rb.n_chunks = (int)chunks.size();
+  std::vector<PbChunk> pbchunks;
+  for (const Chunk& c : chunks)
+    if (!c.pad) pbchunks.push_back(PbChunk{c.cx, c.cy, c.cz, c.r, rb.link_frame[c.link], 0});
+  h->pb_C = (int)pbchunks.size();
   if (rb.n_chunks > GTO_MAX_ACTIVE) { delete h; return fail(nullptr, GTO_ERR_UNSUPPORTED, "too many surface points (max 16384)"); }
 
   if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return fail(nullptr, GTO_ERR_HIP, "hipStreamCreate failed"); }
@@ -544,7 +552,8 @@ int gto_create(const gto_robot_desc* d, const gto_solver_opts* opts, int device,
   bool ok = up((void**)&h->d_rb, &rb, sizeof rb) && up((void**)&h->d_px, px.data(), P * sizeof(double)) &&
             up((void**)&h->d_py, py.data(), P * sizeof(double)) && up((void**)&h->d_pz, pz.data(), P * sizeof(double)) &&
             up((void**)&h->d_plink, plink.data(), P * sizeof(int32_t)) && up((void**)&h->d_perm, perm.data(), P * sizeof(int32_t)) &&
-            up((void**)&h->d_chunks, chunks.data(), chunks.size() * sizeof(Chunk));
+            up((void**)&h->d_chunks, chunks.data(), chunks.size() * sizeof(Chunk)) &&
+            up((void**)&h->d_pbchunks, pbchunks.data(), std::max<size_t>(1, pbchunks.size()) * sizeof(PbChunk));
   if (!ok) { gto_destroy(h); return fail(nullptr, GTO_ERR_ALLOC, "device allocation failed in gto_create"); }
   h->np = rb.n_opt <= GTO_NB ? GTO_NB : 16;
   h->lm_lds = h->np == GTO_NB ? lm_lds_bytes(opts->T, 1) : lm_wide_lds_bytes(opts->T, 16);
@@ -595,7 +604,8 @@ void gto_destroy(gto_handle* h) {
   (void)hipFree(h->d_plink);
   (void)hipFree(h->d_perm);
   (void)hipFree(h->d_chunks);
-  DevBuf* bufs[] = {&h->zws, &h->trajws, &h->evterms, &h->evblocks, &h->counters, &h->state, &h->Qcur, &h->Qtry, &h->vis, &h->screw, &h->blocks, &h->goalblk, &h->ssfixed, &h->ndone, &h->qf, &h->livebuf, &h->qfs, &h->roombuf, &h->itembuf};
+  (void)hipFree(h->d_pbchunks);
+  DevBuf* bufs[] = {&h->zws, &h->trajws, &h->evterms, &h->evblocks, &h->counters, &h->state, &h->Qcur, &h->Qtry, &h->vis, &h->screw, &h->blocks, &h->goalblk, &h->ssfixed, &h->ndone, &h->qf, &h->livebuf, &h->qfs, &h->sswbuf, &h->nzbbuf, &h->itembuf};
   if (h->h_ndone) (void)hipHostFree(h->h_ndone);
   if (h->h_progress) (void)hipHostFree(h->h_progress);
   for (DevBuf* b : bufs) (void)hipFree(b->p);
@@ -845,6 +855,16 @@ int gto_last_kernel_work(gto_handle* h, uint64_t* points_gathered, uint64_t* chu
   return GTO_OK;
 }
 
+int gto_last_kernel_profile(gto_handle* h, int32_t variant, double* total_ms, int32_t* launches, uint64_t* workgroups, uint64_t* points_gathered) {
+  if (!h) return GTO_ERR_INVALID_ARG;
+  if (variant < 0 || variant >= GTO_PROF_VARIANTS) return fail(h, GTO_ERR_INVALID_ARG, "unknown kernel variant");
+  if (total_ms) *total_ms = h->prof_ms[variant];
+  if (launches) *launches = (int32_t)h->prof_launches[variant];
+  if (workgroups) *workgroups = (uint64_t)h->prof_wgs[variant];
+  if (points_gathered) *points_gathered = h->prof_points[variant];
+  return GTO_OK;
+}
+
 int gto_set_profiling(gto_handle* h, int32_t enabled) {
   if (!h) return GTO_ERR_INVALID_ARG;
   h->profiling = enabled != 0;
@@ -877,7 +897,8 @@ static SolveParams make_params(const gto_handle* h, int n_max, bool use_standoff
   sp.lambda0 = o.lambda0;
   sp.dbg_cut = h->dbg_cut;
   sp.interleave = h->obs_interleave == 1;
-  sp.certify = 0, sp.cert_tg = 1, sp.cert_ng = 1, sp.cert_next = 0;
+  sp.pb_next = 0, sp.pb_tg = 1, sp.pb_ng = 1, sp.pb_pw = 1, sp.pb_verify = 0;
+  sp.pb_C = h->pb_C, sp.pb_tab0 = 0, sp.pb_mC = ObsGeom::magic(std::max(1, h->pb_C));
   sp.round = sp.parity = 0;
   sp.kcap = h->np == GTO_NB ? GTO_KSPEC : 1;  // candidate copies of the workspace (the wide step kernel generates one)
   sp.k_acc = sp.k_rej = sp.k_eval = 1;
@@ -901,12 +922,13 @@ static int ensure_workspace(gto_handle* h, int B) {
   if ((rc = ensure(h, h->qf, (size_t)B * T * rb.n_frames * sizeof(double)))) return rc;
   if ((rc = ensure(h, h->livebuf, (2 * (1 + kcap) * (size_t)std::min(B, h->slots) + 32) * sizeof(int32_t)))) return rc;
   if ((rc = ensure(h, h->qfs, 2 * (size_t)std::min(B, h->slots) * kcap * T * rb.n_frames * sizeof(double)))) return rc;
-  if ((rc = ensure(h, h->roombuf, (size_t)(kcap + 1) * B * T * rb.n_links))) return rc;
+  if ((rc = ensure(h, h->sswbuf, (size_t)(kcap + 1) * B * T * sizeof(double)))) return rc;
+  if ((rc = ensure(h, h->nzbbuf, (size_t)(kcap + 1) * B * T))) return rc;
   if ((rc = ensure(h, h->itembuf, 2 * ((size_t)std::min(B, h->slots) * kcap * (T - 2) + 64) * sizeof(int2)))) return rc;
   if (!h->h_ndone) HIPCHK(h, hipHostMalloc((void**)&h->h_ndone, 64));
   if (!h->h_progress) {
     HIPCHK(h, hipHostMalloc((void**)&h->h_progress, 64, hipHostMallocMapped));
-    *h->h_progress = 0ull;
+    std::memset(h->h_progress, 0, 64);  // every word the solve loop reads carries a call tag (never 0)
     HIPCHK(h, hipHostGetDevicePointer((void**)&h->d_progress, h->h_progress, 0));
   }
   return GTO_OK;
@@ -935,7 +957,8 @@ static BatchPtrs make_ptrs(gto_handle* h, const int32_t* scene_id, const double*
   bp.nlive = nullptr;
   bp.next = nullptr;
   bp.qfs = nullptr;
-  bp.room = nullptr;
+  bp.ssw = (double*)h->sswbuf.p;
+  bp.nzb = (uint8_t*)h->nzbbuf.p;
   bp.items = nullptr;
   bp.scenes = h->d_scenes;
   bp.cap = 0;
@@ -947,21 +970,29 @@ static BatchPtrs make_ptrs(gto_handle* h, const int32_t* scene_id, const double*
 
 static inline int obstacle_grid(int B, int nG) { return 8 * ((B + 7) / 8) * nG; }
 
+// profiling (gto_set_profiling): a pair of HIP events on the launch stream around launch number h->last_launches
+static int prof_begin(gto_handle* h, hipStream_t st, int variant, long long wgs) {
+  const size_t need = (size_t)(h->last_launches + 1) * 2;
+  while (h->ev.size() < need) {
+    hipEvent_t e;
+    HIPCHK(h, hipEventCreate(&e));
+    h->ev.push_back(e);
+  }
+  if (h->ev_variant.size() <= (size_t)h->last_launches) h->ev_variant.resize(h->last_launches + 1), h->ev_wgs.resize(h->last_launches + 1);
+  h->ev_variant[h->last_launches] = variant;
+  h->ev_wgs[h->last_launches] = wgs;
+  HIPCHK(h, hipEventRecord(h->ev[2 * h->last_launches], st));
+  return GTO_OK;
+}
+static int prof_end(gto_handle* h, hipStream_t st) {
+  HIPCHK(h, hipEventRecord(h->ev[2 * h->last_launches + 1], st));
+  h->last_launches++;
+  return GTO_OK;
+}
+
 static int launch_obstacle(gto_handle* h, hipStream_t st, const BatchPtrs& bp, const SolveParams& sp, int B, int t_begin,
                            int nT, int fixed_mode, bool timed, bool with_goal_terms = false, int n_jobs = 0, int tg = 0, bool deep = false,
                            bool itemized = false) {
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  if (timed) {
-    size_t need = (size_t)(h->last_launches + 1) * 2;
-    while (h->ev.size() < need) {
-      hipEvent_t e;
-      HIPCHK(h, hipEventCreate(&e));
-      h->ev.push_back(e);
-    }
-    e0 = h->ev[2 * h->last_launches];
-    e1 = h->ev[2 * h->last_launches + 1];
-    HIPCHK(h, hipEventRecord(e0, st));
-  }
   // waypoints per workgroup: groups of h->obs_tg (the two pinned waypoints form one group)
   const int TG = fixed_mode ? 1 : std::max(1, std::min(tg > 0 ? tg : h->obs_tg, nT));  // the init pass has 4 virtual waypoints
   const ObsGeom geo(h->rb.n_cframes, h->rb.n_frames, h->rb.fk_rounds_c, h->rb.n_links, h->rb.n_opt, h->rb.n_chunks, TG, nT, h->np);
@@ -970,27 +1001,31 @@ static int launch_obstacle(gto_handle* h, hipStream_t st, const BatchPtrs& bp, c
   const int n_regular = obstacle_grid(nb, nG);
   const size_t lds = (size_t)geo.lay.total_doubles * sizeof(double) + h->dbg_extra_lds;
   const dim3 grid(n_regular + (with_goal_terms ? 8 * ((nb + 31) / 32) : 0));  // goal-term jobs: four to a workgroup, in front, a multiple of eight workgroups
+  const bool deep_v = h->np == GTO_NB && deep;
+  if (timed) {
+    int rc_ = prof_begin(h, st, deep_v ? GTO_PROF_OBSTACLE_FEW : GTO_PROF_OBSTACLE, (long long)grid.x);
+    if (rc_) return rc_;
+  }
+  BatchPtrs bpl = bp;  // the work counters of this variant (64 cells each)
+  if (bpl.work) bpl.work += 64 * (deep_v ? GTO_PROF_OBSTACLE_FEW : GTO_PROF_OBSTACLE);
   // this round's job list and its length (the kernel's first, preloaded, arguments); null outside the solve loop
   const bool listed = bp.live != nullptr && !fixed_mode;
   const int32_t* jobs_par = listed ? bp.jobs + (size_t)sp.parity * bp.cap * sp.kcap : nullptr;
   const int32_t* njobs_par = listed ? bp.nlive + 2 + sp.parity : nullptr;
-  // rounds with emptiness certificates: the regular workgroups are laid out over k_certify's list of (job, group) pairs
+  // rounds behind a step kernel that ran the broad phase itself: the regular workgroups are laid out over its list of (job, group) pairs
   const size_t items_cap = (size_t)bp.cap * sp.kcap * (sp.T - 2) + 64;
   const int2* items_par = listed && itemized ? bp.items + (size_t)sp.parity * items_cap : nullptr;
   const int32_t* nitems_par = listed && itemized ? bp.nlive + 8 + sp.parity : nullptr;
   if (h->np == GTO_NB && deep)  // few instances in flight: the variant that keeps a wave's record gathers in flight together
     hipLaunchKernelGGL((k_obstacle_gram<GTO_NB, GTO_OBS_DEEP_PD>), grid, dim3(256), lds, st, jobs_par, njobs_par, items_par, nitems_par, geo.nG, geo.m_nG, n_regular, B, h->d_rb, h->d_px, h->d_py, h->d_pz, h->d_chunks, h->d_scenes,
-                       bp, sp, t_begin, nT, fixed_mode, geo);
+                       bpl, sp, t_begin, nT, fixed_mode, geo);
   else if (h->np == GTO_NB)
-    hipLaunchKernelGGL(k_obstacle_gram<GTO_NB>, grid, dim3(256), lds, st, jobs_par, njobs_par, items_par, nitems_par, geo.nG, geo.m_nG, n_regular, B, h->d_rb, h->d_px, h->d_py, h->d_pz, h->d_chunks, h->d_scenes, bp, sp,
+    hipLaunchKernelGGL(k_obstacle_gram<GTO_NB>, grid, dim3(256), lds, st, jobs_par, njobs_par, items_par, nitems_par, geo.nG, geo.m_nG, n_regular, B, h->d_rb, h->d_px, h->d_py, h->d_pz, h->d_chunks, h->d_scenes, bpl, sp,
                        t_begin, nT, fixed_mode, geo);
   else
-    hipLaunchKernelGGL(k_obstacle_gram<16>, grid, dim3(256), lds, st, jobs_par, njobs_par, items_par, nitems_par, geo.nG, geo.m_nG, n_regular, B, h->d_rb, h->d_px, h->d_py, h->d_pz, h->d_chunks, h->d_scenes, bp, sp,
+    hipLaunchKernelGGL(k_obstacle_gram<16>, grid, dim3(256), lds, st, jobs_par, njobs_par, items_par, nitems_par, geo.nG, geo.m_nG, n_regular, B, h->d_rb, h->d_px, h->d_py, h->d_pz, h->d_chunks, h->d_scenes, bpl, sp,
                        t_begin, nT, fixed_mode, geo);
-  if (timed) {
-    HIPCHK(h, hipEventRecord(e1, st));
-    h->last_launches++;
-  }
+  if (timed) return prof_end(h, st);
   return GTO_OK;
 }
 
@@ -1130,9 +1165,7 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
   bp.nlive = bp.jobs + 2 * W * sp.kcap;
   bp.next = bp.nlive + 4;
   bp.qfs = (double*)h->qfs.p;
-  const bool certify_call = h->certify && h->np == GTO_NB && h->rb.reach_link[0][0] >= 0.0 && h->rb.n_links <= 16;
-  bp.room = certify_call ? (int8_t*)h->roombuf.p : nullptr;
-  bp.items = certify_call ? (int2*)h->itembuf.p : nullptr;
+  bp.items = h->np == GTO_NB ? (int2*)h->itembuf.p : nullptr;
   bp.cap = W;
   bp.n_total = B;
   HIPCHK(h, hipMemsetAsync(bp.n_done, 0, sizeof(int32_t), st));
@@ -1142,19 +1175,20 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
   bp.progress = h->d_progress;
   bp.progress_tag = (unsigned long long)h->progress_tag << 32;
   if (h->profiling) {
-    if ((rc = ensure(h, h->counters, 64 * sizeof(unsigned long long)))) return rc;
-    bp.work = (unsigned long long*)h->counters.p;
-    HIPCHK(h, hipMemsetAsync(bp.work, 0, 64 * sizeof(unsigned long long), st));
+    if ((rc = ensure(h, h->counters, GTO_PROF_VARIANTS * 64 * sizeof(unsigned long long)))) return rc;
+    bp.work = (unsigned long long*)h->counters.p;  // 64 cells per kernel variant (launch_obstacle picks the variant's)
+    HIPCHK(h, hipMemsetAsync(bp.work, 0, GTO_PROF_VARIANTS * 64 * sizeof(unsigned long long), st));
   }
-  // emptiness certificates in the rounds that fill the GPU: the step kernel (or, GTO_CERT_KERNEL=1 and the verification
-  // mode, k_certify) settles the groups it can and lists the others
-  const int cert_tg = std::max(1, std::min(h->obs_tg, T - 2)), cert_ng = (T - 2 + cert_tg - 1) / cert_tg;
-  const bool cert_ok = bp.items != nullptr && cert_ng <= 64 && cert_tg * h->rb.n_links <= 64 && h->obs_interleave != 1;
-  const int cert_verify = h->dbg_cut == 10;
-  const bool cert_fused = cert_ok && !cert_verify && !h->cert_kernel;
-  sp.cert_tg = cert_tg, sp.cert_ng = cert_ng;
-  // round 0 of a call with waiting instances: every group of every seed is on the list (k_lm_init writes it)
-  sp.cert_next = cert_fused && std::min(W, B) > h->few_instances && B > W;
+  // The broad phase ahead of the obstacle launch, in the rounds that fill the GPU: the step kernel settles the waypoint
+  // groups none of whose bounding spheres can reach a non-zero voxel record and lists the others (prebroad_tail); the
+  // launch is laid out over that list.  Needs: the groups of the launch it feeds (consecutive waypoints), room for one
+  // pass in the step kernel's dead LDS, at most GTO_PB_PARK parked frames in its serial walk over the kinematic tree.
+  const int pb_tg = std::max(1, std::min(h->obs_tg, T - 2)), pb_ng = (T - 2 + pb_tg - 1) / pb_tg;
+  const PbLayout pbl(T, h->rb.n_frames, h->pb_C);
+  const bool pb_ok = h->prebroad && bp.items != nullptr && pb_ng <= 64 && h->obs_interleave != 1 && h->rb.n_xst <= GTO_PB_PARK && pbl.pw >= 1 &&
+                     h->pb_C >= 1 && std::min(W, B) > h->few_instances;
+  sp.pb_tg = pb_tg, sp.pb_ng = pb_ng, sp.pb_pw = std::max(1, pbl.pw), sp.pb_tab0 = pbl.tab0;
+  sp.pb_verify = h->dbg_cut == 10;
   if (h->np == GTO_NB) hipLaunchKernelGGL(k_lm_init<GTO_NB>, dim3(B), dim3(256), 0, st, h->d_rb, bp, sp, B, 0);
   else hipLaunchKernelGGL(k_lm_init<16>, dim3(B), dim3(256), 0, st, h->d_rb, bp, sp, B, 0);
   {
@@ -1168,13 +1202,7 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
   const int max_rounds = ((B + W - 1) / W + 1) * (sp.max_iter + 2);
   int known_done = 0, seen_round = -1;
   int k_prev = 1;  // candidates per instance the last step launch may have generated
-  bool items_ready = sp.cert_next != 0, cert_off = false;
-  auto launch_certify = [&](int pn, int n_jobs) {
-    hipLaunchKernelGGL(k_certify, dim3(n_jobs), dim3(256), 0, st, h->d_rb, bp, sp, B, pn, cert_tg, cert_ng,
-                       (int)((size_t)W * sp.kcap * (T - 2) + 64), cert_verify);
-    items_ready = true;
-  };
-  if (cert_ok && !cert_fused && std::min(W, B) > h->few_instances && B > W) launch_certify(0, std::min(W, B));
+  bool items_ready = false, pb_off = false;
   auto read_progress = [&]() {
     const unsigned long long p0 = __atomic_load_n(h->h_progress, __ATOMIC_RELAXED), p1 = __atomic_load_n(h->h_progress + 1, __ATOMIC_RELAXED);
     if ((unsigned)(p0 >> 32) == h->progress_tag) known_done = std::max(known_done, (int)(p0 & 0xffffffffull));
@@ -1215,8 +1243,6 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
     const int tg = few ? h->obs_tg_few : h->obs_tg;
     sp.interleave = h->obs_interleave == 1 || (h->obs_interleave == 2 && few);
     const bool itemized = items_ready && !few;
-    sp.certify = cert_ok && !cert_off && !few;  // the looks of the rounds that fill the GPU leave their rooms
-    sp.cert_tg = cert_tg, sp.cert_ng = cert_ng;
     items_ready = false;
     sp.round = k;
     sp.parity = k & 1;
@@ -1229,30 +1255,33 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
         sp.k_rej = in_flight <= h->spec_few ? std::min(h->spec_rej, h->spec_kmax) : 1;
         sp.k_acc = in_flight <= std::min(h->spec_deep, h->spec_few) ? std::min(h->spec_acc, h->spec_kmax) : 1;
         const int kl = std::max(sp.k_acc, sp.k_rej);
-        sp.cert_next = 0;
-        hipLaunchKernelGGL((k_lm_step<8, GTO_KSPEC>), dim3(in_flight), dim3(512), lm_lds_bytes(T, kl), st, h->d_rb, bp, sp, B);
+        sp.pb_next = 0;
+        if (h->profiling && (rc = prof_begin(h, st, GTO_PROF_STEP_FEW, in_flight))) { rc_loop = rc; break; }
+        hipLaunchKernelGGL((k_lm_step<8, GTO_KSPEC>), dim3(in_flight), dim3(512), lm_lds_bytes(T, kl), st, h->d_rb, h->d_pbchunks, bp, sp, B);
+        if (h->profiling && (rc = prof_end(h, st))) { rc_loop = rc; break; }
         k_prev = kl;
       } else {
         sp.k_acc = sp.k_rej = 1;
-        // (a call without waiting instances is young in its first rounds: steps too long for any room)
-        // ... and a call where they settle next to nothing (a robot inside a shelf) stops asking for them: the last itemized
-    // round the host has seen listed more than GTO_CERT_MIN_GAIN of its (job, group) pairs
-    if (cert_ok && !cert_off && !cert_verify) {
-      const unsigned long long p2 = __atomic_load_n(h->h_progress + 2, __ATOMIC_RELAXED);
-      if ((unsigned)(p2 >> 32) == h->progress_tag) {
-        const double jobs_seen = (double)((p2 >> 20) & 0xfffull), items_seen = (double)(p2 & 0xfffffull);
-        if (jobs_seen > 0 && items_seen > 0 && k >= 12 && items_seen > (1.0 - h->cert_min_gain) * jobs_seen * cert_ng) cert_off = true;
-      }
-    }
-    const bool cert_now = cert_ok && !cert_off && !few && (B > W || k + 1 >= h->cert_from);
-        sp.cert_next = cert_now && cert_fused;
-        hipLaunchKernelGGL((k_lm_step<4, 1>), dim3(in_flight), dim3(256), h->lm_lds, st, h->d_rb, bp, sp, B);
+        // a call in which the broad phase settles next to nothing (a robot inside a shelf) stops running it: the last
+        // itemized round the host has seen listed more than 1 - GTO_PB_MIN_GAIN of its (job, group) pairs
+        if (pb_ok && !pb_off && !sp.pb_verify) {
+          const unsigned long long p2 = __atomic_load_n(h->h_progress + 2, __ATOMIC_RELAXED);
+          if ((unsigned)(p2 >> 32) == h->progress_tag) {
+            const double jobs_seen = (double)((p2 >> 20) & 0xfffull), items_seen = (double)(p2 & 0xfffffull);
+            if (jobs_seen > 0 && items_seen > 0 && jobs_seen < 4095 && k >= 12 && items_seen > (1.0 - h->pb_min_gain) * jobs_seen * pb_ng) pb_off = true;
+          }
+        }
+        sp.pb_next = pb_ok && !pb_off && !few;
+        if (h->profiling && (rc = prof_begin(h, st, GTO_PROF_STEP, in_flight))) { rc_loop = rc; break; }
+        hipLaunchKernelGGL((k_lm_step<4, 1>), dim3(in_flight), dim3(256), h->lm_lds, st, h->d_rb, h->d_pbchunks, bp, sp, B);
+        if (h->profiling && (rc = prof_end(h, st))) { rc_loop = rc; break; }
         k_prev = 1;
-        if (cert_now && !cert_fused) launch_certify((k + 1) & 1, in_flight);
-        else if (cert_now) items_ready = true;
+        items_ready = sp.pb_next != 0;
       }
     } else {
+      if (h->profiling && (rc = prof_begin(h, st, GTO_PROF_STEP, in_flight))) { rc_loop = rc; break; }
       hipLaunchKernelGGL(k_lm_step_wide<16>, dim3(in_flight), dim3(256), h->lm_lds, st, h->d_rb, bp, sp, B, (double*)h->zws.p);
+      if (h->profiling && (rc = prof_end(h, st))) { rc_loop = rc; break; }
     }
   }
   if (old_slack > 1000) (void)prctl(PR_SET_TIMERSLACK, (unsigned long)old_slack);
@@ -1277,7 +1306,7 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
       for (int i = 64; i < 128; ++i) fprintf(stderr, " %lld", t[i]);
       fprintf(stderr, "\n");
     }
-    fprintf(stderr, "[gto dbg] emptiness certificates (GTO_DEBUG_CUT=10, -DGTO_DEBUG_LONGEST_WG: certified groups are looked at anyway): %lld groups claimed, %lld of them with a surviving chunk, %lld (waypoint, link) rooms below the promise\n", t[49], t[50], t[51]);
+    fprintf(stderr, "[gto dbg] broad phase of the step kernel (GTO_DEBUG_CUT=10, -DGTO_DEBUG_LONGEST_WG: settled groups are looked at anyway): %lld groups settled, %lld of them with a surviving chunk\n", t[49], t[50]);
     {
       fprintf(stderr, "[gto dbg] workgroups without a surviving chunk by the index shift their closest chunk tolerates (0,1,2,...,63+):");
       for (int i = 128; i < 192; ++i) fprintf(stderr, " %lld", t[i]);
@@ -1288,17 +1317,24 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
   }
   if (h->profiling) {
     HIPCHK(h, hipStreamSynchronize(st));
-    double tot = 0.0;
+    for (int v = 0; v < GTO_PROF_VARIANTS; ++v) h->prof_ms[v] = 0.0, h->prof_launches[v] = h->prof_wgs[v] = 0, h->prof_points[v] = 0;
+    int n_obs = 0;
     for (int i = 0; i < h->last_launches; ++i) {
       float ms = 0.f;
       HIPCHK(h, hipEventElapsedTime(&ms, h->ev[2 * i], h->ev[2 * i + 1]));
-      tot += ms;
+      const int v = h->ev_variant[i];
+      h->prof_ms[v] += ms, h->prof_launches[v] += 1, h->prof_wgs[v] += h->ev_wgs[i];
+      n_obs += v == GTO_PROF_OBSTACLE || v == GTO_PROF_OBSTACLE_FEW;
     }
-    h->last_ms = tot;
-    unsigned long long cells[64];
+    unsigned long long cells[GTO_PROF_VARIANTS * 64];
     HIPCHK(h, hipMemcpy(cells, bp.work, sizeof cells, hipMemcpyDeviceToHost));
-    h->last_counters[0] = h->last_counters[1] = 0;
-    for (unsigned long long c : cells) h->last_counters[0] += c;
+    for (int v = 0; v < GTO_PROF_VARIANTS; ++v)
+      for (int c = 0; c < 64; ++c) h->prof_points[v] += cells[64 * v + c];
+    // gto_last_kernel_time / _work: the obstacle kernel, both variants together (what they always reported)
+    h->last_ms = h->prof_ms[GTO_PROF_OBSTACLE] + h->prof_ms[GTO_PROF_OBSTACLE_FEW];
+    h->last_launches = n_obs;
+    h->last_counters[0] = h->prof_points[GTO_PROF_OBSTACLE] + h->prof_points[GTO_PROF_OBSTACLE_FEW];
+    h->last_counters[1] = 0;
   }
   return GTO_OK;
 }

@@ -45,43 +45,56 @@ def _shard_indices(B: int, world: int, assignment: Optional[np.ndarray]):
 
 
 def gather_results(mine: np.ndarray, result: tuple, B: int, rank: int, world: int, group=None,
-                   assignment: Optional[np.ndarray] = None):
+                   assignment: Optional[np.ndarray] = None, stats: Optional[dict] = None):
     """all_gather the solved shards (Q, dQ, cost, iters, status of the instances `mine`) so that every rank holds the
     full batch of B instances in the original order: the ONLY collective of the multi-GPU path, outside the solve.
-    One fixed-size float64 payload per rank (padded to the largest shard; iteration counts and status travel as exact
-    small integers), on the device for RCCL (`backend="nccl"`), on the host for gloo."""
+    Two fixed-size payloads per rank, padded to the largest shard: float64 (Q, dQ, cost) and int32 (iterations, status:
+    integers travel as integers); on the device for RCCL (`backend="nccl"`), on the host for gloo.  A rank whose `mine`
+    does not match the assignment makes EVERY rank raise (the error flag is reduced first: nobody is left waiting in
+    the collective).  `stats`, if given, receives the bytes this rank sent and received and the seconds the collectives took."""
+    import time
     import torch
     import torch.distributed as dist
     Q, dQ, cost, iters, status = result
     ndof, T = Q.shape[1], Q.shape[2]
     shards = _shard_indices(B, world, assignment)
-    if not np.array_equal(np.asarray(mine), shards[rank]):
-        raise ValueError("gather_results: `mine` is not this rank's shard under the given assignment")
     backend = dist.get_backend(group)
     dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+    bad = torch.tensor([0 if np.array_equal(np.asarray(mine), shards[rank]) else 1], dtype=torch.int32, device=dev)
+    dist.all_reduce(bad, op=dist.ReduceOp.MAX, group=group)
+    if int(bad.item()):
+        raise ValueError("gather_results: on some rank `mine` is not that rank's shard under the given assignment")
     mx = max(len(ix) for ix in shards)
-    width = ndof * T + ndof * (T - 1) + 3
-    payload = np.zeros((mx, width))
+    width = ndof * T + ndof * (T - 1) + 1
+    payload, ipay = np.zeros((mx, width)), np.zeros((mx, 2), dtype=np.int32)
     n = len(mine)
     payload[:n, : ndof * T] = Q.reshape(n, -1)
     payload[:n, ndof * T: ndof * T + ndof * (T - 1)] = dQ.reshape(n, -1)
-    payload[:n, -3], payload[:n, -2], payload[:n, -1] = cost, iters, status
-    send = torch.from_numpy(payload).to(dev)
-    recv = [torch.empty_like(send) for _ in range(world)]
+    payload[:n, -1] = cost
+    ipay[:n, 0], ipay[:n, 1] = iters, status
+    t0 = time.perf_counter()
+    send, isend = torch.from_numpy(payload).to(dev), torch.from_numpy(ipay).to(dev)
+    recv, irecv = [torch.empty_like(send) for _ in range(world)], [torch.empty_like(isend) for _ in range(world)]
     dist.all_gather(recv, send, group=group)
+    dist.all_gather(irecv, isend, group=group)
+    if dev.type == "cuda":
+        torch.cuda.synchronize(dev)
+    if stats is not None:
+        stats.update(backend=backend, seconds=time.perf_counter() - t0, bytes_sent=int(payload.nbytes + ipay.nbytes),
+                     bytes_received=int(world * (payload.nbytes + ipay.nbytes)), collectives=2)
     Qa, dQa = np.empty((B, ndof, T)), np.empty((B, ndof, T - 1))
     ca, ia, sa = np.empty(B), np.empty(B, np.int32), np.empty(B, np.int32)
     for r, idx in enumerate(shards):
-        blk = recv[r].cpu().numpy()[: len(idx)]
+        blk, iblk = recv[r].cpu().numpy()[: len(idx)], irecv[r].cpu().numpy()[: len(idx)]
         Qa[idx] = blk[:, : ndof * T].reshape(-1, ndof, T)
         dQa[idx] = blk[:, ndof * T: ndof * T + ndof * (T - 1)].reshape(-1, ndof, T - 1)
-        ca[idx], ia[idx], sa[idx] = blk[:, -3], blk[:, -2].astype(np.int32), blk[:, -1].astype(np.int32)
+        ca[idx], ia[idx], sa[idx] = blk[:, -1], iblk[:, 0], iblk[:, 1]
     return np.arange(B), Qa, dQa, ca, ia, sa
 
 
 def solve_local_shard(solve_fn: Callable[..., tuple], mine, scene_id, qc, goals, n_goals, standoff, base_pos, Q0,
                       B: int, rank: int, world: int, group=None, gather: bool = True,
-                      assignment: Optional[np.ndarray] = None):
+                      assignment: Optional[np.ndarray] = None, stats: Optional[dict] = None):
     """Like solve_sharded, but the argument arrays hold ONLY this rank's instances (rows in the order of `mine`, the
     global indices of the shard): a rank never materialises the inputs of instances it does not solve.  B is the size of
     the whole batch."""
@@ -97,7 +110,7 @@ def solve_local_shard(solve_fn: Callable[..., tuple], mine, scene_id, qc, goals,
         result = (np.empty((0, ndof, T)), np.empty((0, ndof, T - 1)), np.empty(0), np.empty(0, np.int32), np.empty(0, np.int32))
     if not gather or world == 1:
         return (mine,) + tuple(result)
-    return gather_results(mine, result, B, rank, world, group, assignment)
+    return gather_results(mine, result, B, rank, world, group, assignment, stats)
 
 
 def solve_sharded(solve_fn: Callable[..., tuple], scene_id, qc, goals, n_goals, standoff, base_pos, Q0,

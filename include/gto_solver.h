@@ -257,7 +257,17 @@ int gto_last_kernel_time(gto_handle* h, double* total_ms, int32_t* launches);
  * a field (one 32-B voxel record or one float each; the broad phase skips the rest, which would read exact
  * zeros) and chunk bounding spheres it tested.  bench.py prices the kernel's roofline on the points gathered. */
 int gto_last_kernel_work(gto_handle* h, uint64_t* points_gathered, uint64_t* chunk_tests);
-/* Enable/disable per-launch event timing of the dominant kernel (off by default). */
+/* The same per kernel VARIANT of the solve loop (profiling enabled), so that time, launches and work of one variant are
+ * never mixed with another's: launches, their summed HIP-event time, the workgroups they were laid out for and (obstacle
+ * variants) the surface points they gathered during the most recent gto_solve_batch[_device] call. */
+#define GTO_PROF_OBSTACLE 0      /* k_obstacle_gram<NP,1>: the launches that fill the GPU */
+#define GTO_PROF_OBSTACLE_FEW 1  /* k_obstacle_gram<8,8>: launches with few instances in flight */
+#define GTO_PROF_STEP 2          /* k_lm_step<4,1> (k_lm_step_wide for nine to sixteen optimised joints) */
+#define GTO_PROF_STEP_FEW 3      /* k_lm_step<8,4>: few instances in flight, candidate trial points */
+#define GTO_PROF_VARIANTS 4
+int gto_last_kernel_profile(gto_handle* h, int32_t variant, double* total_ms, int32_t* launches, uint64_t* workgroups,
+                            uint64_t* points_gathered);
+/* Enable/disable per-launch event timing of the solve loop's kernels (off by default). */
 int gto_set_profiling(gto_handle* h, int32_t enabled);
 
 /* ---- evaluation entry points (host pointers, synchronous): the pieces of the objective the

@@ -292,14 +292,15 @@ def test_slots_hand_over_to_waiting_instances(capi, oracle_mod, monkeypatch, slo
     h.close()
 
 
-@pytest.mark.parametrize("env", [{"GTO_CERTIFY": "0"}, {"GTO_CERT_FROM": "1"}, {"GTO_SLOTS": "96"}, {"GTO_SLOTS": "96", "GTO_CERTIFY": "0"},
-                                 {"GTO_OBS_TG": "2"}, {"GTO_FEW_INSTANCES": "16"}])
-def test_emptiness_certificates_do_not_change_results(capi, oracle_mod, monkeypatch, env):
-    """In the rounds that fill the GPU, k_certify settles the (job, group) pairs whose bounding spheres provably stay clear
-    of every non-zero voxel record (room found by the last look at the iterate, less what the step can move a sphere by)
-    without a workgroup of the obstacle kernel: exact zeros either way, so switching the certificates off, starting them
-    in the first round, refilling positions mid-call (96 positions for 160 instances) or changing the group size gives
-    bit-for-bit the same trajectories, costs and iteration counts; and they match the oracle, which culls nothing."""
+@pytest.mark.parametrize("env", [{"GTO_PREBROAD": "0"}, {"GTO_SLOTS": "96"}, {"GTO_SLOTS": "96", "GTO_PREBROAD": "0"},
+                                 {"GTO_OBS_TG": "2"}, {"GTO_OBS_TG": "5"}, {"GTO_FEW_INSTANCES": "16"}, {"GTO_PB_MIN_GAIN": "2"}])
+def test_step_kernel_broad_phase_does_not_change_results(capi, oracle_mod, monkeypatch, env):
+    """In the rounds that fill the GPU the step kernel tests the bounding spheres of its new trial trajectory itself
+    (prebroad_tail: serial kinematics per lane instead of the obstacle kernel's matrix-core prefix), settles the waypoint
+    groups none of whose spheres can reach a non-zero voxel record -- exact zeros either way -- and the obstacle launch is
+    laid out over the groups that are left.  Switching that off, refilling positions mid-call (96 positions for 160
+    instances), changing the group size, or switching it off mid-call (GTO_PB_MIN_GAIN=2: after round 12) gives bit-for-bit
+    the same trajectories, costs and iteration counts; and they match the oracle, which culls nothing."""
     prob = Problem("panda_5k", B=160, scene_seed=5, n=64, res=0.035, n_goals=1)
     h, o = make_pair(capi, oracle_mod, prob, max_iter=40)
     ref = h.solve_batch(*prob.solve_args())
@@ -321,16 +322,19 @@ def test_emptiness_certificates_do_not_change_results(capi, oracle_mod, monkeypa
     h.close()
 
 
-@pytest.mark.parametrize("robot,shelf", [("fetch", False), ("fetch", True)])
-def test_emptiness_certificates_other_robot(capi, oracle_mod, monkeypatch, robot, shelf):
-    """The same on a robot with another link count, collision links on fixed frames (the world frame of the obstacle kernel's
-    compact tree, static links in the room bookkeeping) and, in the shelf, next to nothing to certify (the call switches the
-    certificates off after round 12): bit-identical with and without them, and equal to the oracle."""
-    prob = Problem(robot, B=130, scene_seed=4, n=64, res=0.035, n_goals=1, shelf=shelf)
-    h, o = make_pair(capi, oracle_mod, prob, max_iter=30)
+@pytest.mark.parametrize("robot,shelf,T", [("fetch", False, 50), ("fetch", True, 50), ("fetch", False, 4), ("panda", False, 5), ("panda_5k", False, 30)])
+def test_step_kernel_broad_phase_other_robots_and_horizons(capi, oracle_mod, monkeypatch, robot, shelf, T):
+    """The same on a robot with another link count and collision links on fixed frames (static links: never tested, never
+    settled) and, in the shelf, next to nothing to settle (the call switches the broad phase of the step kernel off after
+    round 12); at horizons down to T = 4, where the step kernel's dead LDS holds the visual transforms of a waypoint or two
+    per pass: bit-identical with and without it, and equal to the oracle."""
+    so = -10 if T >= 30 else -1
+    prob = Problem(robot, B=130, scene_seed=4, n=64, res=0.035, n_goals=1, shelf=shelf, T=T)
+    opts = lambda: oracle_mod.reference_opts(max_iter=30, T=T, standoff_offset=so)
+    h, o = make_pair(capi, oracle_mod, prob, max_iter=30, T=T, standoff_offset=so)
     ref = h.solve_batch(*prob.solve_args())
-    monkeypatch.setenv("GTO_CERTIFY", "0")
-    h2 = capi.SolverHandle(prob.desc, prob.cfg["link_ee"], prob.cfg["link_gripper"], oracle_mod.reference_opts(max_iter=30), device=0)
+    monkeypatch.setenv("GTO_PREBROAD", "0")
+    h2 = capi.SolverHandle(prob.desc, prob.cfg["link_ee"], prob.cfg["link_gripper"], opts(), device=0)
     h2.set_mode(0)
     h2.set_scene(*prob.scene_args())
     got = h2.solve_batch(*prob.solve_args())
