@@ -49,7 +49,7 @@ struct gto_handle {
   SceneDev* d_scenes = nullptr;
   size_t d_scenes_cap = 0;
   // solve workspace (grown on demand)
-  DevBuf state, Qcur, Qtry, vis, screw, blocks, goalblk, ssfixed, ndone, qf, livebuf, qfs, sswbuf, nzbbuf, itembuf;
+  DevBuf state, Qcur, Qtry, vis, screw, blocks, goalblk, ssfixed, ndone, qf, livebuf, qfs, wrecbuf, itembuf;
   DevBuf trajws, evterms, evblocks, counters;  // k_traj_solve: block workspace, evaluation outputs, work counters
   int traj_nw = 8;        // wavefronts per workgroup (instance) of k_traj_solve: 4, 8 or 16 (GTO_TRAJ_NW)
   int traj_nw_few = 16;   // ... when a call has few instances (latency matters more than occupancy)
@@ -331,6 +331,37 @@ int gto_create(const gto_robot_desc* d, const gto_solver_opts* opts, int device,
     const int p = rb.parent[i];
     if (p >= 0 && p != i - 1 && rb.xst_slot[p] < 0) rb.xst_slot[p] = rb.n_xst++;
   }
+  {  // the step kernel's walk over the tree (prebroad_tail): control words, and the widening of its culling radius
+    for (int i = 0; i < d->n_frames; ++i) {
+      const int p = rb.parent[i], l = rb.link_of_frame[i];
+      const int src = p < 0 ? 0 : (p == i - 1 ? 1 : 2 + rb.xst_slot[p]);
+      const bool moving_link = l >= 0 && (rb.frame_anc[rb.link_frame[l]] != 0u);
+      rb.pb_ctl[i] = (src & 7) | (((rb.xst_slot[i] + 1) & 7) << 4) | ((moving_link ? 1 : 0) << 8);
+      for (int e = 0; e < 12; ++e) rb.pb_vo[i][e] = moving_link ? (float)rb.vis_origin[l][e] : 0.f;
+      rb.pb_par[i] = -1;
+      if (rb.joint_type[i] != GTO_JOINT_FIXED && rb.opt_of_frame[i] < 0) rb.pb_par[i] = rb.pb_npar, rb.pb_parf[rb.pb_npar++] = i;
+    }
+    double D = 0.0, maxp = 0.0;  // no frame origin or surface point is further than D from any other
+    for (int i = 0; i < d->n_frames; ++i) {
+      const double* ox = d->origin_xyz + 3 * i;
+      D += std::sqrt(ox[0] * ox[0] + ox[1] * ox[1] + ox[2] * ox[2]);
+      if (rb.joint_type[i] == GTO_JOINT_PRISMATIC) {
+        const int j = rb.opt_of_frame[i];
+        D += j >= 0 ? std::max(std::fabs(rb.lower[j]), std::fabs(rb.upper[j])) : 2.0;
+      }
+    }
+    for (int l = 0; l < d->n_links; ++l) {
+      const double* vx = d->visual_xyz + 3 * l;
+      maxp = std::max(maxp, std::sqrt(vx[0] * vx[0] + vx[1] * vx[1] + vx[2] * vx[2]));
+    }
+    double maxr = 0.0;
+    for (int i = 0; i < d->n_points; ++i) {
+      const double* pp = d->points + 3 * i;
+      maxr = std::max(maxr, std::sqrt(pp[0] * pp[0] + pp[1] * pp[1] + pp[2] * pp[2]));
+    }
+    D += maxp + maxr;
+    rb.pb_eps = 64.0 * d->n_frames * 5.9604644775390625e-08 * D;  // four times the first-order bound 16 F 2^-24 D (gto_kernels.h, PbLayout)
+  }
   {  // operand tables of fk_mfma_tree: the full tree, and the compact tree of the obstacle kernel (gto_device.h)
     const int F = d->n_frames, L = d->n_links, n = d->n_opt;
     auto hom = [](const double* aff, int a, int c) { return a < 3 ? aff[4 * a + c] : (c == 3 ? 1.0 : 0.0); };
@@ -542,6 +573,7 @@ int gto_create(const gto_robot_desc* d, const gto_solver_opts* opts, int device,
   for (const Chunk& c : chunks)
     if (!c.pad) pbchunks.push_back(PbChunk{c.cx, c.cy, c.cz, c.r, rb.link_frame[c.link], 0});
   h->pb_C = (int)pbchunks.size();
+  if (pbchunks.empty()) pbchunks.push_back(PbChunk{0, 0, 0, 0, 0, 0});  // (a robot none of whose links moves: the table is never read)
   if (rb.n_chunks > GTO_MAX_ACTIVE) { delete h; return fail(nullptr, GTO_ERR_UNSUPPORTED, "too many surface points (max 16384)"); }
 
   if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return fail(nullptr, GTO_ERR_HIP, "hipStreamCreate failed"); }
@@ -605,7 +637,7 @@ void gto_destroy(gto_handle* h) {
   (void)hipFree(h->d_perm);
   (void)hipFree(h->d_chunks);
   (void)hipFree(h->d_pbchunks);
-  DevBuf* bufs[] = {&h->zws, &h->trajws, &h->evterms, &h->evblocks, &h->counters, &h->state, &h->Qcur, &h->Qtry, &h->vis, &h->screw, &h->blocks, &h->goalblk, &h->ssfixed, &h->ndone, &h->qf, &h->livebuf, &h->qfs, &h->sswbuf, &h->nzbbuf, &h->itembuf};
+  DevBuf* bufs[] = {&h->zws, &h->trajws, &h->evterms, &h->evblocks, &h->counters, &h->state, &h->Qcur, &h->Qtry, &h->vis, &h->screw, &h->blocks, &h->goalblk, &h->ssfixed, &h->ndone, &h->qf, &h->livebuf, &h->qfs, &h->wrecbuf, &h->itembuf};
   if (h->h_ndone) (void)hipHostFree(h->h_ndone);
   if (h->h_progress) (void)hipHostFree(h->h_progress);
   for (DevBuf* b : bufs) (void)hipFree(b->p);
@@ -898,7 +930,9 @@ static SolveParams make_params(const gto_handle* h, int n_max, bool use_standoff
   sp.dbg_cut = h->dbg_cut;
   sp.interleave = h->obs_interleave == 1;
   sp.pb_next = 0, sp.pb_tg = 1, sp.pb_ng = 1, sp.pb_pw = 1, sp.pb_verify = 0;
-  sp.pb_C = h->pb_C, sp.pb_tab0 = 0, sp.pb_mC = ObsGeom::magic(std::max(1, h->pb_C));
+  sp.pb_C = h->pb_C, sp.pb_tab0 = 0, sp.pb_mC = ObsGeom::magic(std::max(1, h->pb_C)), sp.pb_mF = ObsGeom::magic(h->rb.n_frames);
+  sp.pb_eps = h->rb.pb_eps;
+  sp.pb_npar = h->rb.pb_npar;
   sp.round = sp.parity = 0;
   sp.kcap = h->np == GTO_NB ? GTO_KSPEC : 1;  // candidate copies of the workspace (the wide step kernel generates one)
   sp.k_acc = sp.k_rej = sp.k_eval = 1;
@@ -922,8 +956,7 @@ static int ensure_workspace(gto_handle* h, int B) {
   if ((rc = ensure(h, h->qf, (size_t)B * T * rb.n_frames * sizeof(double)))) return rc;
   if ((rc = ensure(h, h->livebuf, (2 * (1 + kcap) * (size_t)std::min(B, h->slots) + 32) * sizeof(int32_t)))) return rc;
   if ((rc = ensure(h, h->qfs, 2 * (size_t)std::min(B, h->slots) * kcap * T * rb.n_frames * sizeof(double)))) return rc;
-  if ((rc = ensure(h, h->sswbuf, (size_t)(kcap + 1) * B * T * sizeof(double)))) return rc;
-  if ((rc = ensure(h, h->nzbbuf, (size_t)(kcap + 1) * B * T))) return rc;
+  if ((rc = ensure(h, h->wrecbuf, (size_t)(kcap + 1) * B * T * 8 * sizeof(double)))) return rc;
   if ((rc = ensure(h, h->itembuf, 2 * ((size_t)std::min(B, h->slots) * kcap * (T - 2) + 64) * sizeof(int2)))) return rc;
   if (!h->h_ndone) HIPCHK(h, hipHostMalloc((void**)&h->h_ndone, 64));
   if (!h->h_progress) {
@@ -957,8 +990,7 @@ static BatchPtrs make_ptrs(gto_handle* h, const int32_t* scene_id, const double*
   bp.nlive = nullptr;
   bp.next = nullptr;
   bp.qfs = nullptr;
-  bp.ssw = (double*)h->sswbuf.p;
-  bp.nzb = (uint8_t*)h->nzbbuf.p;
+  bp.wrec = (double*)h->wrecbuf.p;
   bp.items = nullptr;
   bp.scenes = h->d_scenes;
   bp.cap = 0;
@@ -1184,7 +1216,7 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
   // launch is laid out over that list.  Needs: the groups of the launch it feeds (consecutive waypoints), room for one
   // pass in the step kernel's dead LDS, at most GTO_PB_PARK parked frames in its serial walk over the kinematic tree.
   const int pb_tg = std::max(1, std::min(h->obs_tg, T - 2)), pb_ng = (T - 2 + pb_tg - 1) / pb_tg;
-  const PbLayout pbl(T, h->rb.n_frames, h->pb_C);
+  const PbLayout pbl(T, h->rb.n_frames, h->pb_C, h->rb.pb_npar);
   const bool pb_ok = h->prebroad && bp.items != nullptr && pb_ng <= 64 && h->obs_interleave != 1 && h->rb.n_xst <= GTO_PB_PARK && pbl.pw >= 1 &&
                      h->pb_C >= 1 && std::min(W, B) > h->few_instances;
   sp.pb_tg = pb_tg, sp.pb_ng = pb_ng, sp.pb_pw = std::max(1, pbl.pw), sp.pb_tab0 = pbl.tab0;
@@ -1294,6 +1326,8 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
     HIPCHK(h, hipMemcpy(t, h->dbg, sizeof t, hipMemcpyDeviceToHost));
     fprintf(stderr, "[gto dbg] step-kernel phases (cycles) P0+P1 %lld | P2 %lld | diag %lld | dense %lld | back %lld | P4 %lld | P5 %lld | s_dense %lld\n",
             t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3], t[5] - t[4], t[6] - t[5], t[7] - t[6], t[9]);
+    fprintf(stderr, "[gto dbg] broad phase in the step kernel's tail (cycles): entry+tables %lld | barrier %lld | A (local transforms, pass 0) %lld | B (chain) %lld | C (sphere tests) %lld | other passes %lld | outputs %lld\n",
+            t[33] - t[6], t[34] - t[33], t[35] - t[34], t[36] - t[35], t[37] - t[36], t[38] - t[37], t[39] - t[38]);
     fprintf(stderr, "[gto dbg] P2 split (cycles): loads+barrier %lld | b-vector+masks %lld | blocks %lld | e,y+barrier %lld\n", t[28] - t[1], t[29] - t[28], t[30] - t[29], t[2] - t[30]);
     fprintf(stderr, "[gto dbg] fk_mfma_tree (cycles): local %lld | rounds %lld %lld %lld %lld | outputs %lld\n", t[21] - t[20], t[22] - t[21], t[23] - t[22], t[24] - t[23], t[25] - t[24], t[27] - t[25]);
     // (only with -DGTO_DEBUG_LONGEST_WG: the extra clocks cost the tuned obstacle kernel registers)
