@@ -410,6 +410,31 @@ def test_hip_lm_ends_where_lbfgsb_ends(capi, oracle_mod, robot, mode):
     h.close()
 
 
+def test_hip_lm_ends_where_lbfgsb_ends_full_horizon(capi, oracle_mod):
+    """The same at the reference's horizon (T = 50, standoff ten waypoints from the end; 336 free variables) on a field that
+    is not empty: a sparse one whose non-zero voxels (the outermost layers of the grid) the arm never reaches, so that the
+    obstacle kernel runs its broad phase against a real distance field while the objective stays the smooth one
+    (GTO_GRAD_ZERO).  Every HIP solution is a KKT point; where L-BFGS-B ends in the same basin, same trajectory, same minimum."""
+    from independent import check_against_lbfgsb
+    T = 50
+    prob = Problem("panda", B=3, scene_seed=1, T=T)
+    opts = oracle_mod.reference_opts(T=T, standoff_offset=-10, grad_mode=1, max_iter=600, tol_rel_f=1e-14)
+    h = capi.SolverHandle(prob.desc, prob.cfg["link_ee"], prob.cfg["link_gripper"], opts, device=0)
+    h.set_mode(0)
+    o = oracle_mod.Oracle(prob.desc, prob.cfg["link_ee"], prob.cfg["link_gripper"], opts)
+    prob.finish(h.eval_fk)
+    c = np.zeros(prob.scene.shape, dtype=np.float32)
+    c[-3:, :, :] = 0.01
+    for x in (h, o):
+        x.set_scene(0, c.reshape(-1), c.reshape(-1), prob.scene.shape, prob.scene.origin, prob.scene.res)
+    Q, _, f, it, st = h.solve_batch(*prob.solve_args())
+    Qo, _, fo, ito, sto = o.solve_batch(*prob.solve_args())
+    np.testing.assert_array_equal(it, ito)
+    np.testing.assert_allclose(Q, Qo, rtol=0, atol=1e-6)
+    check_against_lbfgsb(o, prob, opts, Q, f, st, min_same_basin=2)
+    h.close()
+
+
 @pytest.mark.parametrize("robot", ["panda", "fetch"])
 def test_hip_ik_ends_where_lbfgsb_ends(capi, oracle_mod, robot):
     """gto_solve_ik_batch (no collision term) against SciPy's L-BFGS-B on the objective value (tests/independent.py)."""
@@ -634,9 +659,10 @@ def test_random_robots_base_placement_matches_oracle(capi, oracle_mod, seed):
 
 def test_full_size_properties(capi, oracle_mod):
     """BASELINE.json configs[1] sizes (Panda, ~5k surface points, 128^3 field, 64 goals, T=50):
-    too slow for the scalar oracle end-to-end, so checked through size-independent properties."""
+    size-independent properties on all 64 instances, and eight of them against the oracle at the reference's full
+    iteration cap (100), the oracle running on every core the box allows."""
     prob = Problem("panda_5k", B=64, scene_seed=3, n=128, res=0.0175)
-    opts = oracle_mod.reference_opts(max_iter=40)
+    opts = oracle_mod.reference_opts(max_iter=100)
     h = capi.SolverHandle(prob.desc, prob.cfg["link_ee"], prob.cfg["link_gripper"], opts, device=0)
     prob.finish(h.eval_fk)
     h.set_scene(*prob.scene_args())
@@ -660,10 +686,12 @@ def test_full_size_properties(capi, oracle_mod):
     # a sample of instances against the oracle (same algorithm, FP64)
     o = oracle_mod.Oracle(prob.desc, prob.cfg["link_ee"], prob.cfg["link_gripper"], opts)
     o.set_scene(*prob.scene_args())
-    sel = [0, 17, 63]
-    Qo, _, fo_, ito, _ = o.solve_batch(0, prob.qc[sel], prob.goals[sel], 1, prob.S, prob.base[sel], prob.Q0[sel])
+    sel = [0, 9, 17, 26, 35, 44, 53, 63]
+    Qo, _, fo_, ito, sto = o.solve_batch(0, prob.qc[sel], prob.goals[sel], 1, prob.S, prob.base[sel], prob.Q0[sel], n_threads=o.usable_cores())
     np.testing.assert_array_equal(it[sel], ito)
+    np.testing.assert_array_equal(st[sel], sto)
     np.testing.assert_allclose(Q[sel], Qo, rtol=0, atol=1e-6)
+    np.testing.assert_allclose(f[sel], fo_, rtol=1e-9)
     h.close()
 
 
