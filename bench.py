@@ -119,7 +119,7 @@ def main(argv=None, emit=True):
     ap.add_argument("--grid", type=int, default=128)
     ap.add_argument("--T", type=int, default=50, help="waypoints (reference: 50); the standoff waypoint stays a fifth of them from the end")
     ap.add_argument("--shelf", action="store_true", help="shelf scene (boards and walls around the objects) instead of a table top")
-    ap.add_argument("--mode", choices=["rounds", "single"], default="rounds", help="solver mode (include/gto_solver.h GTO_MODE_*)")
+    ap.add_argument("--mode", choices=["rounds"], default="rounds", help="solver mode (include/gto_solver.h GTO_MODE_*; the single-launch mode was removed in round 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-next-rows", action="store_true", help="skip the next_rows object (IK, depth field, seed scoring, base placement, one plan_goalset call)")
     ap.add_argument("--merged-launches-only", action="store_true",
@@ -199,8 +199,8 @@ def main(argv=None, emit=True):
     default_pose = np.concatenate([np.zeros(ndof - len(cfg["default_pose"])), np.array(cfg["default_pose"], dtype=np.float64)])
     D, M = max(1, args.pipeline), max(1, args.merge)
     slots = int(os.environ.get("GTO_SLOTS", "384"))  # instances a solver call keeps in flight (gto_api.hip)
-    mode = _capi.SolverHandle.MODE_SINGLE_LAUNCH if args.mode == "single" else _capi.SolverHandle.MODE_ROUNDS
-    kernel_name = "k_traj_solve" if args.mode == "single" else "k_obstacle_gram"
+    mode = _capi.SolverHandle.MODE_ROUNDS
+    kernel_name = "k_obstacle_gram"
 
     # this rank's shard of the global problem list: scene = global rank id, 64 grasps each
     lo, hi = shard_range(world * B, rank, world)

@@ -18,7 +18,6 @@
 #include <sys/prctl.h>
 
 #include "gto_kernels.h"
-#include "gto_traj.h"
 
 #define GTO_VERSION 1000
 #ifndef GTO_OBS_DEEP_PD
@@ -50,12 +49,8 @@ struct gto_handle {
   size_t d_scenes_cap = 0;
   // solve workspace (grown on demand)
   DevBuf state, Qcur, Qtry, vis, screw, blocks, goalblk, ssfixed, ndone, qf, livebuf, qfs, wrecbuf, itembuf;
-  DevBuf trajws, evterms, evblocks, counters;  // k_traj_solve: block workspace, evaluation outputs, work counters
-  int traj_nw = 8;        // wavefronts per workgroup (instance) of k_traj_solve: 4, 8 or 16 (GTO_TRAJ_NW)
-  int traj_nw_few = 16;   // ... when a call has few instances (latency matters more than occupancy)
-  int traj_few = 256;     // "few": at most one workgroup per CU
-  int traj_g = 0;         // waypoints per E-phase task (GTO_TRAJ_G), 0 = choose by LDS budget
-  int mode = GTO_MODE_ROUNDS;  // gto_set_mode / GTO_MODE: rounds of two launches over slots, or one launch per call (gto_traj.h)
+  DevBuf counters;  // work counters of a profiled solve
+  int mode = GTO_MODE_ROUNDS;  // gto_set_mode: rounds of two launches over the instances in flight (the only mode left)
   unsigned long long last_counters[4] = {0, 0, 0, 0};
   int32_t* h_ndone = nullptr;  // pinned
   // pinned, device-visible, written by the first workgroup of every step launch: word 0 = call tag << 32 | instances
@@ -81,7 +76,6 @@ struct gto_handle {
   int obs_interleave = 2;
   int prebroad = 1;  // GTO_PREBROAD=0: every (job, group) gets a workgroup of the obstacle kernel in every round
   double pb_min_gain = 0.10;  // GTO_PB_MIN_GAIN: a call whose step-kernel broad phase settles less than this share of the groups stops running it
-  size_t dbg_extra_lds = 0;  // GTO_DEBUG_EXTRA_LDS: occupancy experiments  // GTO_DEBUG_CUT: timing experiments only, results are garbage
   int obs_tg_few = 2;  // ... when few instances are in flight (one small batch, the tail of a call): lower latency per round; results do not depend on the group size
   int few_instances = 64;
   int step_nw_few = 8;  // GTO_STEP_NW_FEW: wavefronts per workgroup of the step kernel in launches with few instances in flight (4 or 8)
@@ -225,31 +219,22 @@ int gto_create(const gto_robot_desc* d, const gto_solver_opts* opts, int device,
   }
   h->opts = *opts;
   if (const char* e = getenv("GTO_AHEAD")) h->ahead = h->ahead_few = std::max(1, atoi(e));
-  if (const char* e = getenv("GTO_AHEAD_FEW")) h->ahead_few = std::max(1, atoi(e));
   if (const char* e = getenv("GTO_SPEC_REJ")) h->spec_rej = std::max(1, std::min(GTO_KSPEC, atoi(e)));
   if (const char* e = getenv("GTO_SPEC_ACC")) h->spec_acc = std::max(1, std::min(GTO_KSPEC, atoi(e)));
   if (const char* e = getenv("GTO_SPEC_DEEP")) h->spec_deep = std::max(0, atoi(e));
   if (const char* e = getenv("GTO_SPEC_FEW")) h->spec_few = std::max(0, atoi(e));
-  if (const char* e = getenv("GTO_OBS_DEEP_MAX")) h->obs_deep_max = std::max(0, atoi(e));
   if (const char* e = getenv("GTO_OBS_DEEP")) h->obs_deep = atoi(e) ? 1 : 0;
   if (const char* e = getenv("GTO_PREBROAD")) h->prebroad = atoi(e) != 0;
   if (const char* e = getenv("GTO_PB_MIN_GAIN")) h->pb_min_gain = atof(e);
   if (const char* e = getenv("GTO_OBS_INTERLEAVE")) h->obs_interleave = std::max(0, std::min(2, atoi(e)));
   if (const char* e = getenv("GTO_DIST_RELAX")) h->dist_relax = atoi(e) ? 1 : 0;
   if (const char* e = getenv("GTO_DEBUG_CUT")) h->dbg_cut = atoi(e);
-  if (const char* e = getenv("GTO_DEBUG_EXTRA_LDS")) h->dbg_extra_lds = (size_t)atoi(e);
   if (h->dbg_cut) fprintf(stderr, "[gto] WARNING: GTO_DEBUG_CUT=%d cuts the obstacle kernel short: timing experiments only, RESULTS ARE GARBAGE\n", h->dbg_cut);
-  if (h->dbg_extra_lds || getenv("GTO_DEBUG_STEP_EXTRA_LDS")) fprintf(stderr, "[gto] WARNING: GTO_DEBUG_*EXTRA_LDS pads the kernels' LDS (occupancy experiments): slower, results unchanged\n");
   if (const char* e = getenv("GTO_SLOTS")) h->slots = std::max(1, atoi(e));
   if (const char* e = getenv("GTO_OBS_TG")) h->obs_tg = h->obs_tg_few = std::max(1, std::min(GTO_MAX_TG, atoi(e)));
   if (const char* e = getenv("GTO_OBS_TG_FEW")) h->obs_tg_few = std::max(1, std::min(GTO_MAX_TG, atoi(e)));
   if (const char* e = getenv("GTO_FEW_INSTANCES")) h->few_instances = atoi(e);
   if (const char* e = getenv("GTO_STEP_NW_FEW")) h->step_nw_few = atoi(e) == 8 ? 8 : 4;
-  if (const char* e = getenv("GTO_TRAJ_NW")) { int v = atoi(e); if (v == 4 || v == 8 || v == 16) h->traj_nw = h->traj_nw_few = v; }
-  if (const char* e = getenv("GTO_TRAJ_NW_FEW")) { int v = atoi(e); if (v == 4 || v == 8 || v == 16) h->traj_nw_few = v; }
-  if (const char* e = getenv("GTO_TRAJ_FEW")) h->traj_few = atoi(e);
-  if (const char* e = getenv("GTO_TRAJ_G")) h->traj_g = std::max(0, std::min(4, atoi(e)));
-  if (const char* e = getenv("GTO_MODE")) h->mode = atoi(e) == GTO_MODE_SINGLE_LAUNCH ? GTO_MODE_SINGLE_LAUNCH : GTO_MODE_ROUNDS;
   if (getenv("GTO_DEBUG_TIMING")) { (void)hipMalloc((void**)&h->dbg, 192 * sizeof(long long)); (void)hipMemset(h->dbg, 0, 192 * sizeof(long long)); }
   RobotDev& rb = h->rb;
   memset(&rb, 0, sizeof rb);
@@ -589,7 +574,6 @@ int gto_create(const gto_robot_desc* d, const gto_solver_opts* opts, int device,
   if (!ok) { gto_destroy(h); return fail(nullptr, GTO_ERR_ALLOC, "device allocation failed in gto_create"); }
   h->np = rb.n_opt <= GTO_NB ? GTO_NB : 16;
   h->lm_lds = h->np == GTO_NB ? lm_lds_bytes(opts->T, 1) : lm_wide_lds_bytes(opts->T, 16);
-  if (const char* e = getenv("GTO_DEBUG_STEP_EXTRA_LDS")) h->lm_lds += (size_t)atoi(e);  // occupancy experiments
   if (h->lm_lds > 160 * 1024) { gto_destroy(h); return fail(nullptr, GTO_ERR_UNSUPPORTED, "T too large for the step kernel's LDS"); }
   // candidates per step the eight-wave step kernel's LDS has room for at this T
   h->spec_kmax = 1;
@@ -598,7 +582,7 @@ int gto_create(const gto_robot_desc* d, const gto_solver_opts* opts, int device,
   {
     const int w = h->np == GTO_NB ? 0 : 1;
     const ObsLds lay(w ? 2 : GTO_MAX_TG, rb.n_frames, rb.n_links, (w ? 2 : GTO_MAX_TG) * rb.n_chunks, h->np);
-    const size_t lds = std::min<size_t>((size_t)lay.total_doubles * sizeof(double) + h->dbg_extra_lds, 160 * 1024);
+    const size_t lds = std::min<size_t>((size_t)lay.total_doubles * sizeof(double), 160 * 1024);
     if ((size_t)lay.total_doubles * sizeof(double) > 150 * 1024) { gto_destroy(h); return fail(nullptr, GTO_ERR_UNSUPPORTED, "robot too large for the obstacle kernel's LDS"); }
     hipError_t e1 = raise_dynamic_lds(w ? (const void*)k_obstacle_gram<16> : (const void*)k_obstacle_gram<GTO_NB>, lds);
     if (!w && e1 == hipSuccess) e1 = raise_dynamic_lds((const void*)k_obstacle_gram<GTO_NB, GTO_OBS_DEEP_PD>, lds);
@@ -637,7 +621,7 @@ void gto_destroy(gto_handle* h) {
   (void)hipFree(h->d_perm);
   (void)hipFree(h->d_chunks);
   (void)hipFree(h->d_pbchunks);
-  DevBuf* bufs[] = {&h->zws, &h->trajws, &h->evterms, &h->evblocks, &h->counters, &h->state, &h->Qcur, &h->Qtry, &h->vis, &h->screw, &h->blocks, &h->goalblk, &h->ssfixed, &h->ndone, &h->qf, &h->livebuf, &h->qfs, &h->wrecbuf, &h->itembuf};
+  DevBuf* bufs[] = {&h->zws, &h->counters, &h->state, &h->Qcur, &h->Qtry, &h->vis, &h->screw, &h->blocks, &h->goalblk, &h->ssfixed, &h->ndone, &h->qf, &h->livebuf, &h->qfs, &h->wrecbuf, &h->itembuf};
   if (h->h_ndone) (void)hipHostFree(h->h_ndone);
   if (h->h_progress) (void)hipHostFree(h->h_progress);
   for (DevBuf* b : bufs) (void)hipFree(b->p);
@@ -860,6 +844,9 @@ int gto_drop_scene(gto_handle* h, int32_t id) {
 int gto_set_mode(gto_handle* h, int32_t mode) {
   if (!h) return GTO_ERR_INVALID_ARG;
   if (mode != GTO_MODE_ROUNDS && mode != GTO_MODE_SINGLE_LAUNCH) return fail(h, GTO_ERR_INVALID_ARG, "unknown solver mode");
+  // (the single-launch kernel of rounds 1-3, one workgroup running an instance's whole solve, was 2.4-2.9x slower than the
+  // rounds and had been a test-only second implementation since round 3: removed in round 4; the mode number stays reserved)
+  if (mode == GTO_MODE_SINGLE_LAUNCH) return fail(h, GTO_ERR_UNSUPPORTED, "GTO_MODE_SINGLE_LAUNCH was removed: the rounds mode is the solver");
   h->mode = mode;
   return GTO_OK;
 }
@@ -1031,7 +1018,7 @@ static int launch_obstacle(gto_handle* h, hipStream_t st, const BatchPtrs& bp, c
   const int nG = geo.nG;
   const int nb = n_jobs > 0 ? n_jobs : B;  // workgroups are laid out for the evaluation jobs there can be; B stays the batch (strides)
   const int n_regular = obstacle_grid(nb, nG);
-  const size_t lds = (size_t)geo.lay.total_doubles * sizeof(double) + h->dbg_extra_lds;
+  const size_t lds = (size_t)geo.lay.total_doubles * sizeof(double);
   const dim3 grid(n_regular + (with_goal_terms ? 8 * ((nb + 31) / 32) : 0));  // goal-term jobs: four to a workgroup, in front, a multiple of eight workgroups
   const bool deep_v = h->np == GTO_NB && deep;
   if (timed) {
@@ -1073,90 +1060,6 @@ static int check_scene_ids_host(gto_handle* h, const int32_t* ids, int B) {
 
 }  // extern "C"
 
-// One workgroup per instance runs the whole solve (gto_traj.h).  nw wavefronts per workgroup; G waypoints per E-phase
-// task, the largest that keeps two workgroups of eight waves (one of sixteen) on a CU.
-template <int NW>
-static int launch_traj_nw(gto_handle* h, hipStream_t st, const TrajArgs& a, const SolveParams& sp, size_t lds) {
-  HIPCHK(h, raise_dynamic_lds((const void*)k_traj_solve<NW>, lds));
-  const int grid = 8 * ((a.B + 7) / 8);
-  hipLaunchKernelGGL(k_traj_solve<NW>, dim3(grid), dim3(64 * NW), lds, st, h->d_rb, h->d_px, h->d_py, h->d_pz, h->d_chunks,
-                     h->d_scenes, a, sp);
-  return GTO_OK;
-}
-
-static int launch_traj(gto_handle* h, hipStream_t st, TrajArgs a, const SolveParams& sp) {
-  const RobotDev& rb = h->rb;
-  int rc;
-  if ((rc = ensure(h, h->trajws, (size_t)a.B * 2 * sp.T * BLK_STRIDE * sizeof(double)))) return rc;
-  if ((rc = ensure(h, h->counters, 64 * sizeof(unsigned long long)))) return rc;
-  a.blocks = (double*)h->trajws.p;
-  a.counters = (unsigned long long*)h->counters.p;
-  a.dbg = h->dbg;
-  // wavefronts per workgroup: as configured, halved while the layout of a robot with many frames / links does not fit
-  int nw = a.B <= h->traj_few ? h->traj_nw_few : h->traj_nw;
-  int G = 2;
-  size_t lds = 0;
-  for (;; nw >>= 1) {
-    const size_t budget = (nw == 16 ? 156 : (nw == 8 ? 78 : 38)) * 1024;  // 1, 2, 4 workgroups per CU
-    G = h->traj_g;
-    if (G <= 0) {
-      G = 2;
-      for (int g = 3; g >= 2; --g)  // three waypoints per task: 16 tasks for T = 50, two rounds of eight waves
-        if ((size_t)TrajLds(sp.T, rb.n_frames, rb.n_links, rb.n_chunks, rb.n_opt, rb.n_xst, g, nw).total * sizeof(double) <= budget) { G = g; break; }
-    }
-    lds = (size_t)TrajLds(sp.T, rb.n_frames, rb.n_links, rb.n_chunks, rb.n_opt, rb.n_xst, G, nw).total * sizeof(double);
-    if (lds <= 160 * 1024 || nw == 4) break;
-  }
-  a.G = G;
-  if (lds > 160 * 1024) return fail(h, GTO_ERR_UNSUPPORTED, "robot / T too large for the solve kernel's LDS");
-  HIPCHK(h, hipMemsetAsync(a.counters, 0, 16 * sizeof(unsigned long long), st));
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  if (h->profiling) {
-    while (h->ev.size() < 2) {
-      hipEvent_t e;
-      HIPCHK(h, hipEventCreate(&e));
-      h->ev.push_back(e);
-    }
-    e0 = h->ev[0], e1 = h->ev[1];
-    HIPCHK(h, hipEventRecord(e0, st));
-  }
-  if (nw == 16) rc = launch_traj_nw<16>(h, st, a, sp, lds);
-  else if (nw == 4) rc = launch_traj_nw<4>(h, st, a, sp, lds);
-  else rc = launch_traj_nw<8>(h, st, a, sp, lds);
-  if (rc) return rc;
-  HIPCHK(h, hipGetLastError());
-  if (h->dbg) {
-    HIPCHK(h, hipStreamSynchronize(st));
-    long long t[48];
-    unsigned long long cn[16];
-    HIPCHK(h, hipMemcpy(t, h->dbg, sizeof t, hipMemcpyDeviceToHost));
-    HIPCHK(h, hipMemcpy(cn, a.counters, sizeof cn, hipMemcpyDeviceToHost));
-    fprintf(stderr, "[gto dbg] k_traj_solve nw=%d G=%d lds=%zu | last iteration of instance 0 (cycles): E %lld | P0-P2 %lld | P3 solve %lld | P4-P5 %lld\n",
-            nw, G, lds, t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3]);
-    fprintf(stderr, "[gto dbg] one regular task of wave 0: sincos %lld | FK %lld | broad+gather %lld | final flush %lld\n", t[9] - t[8], t[10] - t[9],
-            t[11] - t[10], t[12] - t[11]);
-    fprintf(stderr, "[gto dbg] longest task of that evaluation: %lld cycles, task %lld, %lld chunks gathered (evaluation total %lld chunks)\n", t[13], t[14] >> 16,
-            t[14] & 0xffff, t[15]);
-    {
-      const double tot = (double)(cn[4] + cn[5] + cn[6] + cn[7] + cn[8] + cn[9]);
-      fprintf(stderr, "[gto dbg] wave-cycles of the call (all waves, all instances): sincos %.1f%% | FK %.1f%% | broad %.1f%% | gather %.1f%% | idle at E barrier %.1f%% | S phase %.1f%% | total %.3g wave-cycles, %.0f per evaluation\n",
-              100 * cn[4] / tot, 100 * cn[5] / tot, 100 * cn[6] / tot, 100 * cn[7] / tot, 100 * cn[8] / tot, 100 * cn[9] / tot, tot, tot / (double)cn[2]);
-    }
-    fprintf(stderr, "[gto dbg] certification: %llu of %llu waypoint evaluations certified; no survivors %llu, slack >= 2 %llu\n", cn[11], cn[14], cn[12], cn[13]);
-    fprintf(stderr, "[gto dbg] counters: points gathered %llu, chunk tests %llu, evaluations %llu, instances %llu, waypoints skipped as certified free %llu\n", cn[0], cn[1], cn[2], cn[3], cn[10]);
-  }
-  if (h->profiling) {
-    HIPCHK(h, hipEventRecord(e1, st));
-    HIPCHK(h, hipStreamSynchronize(st));
-    float ms = 0.f;
-    HIPCHK(h, hipEventElapsedTime(&ms, e0, e1));
-    h->last_ms = ms;
-    h->last_launches = 1;
-    HIPCHK(h, hipMemcpy(h->last_counters, a.counters, sizeof h->last_counters, hipMemcpyDeviceToHost));
-  }
-  return GTO_OK;
-}
-
 extern "C" {
 
 int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_t* scene_id, const double* qc,
@@ -1171,14 +1074,6 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
   if (h->scenes.empty()) return fail(h, GTO_ERR_NO_SCENE, "no scene has been set");
   HIPCHK(h, hipSetDevice(h->device));
   hipStream_t st = stream ? (hipStream_t)stream : h->stream;
-  if (h->mode == GTO_MODE_SINGLE_LAUNCH) {
-    if (h->np != GTO_NB) return fail(h, GTO_ERR_UNSUPPORTED, "GTO_MODE_SINGLE_LAUNCH handles up to eight optimised joints");
-    TrajArgs a = {};
-    a.scene_id = scene_id, a.qc = qc, a.goals = goals, a.n_goals = n_goals, a.standoff = standoff, a.base_pos = base_pos, a.Q0 = Q0;
-    a.Q_out = Q_out, a.dQ_out = dQ_out, a.cost_out = cost_out, a.iters_out = iters_out, a.status_out = status_out;
-    a.B = B;
-    return launch_traj(h, st, a, make_params(h, n_max, standoff != nullptr));
-  }
   int rc = ensure_workspace(h, B);
   if (rc) return rc;
   SolveParams sp = make_params(h, n_max, standoff != nullptr);
@@ -1682,31 +1577,6 @@ static int eval_common(gto_handle* h, int B, int n_max, const int32_t* scene_id,
   if ((rc = stage_in(h, 4, standoff, (size_t)B * 16 * sizeof(double), &d_so))) return rc;
   if ((rc = stage_in(h, 5, base_pos, (size_t)B * 3 * sizeof(double), &d_base))) return rc;
   if ((rc = stage_in(h, 6, Q, B * ndof * T * sizeof(double), &d_Q0))) return rc;
-  if (h->mode == GTO_MODE_SINGLE_LAUNCH && h->np == GTO_NB) {
-    // the single-launch kernel's own evaluation path (one trajectory evaluation of k_traj_solve, Q taken as it is): what
-    // that mode's solve iterates on is then what the fixture and oracle comparisons look at
-    if ((rc = ensure(h, h->evterms, (size_t)B * 4 * sizeof(double)))) return rc;
-    if ((rc = ensure(h, h->evblocks, (size_t)B * T * BLK_STRIDE * sizeof(double)))) return rc;
-    TrajArgs a = {};
-    a.scene_id = (const int32_t*)d_sid, a.qc = (const double*)d_qc, a.goals = (const double*)d_goals, a.n_goals = (const int32_t*)d_ng;
-    a.standoff = (const double*)d_so, a.base_pos = (const double*)d_base, a.Q0 = (const double*)d_Q0;
-    a.B = B, a.raw = 1, a.eval_only = 1;
-    a.ev_terms = (double*)h->evterms.p, a.ev_blocks = (double*)h->evblocks.p;
-    if ((rc = launch_traj(h, h->stream, a, make_params(h, n_max, standoff != nullptr)))) return rc;
-    std::vector<double> terms((size_t)B * 4);
-    blocks.resize((size_t)B * T * BLK_STRIDE);
-    HIPCHK(h, hipMemcpyAsync(terms.data(), h->evterms.p, terms.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipMemcpyAsync(blocks.data(), h->evblocks.p, blocks.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    HIPCHK(h, hipGetLastError());
-    states.assign(B, InstState{});
-    ssfixed.assign((size_t)B * 4, 0.0);
-    for (int b = 0; b < B; ++b) {
-      states[b].fgoal_try[0] = terms[4 * b], states[b].fvel_try[0] = terms[4 * b + 2], states[b].argmin_try[0] = (int32_t)terms[4 * b + 3];
-      for (int t = 0; t < 2; ++t) ssfixed[4 * b + t] = blocks[((size_t)b * T + t) * BLK_STRIDE + BLK_SS];
-    }
-    return GTO_OK;
-  }
   if ((rc = ensure_workspace(h, B))) return rc;
   SolveParams sp = make_params(h, n_max, standoff != nullptr);
   BatchPtrs bp = make_ptrs(h, (const int32_t*)d_sid, (const double*)d_qc, (const double*)d_goals, (const int32_t*)d_ng,

@@ -38,8 +38,7 @@ extern "C" {
 /* compile-time capacity of the kernels */
 #define GTO_MAX_FRAMES 32 /* kinematic frames after pruning            */
 #define GTO_MAX_LINKS 32  /* collision links carrying surface points   */
-#define GTO_MAX_OPT 16    /* optimised joints (Panda/Fetch arm: 7, mobile Fetch: 10); IK / base placement /
-                             GTO_MODE_SINGLE_LAUNCH: up to 8 */
+#define GTO_MAX_OPT 16    /* optimised joints (Panda/Fetch arm: 7, mobile Fetch: 10); IK / base placement: up to 8 */
 #define GTO_MAX_DOF 32    /* actuated joints (Panda 9, Fetch 15)        */
 
 /* joint types (optas/models.py:850-866) */
@@ -54,8 +53,9 @@ extern "C" {
 /* how gto_solve_batch[_device] runs the Levenberg-Marquardt iterations (same algorithm, same results to round-off) */
 #define GTO_MODE_ROUNDS 0        /* default: rounds of two launches (evaluate / step) over at most 384 instances in flight,
                                     every evaluation spread over the whole GPU: highest throughput, lowest latency */
-#define GTO_MODE_SINGLE_LAUNCH 1 /* one launch per call, one workgroup per instance runs its whole solve on chip: no
-                                    host in the loop (graph-capturable), counts the surface points it gathers */
+#define GTO_MODE_SINGLE_LAUNCH 1 /* reserved: the single-launch kernel of rounds 1-3 (one workgroup runs an instance's whole
+                                    solve; 2.4-2.9x slower than the rounds) was removed; gto_set_mode answers
+                                    GTO_ERR_UNSUPPORTED */
 
 /* per-instance solver status (mirrors "return the iterate anyway", optas/solver.py:135) */
 #define GTO_STATUS_CONVERGED 0
@@ -236,8 +236,7 @@ int gto_solve_base_batch(gto_handle* h, int32_t B, int32_t n_max, const int32_t*
                          const double* goals, double effort_weight, int32_t max_iter, double* y_out, double* q_out,
                          double* cost_out, int32_t* iters_out, int32_t* status_out);
 
-/* Select GTO_MODE_ROUNDS (default) or GTO_MODE_SINGLE_LAUNCH for the following solves (environment GTO_MODE sets the
- * initial value). */
+/* Select the solver mode for the following solves: GTO_MODE_ROUNDS is the only one left. */
 int gto_set_mode(gto_handle* h, int32_t mode);
 
 /*

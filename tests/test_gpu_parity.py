@@ -105,7 +105,7 @@ def test_points_offsets_values_vs_oracle(capi, oracle_mod):
 # ------------------------------------------------------------------------------------------ objective pieces
 @pytest.mark.parametrize("robot,n_goals,standoff", [("panda", 1, True), ("panda", 5, True), ("panda", 3, False),
                                                      ("fetch", 2, True)])
-@pytest.mark.parametrize("mode", [0, 1])  # which kernels evaluate: k_lm_init + k_obstacle_gram | k_traj_solve's evaluation pass
+@pytest.mark.parametrize("mode", [0])
 def test_objective_terms_vs_oracle(capi, oracle_mod, robot, n_goals, standoff, mode):
     prob = Problem(robot, B=5, scene_seed=3, n_goals=n_goals, use_standoff=standoff, base=(0.01, 0.0, -0.02))
     h, o = make_pair(capi, oracle_mod, prob, mode=mode)
@@ -123,7 +123,7 @@ def test_objective_terms_vs_oracle(capi, oracle_mod, robot, n_goals, standoff, m
 
 
 @pytest.mark.parametrize("robot,dense", [("panda", True), ("fetch", True), ("panda", False), ("fetch", False)])
-@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("mode", [0])
 def test_obstacle_normal_equations_vs_oracle(capi, oracle_mod, robot, dense, mode):
     prob = Problem(robot, B=4, scene_seed=1, base=(0.0, 0.02, 0.01))
     h, o = make_pair(capi, oracle_mod, prob, mode=mode)
@@ -175,7 +175,7 @@ def test_plan_cost_vs_oracle(capi, oracle_mod):
 
 
 # ------------------------------------------------------------------------------------------ the solve
-@pytest.mark.parametrize("mode", [0, 1])  # rounds of launches over slots | one launch per call (include/gto_solver.h)
+@pytest.mark.parametrize("mode", [0])
 @pytest.mark.parametrize("max_iter", [0, 1, 2, 5])
 def test_solver_iterates_match_oracle_step_by_step(capi, oracle_mod, max_iter, mode):
     prob = Problem("panda", B=5, scene_seed=3)
@@ -193,7 +193,7 @@ def test_solver_iterates_match_oracle_step_by_step(capi, oracle_mod, max_iter, m
 @pytest.mark.parametrize("robot,n_goals,standoff,grad_mode,scene_seed",
                          [("panda", 1, True, 0, 1), ("panda", 1, True, 0, 3), ("panda", 4, True, 0, 3),
                           ("panda", 1, False, 0, 2), ("panda", 1, True, 1, 3), ("fetch", 1, True, 0, 1)])
-@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("mode", [0])
 def test_full_solve_matches_oracle(capi, oracle_mod, robot, n_goals, standoff, grad_mode, scene_seed, mode):
     prob = Problem(robot, B=6, scene_seed=scene_seed, n_goals=n_goals, use_standoff=standoff)
     h, o = make_pair(capi, oracle_mod, prob, mode=mode, max_iter=60, grad_mode=grad_mode)
@@ -219,7 +219,7 @@ def test_full_solve_matches_oracle(capi, oracle_mod, robot, n_goals, standoff, g
                                           ((-1.5, -1.4, -0.2), 32, 0.05),     # the arm reaches out of the grid on the high side of x
                                           ((0.2, -0.3, 0.05), 24, 0.03),      # a small grid in the middle of the workspace: most spheres outside
                                           ((-0.4, -1.12, 0.12), 48, 0.0467)])  # the table and the lower links are below the grid
-@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("mode", [0])
 def test_robot_partly_outside_the_grid_matches_oracle(capi, oracle_mod, origin, n, res, mode):
     """The broad phase culls a bounding sphere by the distance field at the CLIPPED voxel of its centre (round 3; before,
     spheres that stick out of the grid were never culled): robots that are partly or mostly outside the field, where the
@@ -235,7 +235,7 @@ def test_robot_partly_outside_the_grid_matches_oracle(capi, oracle_mod, origin, 
     h.close()
 
 
-@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("mode", [0])
 def test_ragged_batches_and_scene_table(capi, oracle_mod, mode):
     """B not a multiple of 8, several scenes, per-instance goal counts, then the empty batch."""
     prob = Problem("panda", B=11, scene_seed=1, n_goals=3)
@@ -388,7 +388,7 @@ def test_launch_geometry_does_not_change_results(capi, oracle_mod, monkeypatch, 
     h.close()
 
 
-@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("mode", [0])
 @pytest.mark.parametrize("robot", ["panda", "fetch"])
 def test_hip_lm_ends_where_lbfgsb_ends(capi, oracle_mod, robot, mode):
     """The solver iteration against a third-party optimiser (tests/independent.py): on the smooth problem IPOPT sees
@@ -462,7 +462,7 @@ def test_hip_base_placement_ends_where_lbfgsb_ends(capi, oracle_mod):
     h.close()
 
 
-@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("mode", [0])
 @pytest.mark.parametrize("robot", ["panda", "fetch", "panda_5k"])
 def test_hip_obstacle_blocks_against_finite_difference_jacobians(capi, oracle_mod, robot, mode):
     """k_obstacle_gram's blocks (wrench Grams per link on the matrix core, projected onto the joint screws) against a
@@ -520,7 +520,7 @@ def test_random_robots_match_oracle(capi, oracle_mod, seed):
     np.testing.assert_allclose(A[:, 2:], Ao[:, 2:], rtol=1e-8, atol=1e-10 * max(np.abs(Ao).max(), 1e-30))
     np.testing.assert_allclose(g[:, 2:], go[:, 2:], rtol=1e-8, atol=1e-10 * max(np.abs(go).max(), 1e-30))
     np.testing.assert_allclose(ss, sso, rtol=1e-11, atol=1e-15)
-    for mode in (0, 1):
+    for mode in (0,):
         h.set_mode(mode)
         Qg, _, fg, itg, stg = h.solve_batch(0, qc, goals, 1, S, base, Q0)
         Qo, _, fo, ito, sto = o.solve_batch(0, qc, goals, 1, S, base, Q0)
@@ -622,7 +622,7 @@ def test_random_edge_cases_match_oracle(capi, oracle_mod, seed):
     xo, oo, vo, go = o.eval_points(0, qc, base, use_obs=True)
     np.testing.assert_array_equal(offs, oo)          # clipped voxel indices, bit for bit
     np.testing.assert_array_equal(val, vo)
-    for mode in (0, 1):
+    for mode in (0,):
         h.set_mode(mode)
         Qg, _, fg, itg, stg = h.solve_batch(0, qc, goals, n_goals, S, base, Q0)
         Qo, _, fo, ito, sto = o.solve_batch(0, qc, goals, n_goals, S, base, Q0)
@@ -910,7 +910,7 @@ def _fixture_handle(capi, robot, g, kind=None):
     return h
 
 
-@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("mode", [0])
 @pytest.mark.parametrize("robot", ["panda", "fetch"])
 def test_objective_terms_vs_reference_fixture(capi, robot, mode):
     """gto_eval_objective against the reference's cost expressions (gto/gto_planner.py:84-135): f_goal of the set and of
@@ -1046,7 +1046,7 @@ def test_baseline_config3_one_gpus_share_256_scenes_resident(capi, oracle_mod):
     h.close()
 
 
-@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("mode", [0])
 def test_fetch_shelf_256_instances(capi, oracle_mod, mode):
     """BASELINE configs[2]: Fetch arm, shelf scene, 256 (scene, grasp) instances, T = 50.  Shelf scenes are planned from
     interpolate=False seeds (gto/gto_planner.py:216-219, examples/pybullet_gto_planning.py:98-109): the arm holds qc until
@@ -1163,7 +1163,7 @@ def test_parity_sweep_reduced(capi, oracle_mod, robot, n_goals, T, off, grad):
         h.close()
 
 
-@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("mode", [0])
 def test_device_entry_point_on_caller_stream(capi, oracle_mod, mode):
     """gto_solve_batch_device called directly: every array resident in HBM (torch tensors), work enqueued on the caller's
     stream, results valid after that stream is synchronised; equal to the host-pointer call."""
@@ -1241,9 +1241,8 @@ def test_mobile_fetch_ten_joints_matches_oracle(capi, oracle_mod, T, off, n_goal
     np.testing.assert_allclose(xg, xo, rtol=0, atol=1e-12)
     np.testing.assert_array_equal(og, oo)
     np.testing.assert_array_equal(vg, vo)
-    h.set_mode(1)
-    with pytest.raises(capi.GTOError, match="eight"):
-        h.solve_batch(*prob.solve_args())
+    with pytest.raises(capi.GTOError, match="removed"):  # the single-launch mode of rounds 1-3 is gone; its number stays reserved
+        h.set_mode(1)
     h.close()
 
 

@@ -21,8 +21,6 @@ for i in range(60):
         h.set_scene(0, prob.scene.c_all, prob.scene.c_obs, prob.scene.shape, prob.scene.origin, prob.scene.res)
     if what in ("all", "solve"):
         h.solve_batch(*prob.solve_args())
-    if what in ("all", "mode1"):
-        h.set_mode(1); h.solve_batch(*prob.solve_args())
     if what in ("all", "ik"):
         h.solve_ik_batch(0, prob.qc, prob.goals[:, 0], prob.base, max_iter=5)
     h.close()

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Aggregate rocprofv3 --pmc CSV passes (tools/pmc_pass.sh, tools/pmc_traj.sh) per kernel: mean counter value per dispatch,
+"""Aggregate rocprofv3 --pmc CSV passes (tools/pmc_pass.sh) per kernel: mean counter value per dispatch,
 plus calls and mean duration from the kernel trace of the first pass.  Writes pmc_summary.txt and pmc_summary.json."""
 import csv
 import glob
@@ -9,7 +9,7 @@ import sys
 from collections import defaultdict
 
 out = sys.argv[1]
-want = ("k_obstacle", "k_lm_step", "k_traj_solve")
+want = ("k_obstacle", "k_lm_step")
 agg = defaultdict(lambda: defaultdict(list))
 for f in glob.glob(os.path.join(out, "*", "**", "*counter_collection.csv"), recursive=True):
     with open(f) as fh:

@@ -2,26 +2,40 @@
 """profiles/traffic.json from the PMC passes of tools/pmc_pass.sh: HBM traffic (FETCH_SIZE x 2 + WRITE_SIZE, KB -> bytes; the
 factor 2 is MI355X_MICROARCH.md's gfx950 correction: FETCH_SIZE counts 128-B requests at 64 B) and issue-side figures of
 the dominant kernel per launch, one entry per call size.
-usage: tools/traffic_json.py <gpurun_out/pmc_320> <gpurun_out/pmc_2048> ...   (directory name ends in the call size)"""
+Per kernel VARIANT of the solve loop as well ("variants"), so that bench.py can put a variant's counter traffic next to the
+algorithmic bytes of the same population of launches.
+usage: tools/traffic_json.py <tag> <gpurun_out/pmc_320> <gpurun_out/pmc_2048> ...   (directory name ends in the call size; tag: r04)"""
 import json
 import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 entries = []
-for d in sys.argv[1:]:
+tag = sys.argv[1]
+for d in sys.argv[2:]:
     size = int(os.path.basename(d.rstrip("/")).split("_")[-1])
     js = json.load(open(os.path.join(d, "pmc_summary.json")))
     # the variant for the launches that fill the GPU (the one the roofline is quoted on); the variant for few instances in flight only if there is no other
     cands = [v for n, v in js.items() if "k_obstacle_gram<8, 1>" in n] or [v for n, v in js.items() if "k_obstacle_gram" in n]
     k = max(cands, key=lambda v: v.get("launches", 0) * v.get("mean_us", 0.0))
     us = k["mean_us"]
+    variants = {}
+    for n_, v_ in js.items():
+        if "k_obstacle_gram" in n_ or "k_lm_step" in n_:
+            variants[n_.replace(", ", ",")] = {
+                "launches": v_.get("launches"), "mean_launch_us_profiled": round(v_.get("mean_us", 0.0), 2),
+                "fetch_bytes_per_launch": int(round(2 * v_.get("FETCH_SIZE", 0.0) * 1024)), "write_bytes_per_launch": int(round(v_.get("WRITE_SIZE", 0.0) * 1024)),
+                "hbm_bytes_per_launch": int(round((2 * v_.get("FETCH_SIZE", 0.0) + v_.get("WRITE_SIZE", 0.0)) * 1024)),
+                "l2_hit_rate": round(v_.get("TCC_HIT_sum", 0.0) / max(v_.get("TCC_REQ_sum", 1.0), 1.0), 3),
+                "waves_waiting_frac": round(v_.get("SQ_WAIT_ANY", 0.0) / max(v_.get("SQ_WAVE_CYCLES", 1.0), 1.0), 3),
+                "valu_insts_per_launch": int(v_.get("SQ_INSTS_VALU", 0)), "salu_insts_per_launch": int(v_.get("SQ_INSTS_SALU", 0)),
+                "mfma_insts_per_launch": int(v_.get("SQ_INSTS_MFMA", 0))}
     simd_cycles = 1024 * us * 1e-6 * 2.4e9  # 256 CUs x 4 SIMDs at 2.4 GHz
     entries.append({
         "robot": "panda_5k", "grid": 128, "mode": "rounds", "instances_per_call": size, "slots": 384,
-        "source": f"profiles/r03_pmc_{size}.txt (tools/pmc_pass.sh: rocprofv3 --kernel-trace --pmc, separate passes, bench.py --pipeline 1 "
+        "source": f"profiles/{tag}_pmc_{size}.txt (tools/pmc_pass.sh: rocprofv3 --kernel-trace --pmc, separate passes, bench.py --pipeline 1 "
                   f"--merged-launches-only with calls of {size} instances)",
-        "kernel": "k_obstacle_gram", "launches": k["launches"], "mean_launch_us_profiled": round(us, 2),
+        "kernel": "k_obstacle_gram<8,1>", "variants": variants, "launches": k["launches"], "mean_launch_us_profiled": round(us, 2),
         "FETCH_SIZE_KB_mean_per_launch": round(k["FETCH_SIZE"], 1), "WRITE_SIZE_KB_mean_per_launch": round(k["WRITE_SIZE"], 1),
         "correction": "FETCH_SIZE doubled (gfx950 counts 128-B requests at 64 B, MI355X_MICROARCH.md); WRITE_SIZE uncalibrated, taken as is",
         "hbm_bytes_per_launch": int(round((2 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024)),
