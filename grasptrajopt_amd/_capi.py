@@ -128,7 +128,7 @@ def _preload_hip_runtime():
     for loc in (spec.submodule_search_locations if spec and spec.submodule_search_locations else []):
         cand = os.path.join(loc, "lib", "libamdhip64.so")
         if os.path.exists(cand):
-            if not _same_soname(cand, "/opt/rocm/lib/libamdhip64.so"):
+            if not _same_soname(cand, os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib", "libamdhip64.so")):
                 import warnings
                 warnings.warn(f"torch bundles a HIP runtime ({cand}) with another SONAME than /opt/rocm's: not preloading it; "
                               "import torch AFTER grasptrajopt_amd may then fail to find the GPU")
@@ -192,6 +192,12 @@ def load_library(path: Optional[str] = None):
     lib.gto_set_stream.argtypes = [H, C.c_void_p]
     lib.gto_set_mode.argtypes = [H, C.c_int32]
     lib.gto_share_scene.argtypes = [H, C.c_int32, H, C.c_int32]
+    if hasattr(lib, "gto_scene_from_depth"):  # (an older build named by GTO_HIP_LIB for an A/B run lacks them)
+        lib.gto_scene_from_depth.argtypes = [H, C.c_int32, _pf, C.c_int32, C.c_int32, _pd, _pd, _pd, _pd, C.POINTER(C.c_uint8), C.c_double,
+                                             C.c_double, C.c_double, C.c_float, C.c_float, _pi, _pd, _pd]
+        lib.gto_scene_from_depth.restype = C.c_int
+        lib.gto_get_scene_fields.argtypes = [H, C.c_int32, _pf, _pf]
+        lib.gto_get_scene_fields.restype = C.c_int
     lib.gto_eval_fk.argtypes = [H, C.c_int32, _pd, _pd]
     lib.gto_eval_points.argtypes = [H, C.c_int32, C.c_int32, _pd, _pd, C.c_int32, _pd, _pi, _pd, _pd]
     lib.gto_eval_objective.argtypes = [H, C.c_int32, C.c_int32, _pi, _pd, _pi, _pd, _pd, _pd, _pd, _pd, _pd, _pi]
@@ -219,7 +225,7 @@ EXPORTED_SYMBOLS = (
     "gto_last_kernel_time", "gto_last_kernel_work", "gto_last_kernel_profile", "gto_set_profiling", "gto_set_stream", "gto_set_mode", "gto_share_scene", "gto_eval_fk",
     "gto_eval_points",
     "gto_eval_objective", "gto_eval_obstacle_normal_eq", "gto_plan_cost", "gto_solve_ik_batch", "gto_solve_base_batch",
-    "gto_eval_base_objective", "gto_depth_sdf_cost",
+    "gto_eval_base_objective", "gto_depth_sdf_cost", "gto_scene_from_depth", "gto_get_scene_fields",
 )
 
 
@@ -294,6 +300,32 @@ class SolverHandle:
                     "gto_set_scene_values" if values_only else "gto_set_scene")
         self.scenes[scene_id] = (tuple(int(s) for s in shp), org.copy(), float(res))
 
+    def scene_from_depth(self, scene_id: int, depth, K, cam_pose, target_mask=None, threshold=1.5, grid_res=0.05, margin=0.4,
+                         epsilon=0.02, w_inside=1.0):
+        """gto_scene_from_depth: depth image -> both cost fields resident as scene `scene_id` (voxel records and distance
+        fields included); returns (shape, origin, bounds (3, 2)) of the grid, nothing else leaves the device."""
+        depth = np.ascontiguousarray(depth, dtype=np.float32)
+        Hh, Ww = depth.shape
+        K = _f64(K).reshape(3, 3)
+        cam = _f64(cam_pose).reshape(4, 4)
+        Kinv, cinv = np.ascontiguousarray(np.linalg.inv(K)), np.ascontiguousarray(np.linalg.inv(cam))
+        mask = None if target_mask is None else np.ascontiguousarray(target_mask, dtype=np.uint8)
+        shp, org, bnd = np.zeros(3, np.int32), np.zeros(3), np.zeros(6)
+        pu8 = C.POINTER(C.c_uint8)
+        self._check(self.lib.gto_scene_from_depth(self._h, scene_id, _p(depth, _pf), Hh, Ww, _p(K, _pd), _p(Kinv, _pd), _p(cam, _pd), _p(cinv, _pd),
+                                                  None if mask is None else mask.ctypes.data_as(pu8), float(threshold), float(grid_res), float(margin),
+                                                  float(epsilon), float(w_inside), _p(shp, _pi), _p(org, _pd), _p(bnd, _pd)), "gto_scene_from_depth")
+        self.scenes[scene_id] = (tuple(int(x) for x in shp), org.copy(), float(grid_res))
+        return tuple(int(x) for x in shp), org, np.stack((bnd[:3], bnd[3:]), axis=1)
+
+    def scene_fields(self, scene_id: int):
+        """(c_all, c_obs) of a resident scene as float32 arrays (device to host)."""
+        shape = self.scenes[scene_id][0]
+        n = int(np.prod(shape))
+        ca, co = np.empty(n, np.float32), np.empty(n, np.float32)
+        self._check(self.lib.gto_get_scene_fields(self._h, scene_id, _p(ca, _pf), _p(co, _pf)), "gto_get_scene_fields")
+        return ca, co
+
     def drop_scene(self, scene_id: int):
         self._check(self.lib.gto_drop_scene(self._h, scene_id), "gto_drop_scene")
         self.scenes.pop(scene_id, None)
@@ -345,8 +377,10 @@ class SolverHandle:
 
     def share_scene(self, scene_id, src: "SolverHandle", src_scene_id=None):
         """Use a scene that lives in another handle on the same GPU without a second copy."""
-        self._check(self.lib.gto_share_scene(self._h, int(scene_id), src._h, int(scene_id if src_scene_id is None else src_scene_id)),
-                    "gto_share_scene")
+        src_id = int(scene_id if src_scene_id is None else src_scene_id)
+        self._check(self.lib.gto_share_scene(self._h, int(scene_id), src._h, src_id), "gto_share_scene")
+        if src_id in src.scenes:
+            self.scenes[int(scene_id)] = src.scenes[src_id]
 
     def set_stream(self, stream):
         """Bind every launch/copy of this handle to the caller's HIP stream (an int such as
@@ -394,14 +428,19 @@ class SolverHandle:
         self._check(self.lib.gto_eval_fk(self._h, q.shape[0], _p(q, _pd), _p(out, _pd)), "gto_eval_fk")
         return out
 
-    def eval_points(self, scene_id, q, base_pos, use_obs=False, want_field=True):
+    def eval_points(self, scene_id, q, base_pos, use_obs=False, want_field=True, want=None):
+        """World surface points, voxel offsets, field values and field gradients of configurations q (nq, ndof).
+        ``want``: the outputs to bring back, any of "xyz", "off", "val", "grad" (default: all, or xyz alone with
+        want_field=False); the others are None and cost neither device memory nor a transfer."""
         q = _f64(q).reshape(-1, self.desc.ndof)
         nq, P = q.shape[0], self.desc.n_points
         base = _f64(np.broadcast_to(_f64(base_pos).reshape(-1, 3), (nq, 3)))
-        xyz = np.empty((nq, P, 3))
-        off = np.empty((nq, P), dtype=np.int32) if want_field else None
-        val = np.empty((nq, P)) if want_field else None
-        grad = np.empty((nq, P, 3)) if want_field else None
+        if want is None:
+            want = ("xyz", "off", "val", "grad") if want_field else ("xyz",)
+        xyz = np.empty((nq, P, 3)) if "xyz" in want else None
+        off = np.empty((nq, P), dtype=np.int32) if "off" in want else None
+        val = np.empty((nq, P)) if "val" in want else None
+        grad = np.empty((nq, P, 3)) if "grad" in want else None
         self._check(self.lib.gto_eval_points(self._h, scene_id, nq, _p(q, _pd), _p(base, _pd), int(use_obs),
                                              _p(xyz, _pd), _p(off, _pi), _p(val, _pd), _p(grad, _pd)),
                     "gto_eval_points")

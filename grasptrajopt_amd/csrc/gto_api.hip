@@ -692,7 +692,7 @@ int gto_share_scene(gto_handle* dst, int32_t dst_id, gto_handle* src, int32_t sr
 }
 
 static int set_scene_impl(gto_handle* h, int32_t id, const float* c_all, const float* c_obs, const int32_t shape[3],
-                          const double origin[3], double res, bool values_only) {
+                          const double origin[3], double res, bool values_only, hipMemcpyKind kind = hipMemcpyHostToDevice) {
   if (!h) return GTO_ERR_INVALID_ARG;
   if (!c_all || !shape || !origin) return fail(h, GTO_ERR_INVALID_ARG, "null argument");
   if (id < 0 || id >= 65536) return fail(h, GTO_ERR_INVALID_ARG, "scene_id out of range [0,65536)");
@@ -728,10 +728,10 @@ static int set_scene_impl(gto_handle* h, int32_t id, const float* c_all, const f
   };
   float *da = nullptr, *dob = nullptr;
   SCN(dalloc((void**)&da, nvox * sizeof(float)));
-  SCN(hipMemcpy(da, c_all, nvox * sizeof(float), hipMemcpyHostToDevice));
+  SCN(hipMemcpy(da, c_all, nvox * sizeof(float), kind));
   if (c_obs && c_obs != c_all) {
     SCN(dalloc((void**)&dob, nvox * sizeof(float)));
-    SCN(hipMemcpy(dob, c_obs, nvox * sizeof(float), hipMemcpyHostToDevice));
+    SCN(hipMemcpy(dob, c_obs, nvox * sizeof(float), kind));
   } else {
     dob = da;
   }
@@ -1835,7 +1835,7 @@ int gto_depth_sdf_cost(int device, const float* depth, int32_t H, int32_t W, con
     }
     DCHK(hipcub::DeviceRadixSort::SortPairs(d_tmp, tmp_bytes, d_keys, d_keys2, d_idx, d_idx2, (int)nq, 0, 30, (hipStream_t)0));
     hipLaunchKernelGGL(k_depth_sdf_bvh, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, 0, d_px, d_py, d_pz, d_boxes, P, d_idx2, d_depth, H, W,
-                       d_mats, d_mats + 34, d_q, (long)nq, epsilon, w_inside, d_sdf, d_in, d_cost, d_stats);
+                       d_mats, d_mats + 34, d_q, (long)nq, epsilon, w_inside, d_sdf, d_in, d_cost, d_stats, 0);
     if (d_stats) {
       unsigned long long st[3];
       DCHK(hipMemcpy(st, d_stats, sizeof st, hipMemcpyDeviceToHost));
@@ -1858,6 +1858,209 @@ int gto_depth_sdf_cost(int device, const float* depth, int32_t H, int32_t W, con
   }
 #undef DCHK
   cleanup();
+  return GTO_OK;
+}
+
+
+// numpy.arange(start, stop, step) for doubles, value for value: the length is ceil((stop - start) / step), the fill is
+// a[i] = start + i * ((start + step) - start) (numpy's DOUBLE_fill takes the increment from the first two elements)
+static std::vector<double> np_arange(double start, double stop, double step) {
+  const double len = std::ceil((stop - start) / step);
+  const long n = len > 0 ? (long)len : 0;
+  std::vector<double> a((size_t)n);
+  const double delta = (start + step) - start;
+  for (long i = 0; i < n; ++i) a[i] = i == 0 ? start : (i == 1 ? start + step : start + (double)i * delta);
+  return a;
+}
+
+/* include/gto_solver.h: the per-object perception steps of examples/pybullet_gto_planning.py:176-190 in one call, with
+ * nothing but the grid geometry coming back to the host.  The depth image goes up once; the cloud of all pixels and the
+ * cloud without the target's pixels are back-projected from it; the grid is the bounding box of the first cloud plus
+ * `margin` at `grid_res` (gto/gto_models.py:155-171, numpy.arange's values); both cost fields are searched with ONE
+ * ordering of the voxel centres (one key pass, one radix sort) against the two tile hierarchies, and installed as scene
+ * `scene_id` with their voxel records and distance fields, device to device. */
+int gto_scene_from_depth(gto_handle* h, int32_t scene_id, const float* depth, int32_t H, int32_t W, const double* K,
+                         const double* Kinv, const double* cam_pose, const double* cam_inv, const uint8_t* target_mask,
+                         double threshold, double grid_res, double margin, float epsilon, float w_inside,
+                         int32_t* shape_out, double* origin_out, double* bounds_out) {
+  if (!h) return GTO_ERR_INVALID_ARG;
+  if (!depth || !K || !Kinv || !cam_pose || !cam_inv || H < 1 || W < 1 || !(grid_res > 0) || !(margin >= 0))
+    return fail(h, GTO_ERR_INVALID_ARG, "gto_scene_from_depth: null or empty input");
+  HIPCHK(h, hipSetDevice(h->device));
+  const bool stats = getenv("GTO_DEPTH_STATS") != nullptr;
+  auto t_now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double t_[8] = {t_now(), 0, 0, 0, 0, 0, 0, 0};
+  const size_t N = (size_t)H * W;
+  const int tx = (W + GTO_BVH_TILE_W - 1) / GTO_BVH_TILE_W, ty = (H + GTO_BVH_TILE_H - 1) / GTO_BVH_TILE_H;
+  int P = 1;
+  while (P < tx || P < ty) P <<= 1;
+  if (P > 1024) return fail(h, GTO_ERR_UNSUPPORTED, "gto_scene_from_depth: image larger than 8192 x 4096 pixels");
+  std::vector<std::pair<void*, size_t>> bufs;
+  auto dalloc = [&](size_t bytes) -> void* {
+    size_t cap = 0;
+    void* p = g_depth_pool.take(h->device, bytes ? bytes : 8, &cap);
+    if (p) bufs.emplace_back(p, cap);
+    return p;
+  };
+  auto cleanup = [&]() {
+    (void)hipDeviceSynchronize();
+    for (auto& b : bufs) g_depth_pool.give(h->device, b.first, b.second);
+  };
+#define DCHK(expr)                                                                                   \
+  do {                                                                                               \
+    hipError_t e_ = (expr);                                                                          \
+    if (e_ != hipSuccess) {                                                                          \
+      cleanup();                                                                                     \
+      return fail(h, GTO_ERR_HIP, std::string("gto_scene_from_depth: ") + hipGetErrorString(e_));    \
+    }                                                                                                \
+  } while (0)
+#define DNULL(p)                                                                                     \
+  do {                                                                                               \
+    if (!(p)) {                                                                                      \
+      cleanup();                                                                                     \
+      return fail(h, GTO_ERR_ALLOC, "gto_scene_from_depth: device allocation failed");               \
+    }                                                                                                \
+  } while (0)
+  const bool two = target_mask != nullptr;
+  float* d_depth = (float*)dalloc(N * sizeof(float));
+  double* d_mats = (double*)dalloc((9 + 9 + 16 + 16 + 8) * sizeof(double));
+  uint8_t* d_mask = two ? (uint8_t*)dalloc(N) : nullptr;
+  double* d_pa = (double*)dalloc(3 * N * sizeof(double));
+  double* d_po = two ? (double*)dalloc(3 * N * sizeof(double)) : d_pa;
+  uint8_t* d_valid = (uint8_t*)dalloc(N);
+  double* d_boxa = (double*)dalloc((size_t)(2 * P * P) * 6 * sizeof(double));
+  double* d_boxo = two ? (double*)dalloc((size_t)(2 * P * P) * 6 * sizeof(double)) : d_boxa;
+  DNULL(d_depth); DNULL(d_mats); DNULL(d_pa); DNULL(d_po); DNULL(d_valid); DNULL(d_boxa); DNULL(d_boxo);
+  if (two) DNULL(d_mask);
+  double mats[50];
+  std::memcpy(mats, K, 9 * sizeof(double));
+  std::memcpy(mats + 9, Kinv, 9 * sizeof(double));
+  std::memcpy(mats + 18, cam_pose, 16 * sizeof(double));
+  std::memcpy(mats + 34, cam_inv, 16 * sizeof(double));
+  DCHK(hipMemcpy(d_depth, depth, N * sizeof(float), hipMemcpyHostToDevice));
+  DCHK(hipMemcpy(d_mats, mats, sizeof mats, hipMemcpyHostToDevice));
+  if (two) DCHK(hipMemcpy(d_mask, target_mask, N, hipMemcpyHostToDevice));
+  t_[1] = t_now();
+  const unsigned nbN = (unsigned)((N + 255) / 256);
+  hipLaunchKernelGGL(k_depth_backproject, dim3(nbN), dim3(256), 0, 0, d_depth, H, W, d_mats + 9, d_mats + 18, (const uint8_t*)nullptr, threshold,
+                     d_pa, d_pa + N, d_pa + 2 * N, d_valid);
+  // the hierarchy of the first cloud: its root box is the bounding box of the valid points (gto/gto_models.py:155-157)
+  hipLaunchKernelGGL(k_bvh_leaves, dim3((unsigned)((P * P + 255) / 256)), dim3(256), 0, 0, d_pa, d_pa + N, d_pa + 2 * N, H, W, P, d_boxa);
+  if (P > 1) hipLaunchKernelGGL(k_bvh_up, dim3(1), dim3(1024), 0, 0, P, d_boxa);
+  if (two) {
+    hipLaunchKernelGGL(k_depth_backproject, dim3(nbN), dim3(256), 0, 0, d_depth, H, W, d_mats + 9, d_mats + 18, (const uint8_t*)d_mask, threshold,
+                       d_po, d_po + N, d_po + 2 * N, d_valid);
+    hipLaunchKernelGGL(k_bvh_leaves, dim3((unsigned)((P * P + 255) / 256)), dim3(256), 0, 0, d_po, d_po + N, d_po + 2 * N, H, W, P, d_boxo);
+    if (P > 1) hipLaunchKernelGGL(k_bvh_up, dim3(1), dim3(1024), 0, 0, P, d_boxo);
+  }
+  double root[6];
+  DCHK(hipMemcpy(root, d_boxa, sizeof root, hipMemcpyDeviceToHost));  // (synchronises with the null stream)
+  t_[2] = t_now();
+  if (!(root[0] <= root[3]) || !std::isfinite(root[0]) || !std::isfinite(root[3])) {
+    cleanup();
+    return fail(h, GTO_ERR_INVALID_ARG, "gto_scene_from_depth: no valid pixel in the depth image");
+  }
+  std::vector<double> ax[3];
+  int32_t shape[3];
+  double origin[3];
+  size_t nq = 1;
+  for (int a = 0; a < 3; ++a) {
+    ax[a] = np_arange(root[a] - margin, root[3 + a] + margin, grid_res);
+    shape[a] = (int32_t)ax[a].size();
+    origin[a] = root[a] - margin;
+    nq *= ax[a].size();
+  }
+  if (nq == 0 || nq >= ((size_t)1 << 31)) {
+    cleanup();
+    return fail(h, GTO_ERR_UNSUPPORTED, "gto_scene_from_depth: empty grid or more than 2^31 voxels");
+  }
+  std::vector<double> axes(ax[0]);
+  axes.insert(axes.end(), ax[1].begin(), ax[1].end());
+  axes.insert(axes.end(), ax[2].begin(), ax[2].end());
+  double* d_axes = (double*)dalloc(axes.size() * sizeof(double));
+  double* d_q = (double*)dalloc(nq * 3 * sizeof(double));
+  float* d_costa = (float*)dalloc(nq * sizeof(float));
+  float* d_costo = two ? (float*)dalloc(nq * sizeof(float)) : d_costa;
+  float* d_sdf = (float*)dalloc(nq * sizeof(float));
+  uint8_t* d_in = (uint8_t*)dalloc(nq);
+  unsigned* d_keys = (unsigned*)dalloc(nq * 4 * sizeof(unsigned));
+  DNULL(d_axes); DNULL(d_q); DNULL(d_costa); DNULL(d_costo); DNULL(d_sdf); DNULL(d_in); DNULL(d_keys);
+  DCHK(hipMemcpy(d_axes, axes.data(), axes.size() * sizeof(double), hipMemcpyHostToDevice));
+  const unsigned nbq = (unsigned)((nq + 255) / 256);
+  hipLaunchKernelGGL(k_grid_queries, dim3(nbq), dim3(256), 0, 0, d_axes, shape[0], shape[1], shape[2], d_q);
+  unsigned *d_keys2 = d_keys + nq, *d_idx = d_keys + 2 * nq, *d_idx2 = d_keys + 3 * nq;
+  hipLaunchKernelGGL(k_query_keys, dim3(nbq), dim3(256), 0, 0, d_q, (long)nq, d_boxa, d_keys, d_idx);
+  size_t tmp_bytes = 0;
+  DCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, d_keys, d_keys2, d_idx, d_idx2, (int)nq, 0, 30, (hipStream_t)0));
+  void* d_tmp = dalloc(tmp_bytes);
+  DNULL(d_tmp);
+  DCHK(hipcub::DeviceRadixSort::SortPairs(d_tmp, tmp_bytes, d_keys, d_keys2, d_idx, d_idx2, (int)nq, 0, 30, (hipStream_t)0));
+  unsigned long long* d_stats = nullptr;
+  if (stats) {
+    d_stats = (unsigned long long*)dalloc(3 * sizeof(unsigned long long));
+    if (d_stats) DCHK(hipMemset(d_stats, 0, 3 * sizeof(unsigned long long)));
+    DCHK(hipDeviceSynchronize());
+  }
+  t_[3] = t_now();
+  // the two searches are independent and each is bound by its slowest packets (the voxels deep behind the surfaces): side
+  // by side on two streams of their own, behind everything the null stream has done so far
+  static std::mutex s_mu;
+  static std::vector<std::pair<int, std::pair<hipStream_t, hipStream_t>>> s_streams;  // per device, kept for the process
+  hipStream_t sa = nullptr, sb = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(s_mu);
+    for (auto& e : s_streams)
+      if (e.first == h->device) sa = e.second.first, sb = e.second.second;
+    if (!sa) {
+      DCHK(hipStreamCreateWithFlags(&sa, hipStreamNonBlocking));
+      DCHK(hipStreamCreateWithFlags(&sb, hipStreamNonBlocking));
+      s_streams.push_back({h->device, {sa, sb}});
+    }
+  }
+  DCHK(hipStreamSynchronize(0));
+  uint8_t* d_in2 = two ? (uint8_t*)dalloc(nq) : d_in;
+  DNULL(d_in2);
+  hipLaunchKernelGGL(k_depth_sdf_bvh, dim3(nbq), dim3(256), 0, sa, d_pa, d_pa + N, d_pa + 2 * N, d_boxa, P, d_idx2, d_depth, H, W, d_mats, d_mats + 34,
+                     d_q, (long)nq, epsilon, w_inside, (float*)nullptr, d_in, d_costa, d_stats, 1);
+  if (two)
+    hipLaunchKernelGGL(k_depth_sdf_bvh, dim3(nbq), dim3(256), 0, sb, d_po, d_po + N, d_po + 2 * N, d_boxo, P, d_idx2, d_depth, H, W, d_mats, d_mats + 34,
+                       d_q, (long)nq, epsilon, w_inside, (float*)nullptr, d_in2, d_costo, (unsigned long long*)nullptr, 1);
+  DCHK(hipGetLastError());
+  DCHK(hipDeviceSynchronize());
+  t_[4] = t_now();
+  if (d_stats) {
+    unsigned long long stv[3];
+    DCHK(hipMemcpy(stv, d_stats, sizeof stv, hipMemcpyDeviceToHost));
+    fprintf(stderr, "[gto] depth field search (first cloud): %zu queries, nodes popped per wave %.1f, leaves per wave %.1f\n", nq, (double)stv[2] / ((nq + 63) / 64), (double)stv[1] / 64 / ((nq + 63) / 64));
+  }
+  const int rc = set_scene_impl(h, scene_id, d_costa, two ? d_costo : nullptr, shape, origin, grid_res, false, hipMemcpyDeviceToDevice);
+  t_[5] = t_now();
+#undef DCHK
+#undef DNULL
+  cleanup();
+  t_[6] = t_now();
+  if (stats)
+    fprintf(stderr, "[gto] scene from depth (%d x %d image, %zu voxels), ms: alloc + upload %.3f | back-projection, hierarchies, bounds %.3f | queries, keys, sort %.3f | "
+                    "two searches %.3f | records + distance fields %.3f | release %.3f | total %.3f\n",
+            H, W, nq, t_[1] - t_[0], t_[2] - t_[1], t_[3] - t_[2], t_[4] - t_[3], t_[5] - t_[4], t_[6] - t_[5], t_[6] - t_[0]);
+  if (rc) return rc;
+  if (shape_out) std::memcpy(shape_out, shape, sizeof shape);
+  if (origin_out) std::memcpy(origin_out, origin, sizeof origin);
+  if (bounds_out) std::memcpy(bounds_out, root, sizeof root);
+  return GTO_OK;
+}
+
+/* The two cost fields of a resident scene, device to host (float32 [nx ny nz] each; either pointer may be null). */
+int gto_get_scene_fields(gto_handle* h, int32_t scene_id, float* c_all_out, float* c_obs_out) {
+  if (!h) return GTO_ERR_INVALID_ARG;
+  if (scene_id < 0 || (size_t)scene_id >= h->scenes.size() || !h->scenes[scene_id].valid)
+    return fail(h, GTO_ERR_NO_SCENE, "gto_get_scene_fields: the scene was never set");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  const SceneDev& s = h->scenes[scene_id];
+  const size_t nvox = (size_t)s.nx * s.ny * s.nz;
+  if (c_all_out) HIPCHK(h, hipMemcpy(c_all_out, s.c_all, nvox * sizeof(float), hipMemcpyDeviceToHost));
+  if (c_obs_out) HIPCHK(h, hipMemcpy(c_obs_out, s.c_obs, nvox * sizeof(float), hipMemcpyDeviceToHost));
   return GTO_OK;
 }
 

@@ -15,6 +15,7 @@ import math
 import numpy as np
 
 from . import _capi
+from .depth_scene import LazyCloudPoints, LazyCostField, LazyWorkspacePoints
 
 
 class DepthPointCloud:
@@ -57,21 +58,31 @@ class DepthPointCloud:
     # ------------------------------------------------------------------ reference surface
     @property
     def points(self):
-        """World points of the valid pixels in pixel order (:21-23)."""
+        """World points of the valid pixels in pixel order (:21-23).  A lazy stand-in: the array is only brought to the host
+        if somebody looks at it (GTORobotModel.setup_points_field takes the bounding box from the device instead)."""
+        if self._points is not None:
+            return self._points
+        return LazyCloudPoints(self)
+
+    def _points_now(self):
         if self._points is None:
             self._run(np.zeros((0, 3)), want_points=True)
         return self._points
 
     def get_random_surface_points(self, count):
-        indices = np.random.choice(self.points.shape[0], count)
-        return self.points[indices, :]
+        pts = self._points_now()
+        indices = np.random.choice(pts.shape[0], count)
+        return pts[indices, :]
 
     def get_sdf(self, query_points):
         """:56-61 — float32 signed distances."""
         return self._run(query_points)[0]
 
     def get_sdf_cost(self, query_points, epsilon=0.02, w_inside=1, vis=False):
-        """:64-91 — float32 costs (``vis`` is ignored: no viewer here)."""
+        """:64-91 — float32 costs (``vis`` is ignored: no viewer here).  Asked at the voxel centres of a grid that was sized
+        from a depth cloud (``robot.workspace_points`` still lazy), the answer stays on the device (depth_scene.py)."""
+        if isinstance(query_points, LazyWorkspacePoints):
+            return LazyCostField(self, query_points.robot, epsilon, w_inside)
         return self._run(query_points, epsilon, w_inside)[2]
 
     def get_sdf_in_batches(self, query_points, batch_size=1000000):

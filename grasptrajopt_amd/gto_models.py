@@ -172,10 +172,65 @@ class GTORobotModel:
         self.xlim, self.ylim, self.zlim = [0, arm_len], [-arm_len, arm_len], [0, arm_height + arm_len]
         self._setup_field([self.xlim[0], self.ylim[0], self.zlim[0]], [self.xlim[1], self.ylim[1], self.zlim[1]])
 
+    _FIELD_ATTRS = ("origin", "field_shape", "workspace_points", "field_size", "workspace_bounds")
+
     def setup_points_field(self, points):
+        from .depth_scene import LazyCloudPoints
+        if isinstance(points, LazyCloudPoints):
+            # the cloud is still on the device: the grid is sized there, when the first consumer needs a scene
+            # (depth_scene.py); until then the geometry attributes are pending
+            for a in self._FIELD_ATTRS:
+                self.__dict__.pop(a, None)
+            self._pending_depth = points.dpc
+            return
+        self._pending_depth = None
         points = np.asarray(points)
         self.workspace_bounds = np.stack((points.min(0), points.max(0)), axis=1)
         self._setup_field(self.workspace_bounds[:, 0], self.workspace_bounds[:, 1])
+
+    def __getattr__(self, name):
+        # only reached for attributes that are not set: the grid geometry while a depth cloud is pending
+        if name in GTORobotModel._FIELD_ATTRS and self.__dict__.get("_pending_depth") is not None:
+            if name == "workspace_points":
+                from .depth_scene import LazyWorkspacePoints
+                return LazyWorkspacePoints(self)
+            self._resolve_depth_field()
+            return self.__dict__[name]
+        raise AttributeError(f"{type(self).__name__!s} object has no attribute {name!r}")
+
+    def _resolve_depth_field(self):
+        """Geometry of the pending depth grid: from the resident scene if a consumer has built one, else by building it
+        from the cloud of all pixels."""
+        if "field_shape" not in self.__dict__:
+            self._depth_scene_for(self._pending_depth, 0.02, 1.0)
+
+    def _workspace_points_now(self):
+        """The voxel centres as gto/gto_models.py:159-165 lays them out, from the resident grid's geometry."""
+        lo, hi = self.workspace_bounds[:, 0], self.workspace_bounds[:, 1]
+        m, r = self.field_margin, self.grid_resolution
+        axes = [np.arange(lo[a] - m, hi[a] + m, r) for a in range(3)]
+        return np.array(np.meshgrid(*axes, indexing="ij")).reshape((3, -1)).T
+
+    def _depth_scene_for(self, dpc, epsilon, w_inside):
+        """(handle, scene id) of the resident scene built from `dpc`'s depth image: one gto_scene_from_depth call per image
+        (both cost fields; the field of all pixels does not depend on the mask), shared by every solver handle."""
+        from .depth_scene import DEPTH_SCENE, same_image
+        h = self._util_handle()
+        key = (float(self.grid_resolution), float(self.field_margin), float(epsilon), float(w_inside), float(dpc.threshold))
+        c = self.__dict__.get("_depth_scene")
+        if c is not None and c["key"] == key and same_image(c["depth"], dpc.depth) and np.array_equal(c["K"], dpc.intrinsic_matrix) and \
+                np.array_equal(c["cam"], dpc.camera_pose) and (dpc.target_mask is None or (c["mask"] is not None and same_image(c["mask"], dpc.target_mask))):
+            return h, DEPTH_SCENE
+        shape, origin, bounds = h.scene_from_depth(DEPTH_SCENE, dpc.depth, dpc.intrinsic_matrix, dpc.camera_pose, dpc.target_mask,
+                                                   dpc.threshold, self.grid_resolution, self.field_margin, epsilon, w_inside)
+        self._depth_scene = {"key": key, "depth": dpc.depth, "K": dpc.intrinsic_matrix, "cam": dpc.camera_pose, "mask": dpc.target_mask}
+        pend = self.__dict__.get("_pending_depth")
+        if pend is not None and same_image(pend.depth, dpc.depth):  # this IS the grid setup_points_field was asked for
+            self.workspace_bounds = bounds
+            self.origin = np.asarray(origin, dtype=np.float64).reshape((1, 3))
+            self.field_shape = tuple(int(x) for x in shape)
+            self.field_size = int(np.prod(shape))
+        return h, DEPTH_SCENE
 
     def field_geometry(self):
         if not hasattr(self, "field_shape"):
@@ -233,9 +288,17 @@ class GTORobotModel:
         plan = np.asarray(plan, dtype=np.float64)
         if plan.shape[1] != h.T:
             raise NotImplementedError(f"plans must have T={h.T} waypoints on this handle")
-        shape, origin, res = self.field_geometry()
-        h.set_scene(self.SCRATCH_SCENE, sdf_cost_obstacle, None, shape, origin, res, values_only=True)  # scored, never solved on
-        cost, dist = h.plan_cost(self.SCRATCH_SCENE, plan[None], base_position)
+        sid = self.SCRATCH_SCENE
+        if hasattr(sdf_cost_obstacle, "ensure_scene"):  # resident on the device (depth_scene.py)
+            src, ssid = sdf_cost_obstacle.ensure_scene()
+            if src is h:
+                sid = ssid
+            else:
+                h.share_scene(sid, src, ssid)
+        else:
+            shape, origin, res = self.field_geometry()
+            h.set_scene(sid, sdf_cost_obstacle, None, shape, origin, res, values_only=True)  # scored, never solved on
+        cost, dist = h.plan_cost(sid, plan[None], base_position)
         return float(cost[0]), float(dist[0])
 
     def close(self):

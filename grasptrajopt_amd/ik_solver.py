@@ -43,9 +43,13 @@ class IKSolver:
         if self.collision_avoidance:
             if sdf_cost_obstacle is None:
                 raise ValueError("collision_avoidance=True needs sdf_cost_obstacle")
-            shape, origin, res = self.robot.field_geometry()
             sid = 0  # the IK solver owns its handle
-            h.set_scene(sid, sdf_cost_obstacle, None, shape, origin, res)
+            if hasattr(sdf_cost_obstacle, "ensure_scene"):  # resident on the device (depth_scene.py): shared, not uploaded
+                src, ssid = sdf_cost_obstacle.ensure_scene()
+                h.share_scene(sid, src, ssid)
+            else:
+                shape, origin, res = self.robot.field_geometry()
+                h.set_scene(sid, sdf_cost_obstacle, None, shape, origin, res)
         q, f, iters, status = h.solve_ik_batch(sid, q_0, RTs.reshape(B, 16), base, self.max_iter)
         # errors as the reference reports them (gto/ik_solver.py:88-93)
         tf = h.eval_fk(q)[:, self._fe]
@@ -54,7 +58,7 @@ class IKSolver:
         err_rot = np.degrees(np.arccos(np.clip(cosang, -1.0, 1.0)))
         cost = np.zeros(B)
         if self.collision_avoidance:  # compute_plan_cost of a one-column plan (gto/gto_models.py:204-215)
-            _, _, val, _ = h.eval_points(sid, q, base, use_obs=True)
+            _, _, val, _ = h.eval_points(sid, q, base, use_obs=True, want=("val",))
             cost = val.sum(axis=1)
         return q, err_pos, err_rot, cost, iters, status
 

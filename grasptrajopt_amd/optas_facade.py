@@ -191,7 +191,11 @@ class Solver:
                 raise KeyError(f"unknown parameter '{k}'")
         self._p_dict = {k: np.zeros(shape, dtype=np.float32 if k in ("sdf_cost_all", "sdf_cost_obstacle") else np.float64)
                         for k, shape in self.opt.parameters.items() if k not in p}
+        from .depth_scene import LazyCostField
         for k, v in p.items():
+            if isinstance(v, LazyCostField):  # a cost field that is resident on the device (depth_scene.py): stays there
+                self._p_dict[k] = v
+                continue
             # the two cost fields stay float32 (they are float32 at the boundary, include/gto_solver.h): converting 2 x 2 M
             # voxels to float64 here and back in set_scene cost more than the upload itself
             keep = k in ("sdf_cost_all", "sdf_cost_obstacle") and getattr(v, "dtype", None) == np.float32
@@ -249,12 +253,21 @@ class CasADiSolver(Solver):
         # planner's upload replaces the field under this solver, so "already uploaded" is only true while this solver was the
         # last one to write the scene
         if getattr(self, "_scene_dirty", True) or getattr(self._handle, "_scene0_owner", None) is not self:
+            from .depth_scene import LazyCostField
             robot, p = self.opt.robot, self._p_dict
-            shape, origin, res = robot.field_geometry()
-            # parameters that were never set are zeros (optas/mx_container.py:121): plan() leaves sdf_cost_all out
-            c_all = p.get("sdf_cost_all", np.zeros(int(np.prod(shape))))
-            c_obs = p.get("sdf_cost_obstacle", np.zeros(int(np.prod(shape))))
-            self._handle.set_scene(self.SCENE_ID, c_all, c_obs, shape, origin, res)
+            la, lo = p.get("sdf_cost_all"), p.get("sdf_cost_obstacle")
+            if isinstance(la, LazyCostField) and isinstance(lo, LazyCostField) and la.dpc.target_mask is None and \
+                    la.ensure_scene() == lo.ensure_scene():
+                # both fields are the two halves of one resident depth scene: the solver's scene becomes that scene (no copy,
+                # nothing through the host)
+                src, sid = lo.ensure_scene()
+                self._handle.share_scene(self.SCENE_ID, src, sid)
+            else:
+                shape, origin, res = robot.field_geometry()
+                # parameters that were never set are zeros (optas/mx_container.py:121): plan() leaves sdf_cost_all out
+                c_all = p.get("sdf_cost_all", np.zeros(int(np.prod(shape))))
+                c_obs = p.get("sdf_cost_obstacle", np.zeros(int(np.prod(shape))))
+                self._handle.set_scene(self.SCENE_ID, np.asarray(c_all), np.asarray(c_obs), shape, origin, res)
             self._handle._scene0_owner = self
             self._scene_dirty = False
         return self.SCENE_ID

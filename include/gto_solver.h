@@ -331,6 +331,23 @@ int gto_depth_sdf_cost(int device, const float* depth, int32_t height, int32_t w
                        const double* query, int64_t nq, float epsilon, float w_inside, float* sdf_out,
                        uint8_t* inside_out, float* cost_out, double* points_out, uint8_t* valid_out);
 
+/*
+ * The per-object perception steps of examples/pybullet_gto_planning.py:176-190 in ONE call, leaving a scene resident:
+ * depth image -> cloud of all pixels and cloud without the target's pixels (mesh_to_sdf/depth_point_cloud.py:9-53) ->
+ * grid = bounding box of the first cloud + margin at grid_res (gto/gto_models.py:155-171; numpy.arange's values) ->
+ * sdf_cost_all and sdf_cost_obstacle at the voxel centres (depth_point_cloud.py:64-91; bit-identical to two
+ * gto_depth_sdf_cost calls) -> scene `scene_id` of the handle with its voxel records and distance fields.  The image is
+ * uploaded once, back-projection and query ordering are shared by the two fields, and nothing but the geometry returns
+ * to the host: shape_out [3], origin_out [3], bounds_out [6] = (min x, y, z, max x, y, z) of the first cloud.
+ * target_mask == NULL: one cloud, sdf_cost_obstacle = sdf_cost_all.
+ */
+int gto_scene_from_depth(gto_handle* h, int32_t scene_id, const float* depth, int32_t H, int32_t W, const double* K,
+                         const double* Kinv, const double* cam_pose, const double* cam_inv, const uint8_t* target_mask,
+                         double threshold, double grid_res, double margin, float epsilon, float w_inside,
+                         int32_t* shape_out, double* origin_out, double* bounds_out);
+/* The two float32 cost fields of a resident scene, device to host (either pointer may be NULL). */
+int gto_get_scene_fields(gto_handle* h, int32_t scene_id, float* c_all_out, float* c_obs_out);
+
 #ifdef __cplusplus
 }
 #endif

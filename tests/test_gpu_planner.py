@@ -303,3 +303,77 @@ def test_plan_goalset_seed_vs_reference_fixture(robot_name, interpolate):
     exp[:, 0] = exp[:, 1] = qc
     np.testing.assert_allclose(plan, exp, rtol=0, atol=1e-13)
     robot.close()
+
+
+def _depth_scene_inputs():
+    """A camera looking down at a table with two boxes, 480 x 640 (tools/pipeline_latency.py's image)."""
+    H, W = 480, 640
+    K = np.array([[600.0, 0, 320.0], [0, 600.0, 240.0], [0, 0, 1.0]])
+    v, u = np.mgrid[0:H, 0:W]
+    depth = (1.0 + 0.0012 * (v - H / 2) + 0.0003 * (u - W / 2)).astype(np.float32)
+    for (r0, r1, c0, c1, dz) in ((150, 260, 200, 330, 0.2), (280, 400, 380, 520, 0.1)):
+        depth[r0:r1, c0:c1] -= dz
+    depth[5:9, 7:30] = 0.0  # a few invalid pixels
+    target = np.zeros((H, W), np.uint8)
+    target[150:260, 200:330] = 1
+    a = 0.9
+    cam = np.eye(4)
+    cam[:3, :3] = np.array([[0, -np.sin(a), np.cos(a)], [-1.0, 0, 0], [0, -np.cos(a), -np.sin(a)]])
+    cam[:3, 3] = [-0.1, 0.0, 0.9]
+    return depth, K, cam, target
+
+
+@pytest.mark.parametrize("res", [0.05, 0.031])
+def test_device_resident_depth_scene_equals_the_host_path(oracle_mod, res):
+    """examples/pybullet_gto_planning.py:176-190, 242-272, 291 called the reference's way: two DepthPointCloud objects from one
+    image, setup_points_field(points), get_sdf_cost(workspace_points) twice, IK of the grasps, plan_goalset.  Left lazy, all
+    of it stays on the GPU (ONE gto_scene_from_depth call: depth_scene.py); forced through numpy (the host path of rounds
+    2-3: points, grid and fields as arrays) it must give the same grid, bit-identical fields and the same IK and plan."""
+    cfg = cfg_of("panda")
+    depth, K, cam, target = _depth_scene_inputs()
+    n_goals = 12
+    qc = np.array(cfg["default_pose"])
+    out = {}
+    for path in ("host", "device"):
+        robot = g.GTORobotModel(desc=g.load_builtin("panda"), time_derivs=[0, 1], param_joints=cfg["param_joints"],
+                                collision_link_names=cfg["collision_link_names"], device=0)
+        robot.grid_resolution = res
+        dpc_all = g.DepthPointCloud(depth, K, cam, target_mask=None, threshold=2.0)
+        dpc_obs = g.DepthPointCloud(depth, K, cam, target_mask=target, threshold=2.0)
+        pts = dpc_all.points
+        if path == "host":
+            pts = np.asarray(pts)  # the array the reference's DepthPointCloud hands out
+        robot.setup_points_field(pts)
+        wp = robot.workspace_points
+        if path == "host":
+            assert isinstance(wp, np.ndarray)
+        c_all = dpc_all.get_sdf_cost(wp)
+        c_obs = dpc_obs.get_sdf_cost(wp)
+        if path == "device":
+            assert not isinstance(c_all, np.ndarray) and not isinstance(c_obs, np.ndarray)  # nothing came to the host
+        ik = g.IKSolver(robot, cfg["link_ee"], cfg["link_gripper"], collision_avoidance=True)
+        RT, _ = syn.make_goals(robot.desc, robot._util_handle().eval_fk, cfg["link_ee"], n_goals, seed=11, zlim=(0.15, 0.6))
+        q_ik, ep, er, cost_ik, it, st = ik.solve_ik_batch(qc, RT, c_obs, [0.0, 0.0, 0.0])
+        planner = g.GTOPlanner(robot, cfg["link_ee"], cfg["link_gripper"], standoff_distance=-0.1, standoff_offset=-10)
+        planner.max_iter = 25
+        plan, dQ, cost = planner.plan_goalset(qc, RT, c_all, c_obs, [0.0, 0.0, 0.0], q_ik.T.astype(np.float32),
+                                              use_standoff=True, axis_standoff=cfg["axis_standoff"], interpolate=True)
+        pc, pd_ = robot.compute_plan_cost(plan, c_obs, [0.0, 0.0, 0.0])
+        out[path] = dict(shape=robot.field_geometry()[0], origin=robot.field_geometry()[1], bounds=np.asarray(robot.workspace_bounds),
+                         wp=np.asarray(robot.workspace_points), c_all=np.asarray(c_all), c_obs=np.asarray(c_obs), q_ik=q_ik, it=it,
+                         plan=plan, cost=cost, seed=planner.seed_index, pc=pc, size=robot.field_size)
+        robot.close()
+    h_, d_ = out["host"], out["device"]
+    assert h_["shape"] == d_["shape"] and h_["size"] == d_["size"]
+    np.testing.assert_array_equal(h_["origin"], d_["origin"])
+    np.testing.assert_array_equal(h_["bounds"], d_["bounds"])
+    np.testing.assert_array_equal(h_["wp"], d_["wp"])          # numpy.arange's values, reproduced on the host side of the C call
+    np.testing.assert_array_equal(h_["c_all"], d_["c_all"])    # bit-identical float32 fields
+    np.testing.assert_array_equal(h_["c_obs"], d_["c_obs"])
+    assert (h_["c_all"] != h_["c_obs"]).any()
+    np.testing.assert_array_equal(h_["q_ik"], d_["q_ik"])
+    np.testing.assert_array_equal(h_["it"], d_["it"])
+    assert h_["seed"] == d_["seed"]
+    np.testing.assert_array_equal(h_["plan"], d_["plan"])
+    np.testing.assert_array_equal(h_["cost"], d_["cost"])
+    assert h_["pc"] == d_["pc"]

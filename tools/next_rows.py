@@ -187,6 +187,17 @@ def measure(device=0, scene=None, n_ik=1024, n_sets=1024, n_goals_base=10, n_pla
                                              "iters_equal": bool(planner.solver.number_of_iterations() == int(ito[0])),
                                              "rel_dcost": float(abs(float(cost[0]) - float(fo[0])) / max(abs(float(fo[0])), 1e-300))}}
     robot.close()
+    # ---- the whole per-object pipeline through the drop-in surface (examples/pybullet_gto_planning.py:176-190, 242-272, 291):
+    # device-resident since round 4, next to the host path of rounds 2-3 on the same inputs (same plan, checked)
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gto_pipeline_latency", os.path.join(ROOT, "tools", "pipeline_latency.py"))
+    pl = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(pl)
+    dv, ho = pl.stage_table(0.05, 64, 6, host=False, device=device), pl.stage_table(0.05, 64, 3, host=True, device=device)
+    out["per_object_pipeline"] = {"reference": "examples/pybullet_gto_planning.py:176-190 (clouds, grid, two cost fields), :242-272 (IK of the grasps), :291 (plan_goalset); "
+                                               "the reference's timers for these stages add up to 6-33 s per object",
+                                  "device_resident": dv, "host_path_rounds_2_3": ho["ms"],
+                                  "check": {"same_plan_cost_as_host_path": bool(dv["plan_cost"] == ho["plan_cost"]), "same_grid": dv["field_shape"] == ho["field_shape"]}}
     return out
 
 

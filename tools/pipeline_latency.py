@@ -1,9 +1,12 @@
 #!/usr/bin/env python3
 """Per-object latency of the whole drop-in pipeline, stage by stage, through the Python surface that mirrors
 examples/pybullet_gto_planning.py:
-  depth image -> point cloud -> grid (:176-179) -> cost fields sdf_cost_all / sdf_cost_obstacle (:181-184, two
-  DepthPointCloud.get_sdf_cost calls) -> IK pre-filter of the candidate grasps (:242-272, one solve_ik_batch instead of
-  a loop of IPOPT runs) -> plan_goalset (:291).
+  depth image -> two DepthPointCloud objects, grid from the first one's points (:176-179) -> cost fields sdf_cost_all /
+  sdf_cost_obstacle (:181-190, two get_sdf_cost calls) -> IK pre-filter of the candidate grasps (:242-272, one
+  solve_ik_batch instead of a loop of IPOPT runs) -> plan_goalset (:291).
+Since round 4 the first two stages only hand out lazy stand-ins (grasptrajopt_amd/depth_scene.py); the GPU work of the
+perception steps happens in ONE gto_scene_from_depth call when the first consumer needs a scene, timed here as its own
+stage (`resident scene`).  `host=True` forces the round-3 path (points, grid and fields through numpy) for comparison.
 The reference reports 1.6-2.5 s for the IK loop and 4-30 s planning_time per object; its KD-tree field takes seconds.
 usage: python tools/pipeline_latency.py [grid_resolution=0.05] [n_grasps=64] [reps=10]"""
 import os
@@ -15,18 +18,15 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-import grasptrajopt_amd as g  # noqa: E402
-from grasptrajopt_amd import synthetic as syn  # noqa: E402
-from helpers import cfg_of  # noqa: E402
 
 
-def main():
-    res = float(sys.argv[1]) if len(sys.argv) > 1 else 0.05
-    n_goals = int(sys.argv[2]) if len(sys.argv) > 2 else 64
-    reps = int(sys.argv[3]) if len(sys.argv) > 3 else 10
+def stage_table(res=0.05, n_goals=64, reps=10, host=False, device=0):
+    import grasptrajopt_amd as g
+    from grasptrajopt_amd import synthetic as syn
+    from helpers import cfg_of
     cfg = cfg_of("panda_5k")
     robot = g.GTORobotModel(desc=g.load_builtin("panda_5k"), time_derivs=[0, 1], param_joints=cfg["param_joints"],
-                            collision_link_names=cfg["collision_link_names"], device=0)
+                            collision_link_names=cfg["collision_link_names"], device=device)
     robot.grid_resolution = res
     # a camera looking down at a table with two boxes, 480 x 640
     H, W = 480, 640
@@ -51,10 +51,14 @@ def main():
         t = [time.perf_counter()]
         dpc_all = g.DepthPointCloud(d, K, cam, target_mask=None, threshold=2.0)
         dpc_obs = g.DepthPointCloud(d, K, cam, target_mask=target, threshold=2.0)
-        robot.setup_points_field(dpc_all.points)
+        pts = dpc_all.points
+        robot.setup_points_field(np.asarray(pts) if host else pts)
         t.append(time.perf_counter())
         c_all = dpc_all.get_sdf_cost(robot.workspace_points)
         c_obs = dpc_obs.get_sdf_cost(robot.workspace_points)
+        t.append(time.perf_counter())
+        if hasattr(c_obs, "ensure_scene"):
+            c_obs.ensure_scene()  # (the IK call would do it: timed as a stage of its own)
         t.append(time.perf_counter())
         q_ik, ep, er, cost_ik, it, st = ik.solve_ik_batch(qc, RT, c_obs, [0.0, 0.0, 0.0])
         ok = (ep < 0.01) & (er < 5.0)
@@ -66,12 +70,30 @@ def main():
         rows.append(np.diff(t))
     ms = np.median(np.array(rows[2:]), axis=0) * 1e3
     shape = robot.field_geometry()[0]
-    print(f"grid {res*100:.2f} cm -> field {tuple(shape)} ({int(np.prod(shape))} voxels), {n_goals} candidate grasps ({int(ok.sum())} pass the IK thresholds), 480x640 depth")
-    print(f"  point clouds + grid      {ms[0]:7.2f} ms")
-    print(f"  two cost fields          {ms[1]:7.2f} ms")
-    print(f"  IK of all grasps         {ms[2]:7.2f} ms")
-    print(f"  plan_goalset             {ms[3]:7.2f} ms")
-    print(f"  per object, end to end   {ms.sum():7.2f} ms (median of {reps})")
+    out = {"grid_resolution_m": res, "field_shape": [int(x) for x in shape], "voxels": int(np.prod(shape)), "candidate_grasps": n_goals,
+           "grasps_passing_ik": int(ok.sum()), "image": f"{H}x{W} depth", "path": "host (numpy points, grid and fields: rounds 2-3)" if host else "device-resident (depth_scene.py)",
+           "ms": {"clouds_and_grid": round(float(ms[0]), 3), "two_cost_fields": round(float(ms[1]), 3), "resident_scene_build": round(float(ms[2]), 3),
+                  "ik_of_all_grasps": round(float(ms[3]), 3), "plan_goalset": round(float(ms[4]), 3), "per_object": round(float(ms.sum()), 3)},
+           "plan_cost": float(cost[0]), "reps": reps}
+    robot.close()
+    return out
+
+
+def main():
+    res = float(sys.argv[1]) if len(sys.argv) > 1 else 0.05
+    n_goals = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+    reps = int(sys.argv[3]) if len(sys.argv) > 3 else 10
+    for host in (False, True):
+        o = stage_table(res, n_goals, reps, host)
+        m = o["ms"]
+        print(f"[{o['path']}] grid {res*100:.2f} cm -> field {tuple(o['field_shape'])} ({o['voxels']} voxels), {n_goals} candidate grasps "
+              f"({o['grasps_passing_ik']} pass the IK thresholds), {o['image']}")
+        print(f"  point clouds + grid      {m['clouds_and_grid']:7.2f} ms")
+        print(f"  two cost fields          {m['two_cost_fields']:7.2f} ms")
+        print(f"  resident scene build     {m['resident_scene_build']:7.2f} ms")
+        print(f"  IK of all grasps         {m['ik_of_all_grasps']:7.2f} ms")
+        print(f"  plan_goalset             {m['plan_goalset']:7.2f} ms")
+        print(f"  per object, end to end   {m['per_object']:7.2f} ms (median of {reps}); plan cost {o['plan_cost']:.6f}")
 
 
 if __name__ == "__main__":
