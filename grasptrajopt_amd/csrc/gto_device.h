@@ -118,19 +118,25 @@ struct Chunk {
 // ---------------------------------------------------------------- 3x4 affine helpers (row-major)
 __host__ __device__ inline void aff_mul(const double* a, const double* b, double* c) {
   double r[12];
+#pragma unroll
   for (int i = 0; i < 3; ++i) {
+#pragma unroll
     for (int j = 0; j < 4; ++j) {
       double s = a[4 * i] * b[j] + a[4 * i + 1] * b[4 + j] + a[4 * i + 2] * b[8 + j];
       if (j == 3) s += a[4 * i + 3];
       r[4 * i + j] = s;
     }
   }
+#pragma unroll
   for (int i = 0; i < 12; ++i) c[i] = r[i];
 }
 __host__ __device__ inline void mat3_mul(const double* a, const double* b, double* c) {
   double r[9];
+#pragma unroll
   for (int i = 0; i < 3; ++i)
+#pragma unroll
     for (int j = 0; j < 3; ++j) r[3 * i + j] = a[3 * i] * b[j] + a[3 * i + 1] * b[3 + j] + a[3 * i + 2] * b[6 + j];
+#pragma unroll
   for (int i = 0; i < 9; ++i) c[i] = r[i];
 }
 // optas/spatialmath.py:186-211 rpy2r 'zyx' = rotz(y) @ roty(p) @ rotx(r)
