@@ -26,6 +26,16 @@ __global__ void chains(double* out, long long* cyc, int n, double a, double b) {
         x[k] = __hiloint2double(hi, lo);
       }
       if (OP == 6) x[k] = __shfl_xor(x[k], 1, 64);
+      if (OP == 8 || OP == 9) {
+        typedef unsigned u2 __attribute__((ext_vector_type(2)));
+        const unsigned lo = __double2loint(x[k]), hi = __double2hiint(x[k]);
+        const u2 l = OP == 8 ? __builtin_amdgcn_permlane32_swap(lo, lo, false, false) : __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+        const u2 h = OP == 8 ? __builtin_amdgcn_permlane32_swap(hi, hi, false, false) : __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        x[k] = __hiloint2double((int)h.y, (int)l.y);
+      }
+      if (OP == 10) x[k] = __shfl(x[k], (lane & 56) | 3, 64);  // ds_bpermute
+      if (OP == 11) x[k] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x[k]), 9), __builtin_amdgcn_readlane(__double2loint(x[k]), 9)) + b;
+      if (OP == 12) { const double r0 = __builtin_amdgcn_rcp(x[k]); const double r1 = fma(fma(-x[k], r0, 1.0), r0, r0); x[k] = fma(fma(-x[k], r1, 1.0), r1, r1); }
       if (OP == 7) { float f = (float)x[k]; f = fmaf(f, (float)a, (float)b); x[k] = f; }
     }
   }
@@ -61,5 +71,10 @@ int main() {
   ALL(5, "dpp quad_perm mov (x2)")
   ALL(6, "shfl_xor f64 (ds_swizzle/bpermute)")
   ALL(7, "cvt+v_fma_f32+cvt")
+  ALL(8, "permlane32_swap (x2, +movs)")
+  ALL(9, "permlane16_swap (x2, +movs)")
+  ALL(10, "__shfl f64 (ds_bpermute x2)")
+  ALL(11, "readlane x2 + v_add_f64")
+  ALL(12, "rcp + 2 Newton (5 ops)")
   return 0;
 }
