@@ -61,13 +61,18 @@ struct gto_handle {
   unsigned progress_tag = 0;
   int ahead = 8;           // GTO_AHEAD: rounds the host may enqueue beyond the last one it has seen running
   int ahead_few = 8;       // GTO_AHEAD_FEW: ... in launches with few instances in flight (short rounds)
-  // speculation (gto_kernels.h GTO_KSPEC): candidates a step generates after a round without an accepted evaluation, in
-  // launches with few instances in flight (more work, fewer dependent rounds); after an accepted evaluation once at most
-  // `spec_deep` instances are in flight (the GPU is nearly idle then: every candidate is free)
-  int spec_rej = 4, spec_acc = 3, spec_deep = 6, spec_kmax = 1;
+  // speculation (gto_kernels.h GTO_KSPEC): candidates a step generates ahead of their evaluation in launches with few
+  // instances in flight (more work, fewer dependent rounds).  Every candidate is a job of the next obstacle launch, and
+  // that launch stays one wave of workgroups up to about `spec_jobs` jobs: with n instances in flight a step hands out
+  // up to spec_jobs / n candidates (at most spec_acc after an accepted evaluation, spec_rej after a round without one);
+  // beyond that, after a rejection only, spec_rej_few while at most spec_few are in flight.  spec_deep caps n for the
+  // candidates after an accepted evaluation.
+  int spec_rej = 4, spec_acc = 4, spec_deep = 32, spec_kmax = 1;
+  int spec_rej_few = 2, spec_jobs = 20;
+  int spec_streak = 4;  // GTO_SPEC_STREAK: first candidate accepted this many rounds in a row -> one candidate after the next accepted evaluation (0: off)
   int obs_deep_max = 32;  // GTO_OBS_DEEP_MAX: ... only up to this many instances in flight (two workgroups per CU: beyond that the five-per-CU variant gets through a launch faster)
   int obs_deep = 1;   // GTO_OBS_DEEP: launches with few instances in flight use the obstacle kernel variant with deep gather batches
-  int spec_few = 32;  // GTO_SPEC_FEW: speculation starts once at most this many instances are in flight: before that the GPU is full and every extra evaluation costs time
+  int spec_few = 64;  // GTO_SPEC_FEW: speculation starts once at most this many instances are in flight: before that the GPU is full and every extra evaluation costs time
   int dbg_cut = 0;
   int dist_relax = 0;  // GTO_DIST_RELAX: build the distance fields by relaxation sweeps instead of the separable passes
   // GTO_OBS_INTERLEAVE: waypoints of an obstacle workgroup nG apart instead of consecutive, so that the waypoints next to
@@ -77,7 +82,7 @@ struct gto_handle {
   int prebroad = 1;  // GTO_PREBROAD=0: every (job, group) gets a workgroup of the obstacle kernel in every round
   double pb_min_gain = 0.10;  // GTO_PB_MIN_GAIN: a call whose step-kernel broad phase settles less than this share of the groups stops running it
   int obs_tg_few = 2;  // ... when few instances are in flight (one small batch, the tail of a call): lower latency per round; results do not depend on the group size
-  int few_instances = 64;
+  int few_instances = 192;
   int step_nw_few = 8;  // GTO_STEP_NW_FEW: wavefronts per workgroup of the step kernel in launches with few instances in flight (4 or 8)
   int obs_tg = 3;  // waypoints per workgroup of the obstacle kernel: they share the table staging, the FK barriers and the launch overhead
   long long* dbg = nullptr;
@@ -220,6 +225,9 @@ int gto_create(const gto_robot_desc* d, const gto_solver_opts* opts, int device,
   h->opts = *opts;
   if (const char* e = getenv("GTO_AHEAD")) h->ahead = h->ahead_few = std::max(1, atoi(e));
   if (const char* e = getenv("GTO_SPEC_REJ")) h->spec_rej = std::max(1, std::min(GTO_KSPEC, atoi(e)));
+  if (const char* e = getenv("GTO_SPEC_REJ_FEW")) h->spec_rej_few = std::max(1, std::min(GTO_KSPEC, atoi(e)));
+  if (const char* e = getenv("GTO_SPEC_STREAK")) h->spec_streak = std::max(0, atoi(e));
+  if (const char* e = getenv("GTO_SPEC_JOBS")) h->spec_jobs = std::max(1, atoi(e));
   if (const char* e = getenv("GTO_SPEC_ACC")) h->spec_acc = std::max(1, std::min(GTO_KSPEC, atoi(e)));
   if (const char* e = getenv("GTO_SPEC_DEEP")) h->spec_deep = std::max(0, atoi(e));
   if (const char* e = getenv("GTO_SPEC_FEW")) h->spec_few = std::max(0, atoi(e));
@@ -923,6 +931,7 @@ static SolveParams make_params(const gto_handle* h, int n_max, bool use_standoff
   sp.round = sp.parity = 0;
   sp.kcap = h->np == GTO_NB ? GTO_KSPEC : 1;  // candidate copies of the workspace (the wide step kernel generates one)
   sp.k_acc = sp.k_rej = sp.k_eval = 1;
+  sp.spec_streak = h->spec_streak;
   return sp;
 }
 
@@ -1179,8 +1188,9 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
     if (h->np == GTO_NB) {
       if (few && h->step_nw_few == 8) {
         // few instances in flight: eight waves per instance and candidate trial points ahead of their evaluation
-        sp.k_rej = in_flight <= h->spec_few ? std::min(h->spec_rej, h->spec_kmax) : 1;
-        sp.k_acc = in_flight <= std::min(h->spec_deep, h->spec_few) ? std::min(h->spec_acc, h->spec_kmax) : 1;
+        const int k_budget = std::max(1, h->spec_jobs / std::max(1, in_flight));
+        sp.k_acc = in_flight <= std::min(h->spec_deep, h->spec_few) ? std::min(std::min(h->spec_acc, k_budget), h->spec_kmax) : 1;
+        sp.k_rej = in_flight <= h->spec_few ? std::min(std::max(std::min(h->spec_rej, k_budget), h->spec_rej_few), h->spec_kmax) : 1;
         const int kl = std::max(sp.k_acc, sp.k_rej);
         sp.pb_next = 0;
         if (h->profiling && (rc = prof_begin(h, st, GTO_PROF_STEP_FEW, in_flight))) { rc_loop = rc; break; }
@@ -1221,6 +1231,10 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
     HIPCHK(h, hipMemcpy(t, h->dbg, sizeof t, hipMemcpyDeviceToHost));
     fprintf(stderr, "[gto dbg] step-kernel phases (cycles) P0+P1 %lld | P2 %lld | diag %lld | dense %lld | back %lld | P4 %lld | P5 %lld | s_dense %lld\n",
             t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3], t[5] - t[4], t[6] - t[5], t[7] - t[6], t[9]);
+    fprintf(stderr, "[gto dbg] solve by wave (cycles from the start of P3): downward sweep: diagonal stretch %lld, its dense blocks %lld | upward sweep %lld | meeting block %lld | back substitution from its start: downward wave dense %lld, diagonal stretch %lld | upward wave %lld\n",
+            t[3] - t[2], t[41] - t[2], t[17] - t[2], t[42] - t[4], t[18] - t[42], t[19] - t[42], t[26] - t[42]);
+    fprintf(stderr, "[gto dbg] sweeps of the other candidates' waves (2..6) done at (cycles from the start of P3, 0 = no candidate): %lld %lld %lld %lld %lld | barrier passed at %lld\n",
+            t[43] ? t[43] - t[2] : 0, t[44] ? t[44] - t[2] : 0, t[45] ? t[45] - t[2] : 0, t[46] ? t[46] - t[2] : 0, t[47] ? t[47] - t[2] : 0, t[4] - t[2]);
     fprintf(stderr, "[gto dbg] broad phase in the step kernel's tail (cycles): entry+tables %lld | barrier %lld | A (local transforms, pass 0) %lld | B (chain) %lld | C (sphere tests) %lld | other passes %lld | outputs %lld\n",
             t[33] - t[6], t[34] - t[33], t[35] - t[34], t[36] - t[35], t[37] - t[36], t[38] - t[37], t[39] - t[38]);
     fprintf(stderr, "[gto dbg] P2 split (cycles): loads+barrier %lld | b-vector+masks %lld | blocks %lld | e,y+barrier %lld\n", t[28] - t[1], t[29] - t[28], t[30] - t[29], t[2] - t[30]);

@@ -353,14 +353,18 @@ def test_step_kernel_broad_phase_other_robots_and_horizons(capi, oracle_mod, mon
                                         ("GTO_OBS_INTERLEAVE", "1"), ("GTO_AHEAD", "1"), ("GTO_AHEAD", "24"),
                                         ("GTO_STEP_NW_FEW", "4"), ("GTO_DIST_RELAX", "1"), ("GTO_FEW_INSTANCES", "0"),
                                         ("GTO_FEW_INSTANCES", "8"), ("GTO_SPEC_REJ", "1"), ("GTO_SPEC_REJ", "2"), ("GTO_SPEC_REJ", "3"),
-                                        ("GTO_SPEC_ACC,GTO_SPEC_DEEP", "4,100000"), ("GTO_SPEC_ACC,GTO_SPEC_DEEP,GTO_SPEC_REJ", "2,100000,1"),
+                                        ("GTO_SPEC_ACC,GTO_SPEC_DEEP,GTO_SPEC_JOBS,GTO_SPEC_STREAK", "4,100000,100000,0"),
+                                        ("GTO_SPEC_ACC,GTO_SPEC_DEEP,GTO_SPEC_REJ,GTO_SPEC_JOBS,GTO_SPEC_STREAK", "2,100000,1,100000,0"),
                                         ("GTO_SPEC_ACC,GTO_SPEC_DEEP,GTO_SPEC_REJ", "1,0,1"), ("GTO_OBS_DEEP", "0"),
-                                        ("GTO_SPEC_FEW,GTO_SPEC_REJ", "100000,4"), ("GTO_SPEC_FEW", "0")])
+                                        ("GTO_SPEC_FEW,GTO_SPEC_REJ,GTO_SPEC_JOBS", "100000,4,100000"), ("GTO_SPEC_FEW", "0"),
+                                        ("GTO_SPEC_STREAK,GTO_SPEC_JOBS", "1,100000"), ("GTO_SPEC_STREAK,GTO_SPEC_JOBS", "0,100000"),
+                                        ("GTO_SPEC_JOBS,GTO_SPEC_REJ_FEW", "1,1"), ("GTO_SPEC_JOBS,GTO_SPEC_REJ_FEW", "48,4")])
 def test_launch_geometry_does_not_change_results(capi, oracle_mod, monkeypatch, knob, value):
     """How the waypoints are dealt to the workgroups of the obstacle kernel (group size, consecutive or interleaved), how
     far the host runs ahead of the GPU, when a call switches to the launches for few instances in flight, and how many
     candidate trial points a step hands out ahead of their evaluation (speculation: after a rejection the next trial point
-    is known; GTO_SPEC_*) are scheduling decisions: every instance gets bit-for-bit the same trajectory, cost and iteration
+    is known; GTO_SPEC_*: per launch by the number of instances in flight, per instance by its run of first-try accepts)
+    are scheduling decisions: every instance gets bit-for-bit the same trajectory, cost and iteration
     count (a (waypoint, link) key is folded by one wave in chunk order, the keys of a waypoint are added up in link order;
     the candidates of a step are walked in the order the sequential algorithm would have met them)."""
     prob = Problem("panda", B=24, scene_seed=5, n_goals=2)
