@@ -2,9 +2,10 @@
 """Per-round listing of solver calls from a rocprofv3 --kernel-trace CSV (rounds mode): for the LAST group of calls that
 overlap in time (the timed region of `bench.py --steps 20`), every round of every queue: start offset, obstacle kernel
 duration, gap, step kernel duration, gap to the next round (us).
-usage: tools/round_trace.py <kernel_trace.csv> [call index from the end, default 0]"""
+usage: [MIN_CALLS=1] tools/round_trace.py <kernel_trace.csv> [call index from the end, default 0]   (MIN_CALLS=1: calls that run alone count as groups)"""
 import collections
 import csv
+import os
 import sys
 
 rows = []
@@ -38,7 +39,7 @@ for c in calls:
     cur.append(c)
 if cur:
     groups.append(cur)
-groups = [g for g in groups if len(g) >= 2 and all(len(c["ev"]) >= 20 for c in g)]
+groups = [g for g in groups if len(g) >= int(os.environ.get("MIN_CALLS", "2")) and all(len(c["ev"]) >= 20 for c in g)]
 which = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 g = groups[-1 - which]
 t0 = min(c["t0"] for c in g)
