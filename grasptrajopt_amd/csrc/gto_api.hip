@@ -60,7 +60,7 @@ struct gto_handle {
   unsigned long long* d_progress = nullptr;  // its device address
   unsigned progress_tag = 0;
   int ahead = 8;           // GTO_AHEAD: rounds the host may enqueue beyond the last one it has seen running
-  int ahead_few = 8;       // GTO_AHEAD_FEW: ... in launches with few instances in flight (short rounds)
+  int ahead_few = 4;       // ... in launches with few instances in flight (short rounds: four of them cover the host's launch time, and every round enqueued beyond the last instance's end runs empty)
   // speculation (gto_kernels.h GTO_KSPEC): candidates a step generates ahead of their evaluation in launches with few
   // instances in flight (more work, fewer dependent rounds).  Every candidate is a job of the next obstacle launch, and
   // that launch stays one wave of workgroups up to about `spec_jobs` jobs: with n instances in flight a step hands out
