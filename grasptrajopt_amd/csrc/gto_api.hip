@@ -953,7 +953,7 @@ static int ensure_workspace(gto_handle* h, int B) {
   if ((rc = ensure(h, h->livebuf, (2 * (1 + kcap) * (size_t)std::min(B, h->slots) + 32) * sizeof(int32_t)))) return rc;
   if ((rc = ensure(h, h->qfs, 2 * (size_t)std::min(B, h->slots) * kcap * T * rb.n_frames * sizeof(double)))) return rc;
   if ((rc = ensure(h, h->wrecbuf, (size_t)(kcap + 1) * B * T * 8 * sizeof(double)))) return rc;
-  if ((rc = ensure(h, h->itembuf, 2 * ((size_t)std::min(B, h->slots) * kcap * (T - 2) + 64) * sizeof(int2)))) return rc;
+  if ((rc = ensure(h, h->itembuf, 2 * ((size_t)std::min(B, h->slots) * kcap * (T - 2) + GTO_ITEM_SLACK) * sizeof(int2)))) return rc;
   if (!h->h_ndone) HIPCHK(h, hipHostMalloc((void**)&h->h_ndone, 64));
   if (!h->h_progress) {
     HIPCHK(h, hipHostMalloc((void**)&h->h_progress, 64, hipHostMallocMapped));
@@ -1041,7 +1041,7 @@ static int launch_obstacle(gto_handle* h, hipStream_t st, const BatchPtrs& bp, c
   const int32_t* jobs_par = listed ? bp.jobs + (size_t)sp.parity * bp.cap * sp.kcap : nullptr;
   const int32_t* njobs_par = listed ? bp.nlive + 2 + sp.parity : nullptr;
   // rounds behind a step kernel that ran the broad phase itself: the regular workgroups are laid out over its list of (job, group) pairs
-  const size_t items_cap = (size_t)bp.cap * sp.kcap * (sp.T - 2) + 64;
+  const size_t items_cap = (size_t)bp.cap * sp.kcap * (sp.T - 2) + GTO_ITEM_SLACK;
   const int2* items_par = listed && itemized ? bp.items + (size_t)sp.parity * items_cap : nullptr;
   const int32_t* nitems_par = listed && itemized ? bp.nlive + 8 + sp.parity : nullptr;
   if (h->np == GTO_NB && deep)  // few instances in flight: the variant that keeps a wave's record gathers in flight together
