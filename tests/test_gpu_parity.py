@@ -293,16 +293,25 @@ def test_slots_hand_over_to_waiting_instances(capi, oracle_mod, monkeypatch, slo
 
 
 @pytest.mark.parametrize("env", [{"GTO_PREBROAD": "0"}, {"GTO_SLOTS": "96"}, {"GTO_SLOTS": "96", "GTO_PREBROAD": "0"},
-                                 {"GTO_OBS_TG": "2"}, {"GTO_OBS_TG": "5"}, {"GTO_FEW_INSTANCES": "16"}, {"GTO_PB_MIN_GAIN": "2"}])
+                                 {"GTO_OBS_TG": "2"}, {"GTO_OBS_TG": "5"}, {"GTO_FEW_INSTANCES": "16"}, {"GTO_PB_MIN_GAIN": "2"},
+                                 {"GTO_SLOTS": "1", "GTO_FEW_INSTANCES": "0", "GTO_OBS_TG": "1"}])
 def test_step_kernel_broad_phase_does_not_change_results(capi, oracle_mod, monkeypatch, env):
     """In the rounds that fill the GPU the step kernel tests the bounding spheres of its new trial trajectory itself
     (prebroad_tail: serial kinematics per lane instead of the obstacle kernel's matrix-core prefix), settles the waypoint
     groups none of whose spheres can reach a non-zero voxel record -- exact zeros either way -- and the obstacle launch is
     laid out over the groups that are left.  Switching that off, refilling positions mid-call (96 positions for 160
-    instances), changing the group size, or switching it off mid-call (GTO_PB_MIN_GAIN=2: after round 12) gives bit-for-bit
+    instances; one position and one waypoint per group: the item list at its shortest against the launch's rounding),
+    changing the group size, or switching it off mid-call (GTO_PB_MIN_GAIN=2: after round 12) gives bit-for-bit
     the same trajectories, costs and iteration counts; and they match the oracle, which culls nothing."""
     prob = Problem("panda_5k", B=160, scene_seed=5, n=64, res=0.035, n_goals=1)
+    # (a call of 160 would run in the launches for few instances from its first round: the broad phase belongs to the others)
+    monkeypatch.setenv("GTO_FEW_INSTANCES", "64")
     h, o = make_pair(capi, oracle_mod, prob, max_iter=40)
+    h.set_profiling(True)
+    ref = h.solve_batch(*prob.solve_args())
+    prof = h.last_kernel_profile()
+    h.set_profiling(False)
+    assert prof["k_lm_step<4,1>"][1] > 10, prof  # launches of the step kernel variant that carries the broad phase: the path under test ran
     ref = h.solve_batch(*prob.solve_args())
     for kn, va in env.items():
         monkeypatch.setenv(kn, va)
@@ -331,6 +340,7 @@ def test_step_kernel_broad_phase_other_robots_and_horizons(capi, oracle_mod, mon
     so = -10 if T >= 30 else -1
     prob = Problem(robot, B=130, scene_seed=4, n=64, res=0.035, n_goals=1, shelf=shelf, T=T)
     opts = lambda: oracle_mod.reference_opts(max_iter=30, T=T, standoff_offset=so)
+    monkeypatch.setenv("GTO_FEW_INSTANCES", "64")  # (130 instances: otherwise few-instance launches throughout, no broad phase in the step kernel)
     h, o = make_pair(capi, oracle_mod, prob, max_iter=30, T=T, standoff_offset=so)
     ref = h.solve_batch(*prob.solve_args())
     monkeypatch.setenv("GTO_PREBROAD", "0")
