@@ -192,8 +192,11 @@ def load_library(path: Optional[str] = None):
     lib.gto_set_stream.argtypes = [H, C.c_void_p]
     lib.gto_set_mode.argtypes = [H, C.c_int32]
     lib.gto_share_scene.argtypes = [H, C.c_int32, H, C.c_int32]
+    if hasattr(lib, "gto_share_scene_halves"):  # (an older build named by GTO_HIP_LIB for an A/B run lacks it)
+        lib.gto_share_scene_halves.argtypes = [H, C.c_int32, H, C.c_int32, C.c_int32, C.c_int32]
+        lib.gto_share_scene_halves.restype = C.c_int
     if hasattr(lib, "gto_scene_from_depth"):  # (an older build named by GTO_HIP_LIB for an A/B run lacks them)
-        lib.gto_scene_from_depth.argtypes = [H, C.c_int32, _pf, C.c_int32, C.c_int32, _pd, _pd, _pd, _pd, C.POINTER(C.c_uint8), C.c_double,
+        lib.gto_scene_from_depth.argtypes = [H, C.c_int32, _pf, C.c_int32, C.c_int32, _pd, _pd, _pd, _pd, C.POINTER(C.c_uint8), _pf, C.c_double,
                                              C.c_double, C.c_double, C.c_float, C.c_float, _pi, _pd, _pd]
         lib.gto_scene_from_depth.restype = C.c_int
         lib.gto_get_scene_fields.argtypes = [H, C.c_int32, _pf, _pf]
@@ -222,8 +225,8 @@ def load_library(path: Optional[str] = None):
 EXPORTED_SYMBOLS = (
     "gto_default_opts", "gto_version", "gto_create", "gto_destroy", "gto_last_error", "gto_set_opts",
     "gto_set_scene", "gto_set_scene_values", "gto_drop_scene", "gto_solve_batch", "gto_solve_batch_device",
-    "gto_last_kernel_time", "gto_last_kernel_work", "gto_last_kernel_profile", "gto_set_profiling", "gto_set_stream", "gto_set_mode", "gto_share_scene", "gto_eval_fk",
-    "gto_eval_points",
+    "gto_last_kernel_time", "gto_last_kernel_work", "gto_last_kernel_profile", "gto_set_profiling", "gto_set_stream", "gto_set_mode", "gto_share_scene", "gto_share_scene_halves",
+    "gto_eval_fk", "gto_eval_points",
     "gto_eval_objective", "gto_eval_obstacle_normal_eq", "gto_plan_cost", "gto_solve_ik_batch", "gto_solve_base_batch",
     "gto_eval_base_objective", "gto_depth_sdf_cost", "gto_scene_from_depth", "gto_get_scene_fields",
 )
@@ -256,6 +259,7 @@ class SolverHandle:
             raise GTOError(f"gto_create failed ({rc}): {msg.decode() if msg else ''}")
         self._h = h
         self.scenes = {}
+        self._scene_gen = {}  # scene id -> number of times it was written (set_scene, scene_from_depth, share_scene, drop_scene)
 
     # -------------------------------------------------------------- helpers
     def _check(self, rc: int, what: str):
@@ -299,13 +303,27 @@ class SolverHandle:
         self._check(fn(self._h, scene_id, _p(ca, _pf), _p(co, _pf), _p(shp, _pi), _p(org, _pd), float(res)),
                     "gto_set_scene_values" if values_only else "gto_set_scene")
         self.scenes[scene_id] = (tuple(int(s) for s in shp), org.copy(), float(res))
+        self._bump(scene_id)
+
+    def _bump(self, scene_id: int):
+        """A scene of this handle was written: handles that borrowed it (share_scene) hold pointers into buffers that are
+        gone.  Borrowers remember the generation they shared and share again when it has moved (scene_generation)."""
+        self._scene_gen[int(scene_id)] = self._scene_gen.get(int(scene_id), 0) + 1
+
+    def scene_generation(self, scene_id: int) -> int:
+        return self._scene_gen.get(int(scene_id), 0)
 
     def scene_from_depth(self, scene_id: int, depth, K, cam_pose, target_mask=None, threshold=1.5, grid_res=0.05, margin=0.4,
-                         epsilon=0.02, w_inside=1.0):
+                         epsilon=0.02, w_inside=1.0, depth_obstacle=None):
         """gto_scene_from_depth: depth image -> both cost fields resident as scene `scene_id` (voxel records and distance
-        fields included); returns (shape, origin, bounds (3, 2)) of the grid, nothing else leaves the device."""
+        fields included); returns (shape, origin, bounds (3, 2)) of the grid, nothing else leaves the device.
+        depth_obstacle: the image of the second cloud (the driver's copy with the target's pixels at the threshold,
+        examples/pybullet_gto_planning.py:187-189); None: the same image."""
         depth = np.ascontiguousarray(depth, dtype=np.float32)
         Hh, Ww = depth.shape
+        dobs = None if depth_obstacle is None else np.ascontiguousarray(depth_obstacle, dtype=np.float32)
+        if dobs is not None and dobs.shape != depth.shape:
+            raise ValueError("depth_obstacle must have the shape of depth")
         K = _f64(K).reshape(3, 3)
         cam = _f64(cam_pose).reshape(4, 4)
         Kinv, cinv = np.ascontiguousarray(np.linalg.inv(K)), np.ascontiguousarray(np.linalg.inv(cam))
@@ -313,9 +331,10 @@ class SolverHandle:
         shp, org, bnd = np.zeros(3, np.int32), np.zeros(3), np.zeros(6)
         pu8 = C.POINTER(C.c_uint8)
         self._check(self.lib.gto_scene_from_depth(self._h, scene_id, _p(depth, _pf), Hh, Ww, _p(K, _pd), _p(Kinv, _pd), _p(cam, _pd), _p(cinv, _pd),
-                                                  None if mask is None else mask.ctypes.data_as(pu8), float(threshold), float(grid_res), float(margin),
+                                                  None if mask is None else mask.ctypes.data_as(pu8), _p(dobs, _pf), float(threshold), float(grid_res), float(margin),
                                                   float(epsilon), float(w_inside), _p(shp, _pi), _p(org, _pd), _p(bnd, _pd)), "gto_scene_from_depth")
         self.scenes[scene_id] = (tuple(int(x) for x in shp), org.copy(), float(grid_res))
+        self._bump(scene_id)
         return tuple(int(x) for x in shp), org, np.stack((bnd[:3], bnd[3:]), axis=1)
 
     def scene_fields(self, scene_id: int):
@@ -329,6 +348,7 @@ class SolverHandle:
     def drop_scene(self, scene_id: int):
         self._check(self.lib.gto_drop_scene(self._h, scene_id), "gto_drop_scene")
         self.scenes.pop(scene_id, None)
+        self._bump(scene_id)
 
     # -------------------------------------------------------------- solve
     def solve_batch(self, scene_id, qc, goals, n_goals, standoff, base_pos, Q0, out=None):
@@ -375,12 +395,18 @@ class SolverHandle:
                                              vp(cost_out), vp(iters_out), vp(status_out), vp(stream))
         self._check(rc, "gto_solve_batch_device")
 
-    def share_scene(self, scene_id, src: "SolverHandle", src_scene_id=None):
-        """Use a scene that lives in another handle on the same GPU without a second copy."""
+    def share_scene(self, scene_id, src: "SolverHandle", src_scene_id=None, all_from: int = 0, obs_from: int = 1):
+        """Use a scene that lives in another handle on the same GPU without a second copy.  all_from / obs_from: which of
+        the source's two fields (0: sdf_cost_all, 1: sdf_cost_obstacle) this handle sees as its sdf_cost_all / sdf_cost_obstacle
+        (gto_share_scene_halves)."""
         src_id = int(scene_id if src_scene_id is None else src_scene_id)
-        self._check(self.lib.gto_share_scene(self._h, int(scene_id), src._h, src_id), "gto_share_scene")
+        if (all_from, obs_from) == (0, 1):
+            self._check(self.lib.gto_share_scene(self._h, int(scene_id), src._h, src_id), "gto_share_scene")
+        else:
+            self._check(self.lib.gto_share_scene_halves(self._h, int(scene_id), src._h, src_id, int(all_from), int(obs_from)), "gto_share_scene_halves")
         if src_id in src.scenes:
             self.scenes[int(scene_id)] = src.scenes[src_id]
+        self._bump(scene_id)
 
     def set_stream(self, stream):
         """Bind every launch/copy of this handle to the caller's HIP stream (an int such as

@@ -680,7 +680,12 @@ static int free_scene(gto_handle* h, SceneDev& s) {
 }
 
 int gto_share_scene(gto_handle* dst, int32_t dst_id, gto_handle* src, int32_t src_id) {
+  return gto_share_scene_halves(dst, dst_id, src, src_id, 0, 1);
+}
+
+int gto_share_scene_halves(gto_handle* dst, int32_t dst_id, gto_handle* src, int32_t src_id, int32_t all_from, int32_t obs_from) {
   if (!dst || !src) return GTO_ERR_INVALID_ARG;
+  if ((all_from != 0 && all_from != 1) || (obs_from != 0 && obs_from != 1)) return fail(dst, GTO_ERR_INVALID_ARG, "gto_share_scene_halves: a half is 0 (c_all) or 1 (c_obs)");
   if (dst_id < 0 || dst_id >= 65536) return fail(dst, GTO_ERR_INVALID_ARG, "scene_id out of range [0,65536)");
   if (src_id < 0 || (size_t)src_id >= src->scenes.size() || !src->scenes[src_id].valid)
     return fail(dst, GTO_ERR_NO_SCENE, "gto_share_scene: the source scene was never set");
@@ -694,8 +699,12 @@ int gto_share_scene(gto_handle* dst, int32_t dst_id, gto_handle* src, int32_t sr
   }
   int rcf = free_scene(dst, dst->scenes[dst_id]);
   if (rcf) return rcf;
-  dst->scenes[dst_id] = src->scenes[src_id];
-  dst->scenes[dst_id].valid = 2;
+  const SceneDev& ss = src->scenes[src_id];
+  SceneDev& ds = dst->scenes[dst_id];
+  ds = ss;
+  ds.c_all = all_from ? ss.c_obs : ss.c_all, ds.r_all = all_from ? ss.r_obs : ss.r_all, ds.d_all = all_from ? ss.d_obs : ss.d_all;
+  ds.c_obs = obs_from ? ss.c_obs : ss.c_all, ds.r_obs = obs_from ? ss.r_obs : ss.r_all, ds.d_obs = obs_from ? ss.d_obs : ss.d_all;
+  ds.valid = 2;
   return sync_scene_table(dst);
 }
 
@@ -1895,8 +1904,8 @@ static std::vector<double> np_arange(double start, double stop, double step) {
  * `scene_id` with their voxel records and distance fields, device to device. */
 int gto_scene_from_depth(gto_handle* h, int32_t scene_id, const float* depth, int32_t H, int32_t W, const double* K,
                          const double* Kinv, const double* cam_pose, const double* cam_inv, const uint8_t* target_mask,
-                         double threshold, double grid_res, double margin, float epsilon, float w_inside,
-                         int32_t* shape_out, double* origin_out, double* bounds_out) {
+                         const float* depth_obstacle, double threshold, double grid_res, double margin, float epsilon,
+                         float w_inside, int32_t* shape_out, double* origin_out, double* bounds_out) {
   if (!h) return GTO_ERR_INVALID_ARG;
   if (!depth || !K || !Kinv || !cam_pose || !cam_inv || H < 1 || W < 1 || !(grid_res > 0) || !(margin >= 0))
     return fail(h, GTO_ERR_INVALID_ARG, "gto_scene_from_depth: null or empty input");
@@ -1935,25 +1944,29 @@ int gto_scene_from_depth(gto_handle* h, int32_t scene_id, const float* depth, in
       return fail(h, GTO_ERR_ALLOC, "gto_scene_from_depth: device allocation failed");               \
     }                                                                                                \
   } while (0)
-  const bool two = target_mask != nullptr;
+  // the second cloud: the obstacle image (the driver's depth_obstacle, examples/pybullet_gto_planning.py:187-189: the target's
+  // pixels pushed to the threshold) without the masked pixels; its visibility test reads the obstacle image
+  const bool two = target_mask != nullptr || depth_obstacle != nullptr;
   float* d_depth = (float*)dalloc(N * sizeof(float));
+  float* d_depth_o = depth_obstacle ? (float*)dalloc(N * sizeof(float)) : d_depth;
   double* d_mats = (double*)dalloc((9 + 9 + 16 + 16 + 8) * sizeof(double));
-  uint8_t* d_mask = two ? (uint8_t*)dalloc(N) : nullptr;
+  uint8_t* d_mask = target_mask ? (uint8_t*)dalloc(N) : nullptr;
   double* d_pa = (double*)dalloc(3 * N * sizeof(double));
   double* d_po = two ? (double*)dalloc(3 * N * sizeof(double)) : d_pa;
   uint8_t* d_valid = (uint8_t*)dalloc(N);
   double* d_boxa = (double*)dalloc((size_t)(2 * P * P) * 6 * sizeof(double));
   double* d_boxo = two ? (double*)dalloc((size_t)(2 * P * P) * 6 * sizeof(double)) : d_boxa;
-  DNULL(d_depth); DNULL(d_mats); DNULL(d_pa); DNULL(d_po); DNULL(d_valid); DNULL(d_boxa); DNULL(d_boxo);
-  if (two) DNULL(d_mask);
+  DNULL(d_depth); DNULL(d_depth_o); DNULL(d_mats); DNULL(d_pa); DNULL(d_po); DNULL(d_valid); DNULL(d_boxa); DNULL(d_boxo);
+  if (target_mask) DNULL(d_mask);
   double mats[50];
   std::memcpy(mats, K, 9 * sizeof(double));
   std::memcpy(mats + 9, Kinv, 9 * sizeof(double));
   std::memcpy(mats + 18, cam_pose, 16 * sizeof(double));
   std::memcpy(mats + 34, cam_inv, 16 * sizeof(double));
   DCHK(hipMemcpy(d_depth, depth, N * sizeof(float), hipMemcpyHostToDevice));
+  if (depth_obstacle) DCHK(hipMemcpy(d_depth_o, depth_obstacle, N * sizeof(float), hipMemcpyHostToDevice));
   DCHK(hipMemcpy(d_mats, mats, sizeof mats, hipMemcpyHostToDevice));
-  if (two) DCHK(hipMemcpy(d_mask, target_mask, N, hipMemcpyHostToDevice));
+  if (target_mask) DCHK(hipMemcpy(d_mask, target_mask, N, hipMemcpyHostToDevice));
   t_[1] = t_now();
   const unsigned nbN = (unsigned)((N + 255) / 256);
   hipLaunchKernelGGL(k_depth_backproject, dim3(nbN), dim3(256), 0, 0, d_depth, H, W, d_mats + 9, d_mats + 18, (const uint8_t*)nullptr, threshold,
@@ -1962,7 +1975,7 @@ int gto_scene_from_depth(gto_handle* h, int32_t scene_id, const float* depth, in
   hipLaunchKernelGGL(k_bvh_leaves, dim3((unsigned)((P * P + 255) / 256)), dim3(256), 0, 0, d_pa, d_pa + N, d_pa + 2 * N, H, W, P, d_boxa);
   if (P > 1) hipLaunchKernelGGL(k_bvh_up, dim3(1), dim3(1024), 0, 0, P, d_boxa);
   if (two) {
-    hipLaunchKernelGGL(k_depth_backproject, dim3(nbN), dim3(256), 0, 0, d_depth, H, W, d_mats + 9, d_mats + 18, (const uint8_t*)d_mask, threshold,
+    hipLaunchKernelGGL(k_depth_backproject, dim3(nbN), dim3(256), 0, 0, d_depth_o, H, W, d_mats + 9, d_mats + 18, (const uint8_t*)d_mask, threshold,
                        d_po, d_po + N, d_po + 2 * N, d_valid);
     hipLaunchKernelGGL(k_bvh_leaves, dim3((unsigned)((P * P + 255) / 256)), dim3(256), 0, 0, d_po, d_po + N, d_po + 2 * N, H, W, P, d_boxo);
     if (P > 1) hipLaunchKernelGGL(k_bvh_up, dim3(1), dim3(1024), 0, 0, P, d_boxo);
@@ -2037,7 +2050,7 @@ int gto_scene_from_depth(gto_handle* h, int32_t scene_id, const float* depth, in
   hipLaunchKernelGGL(k_depth_sdf_bvh, dim3(nbq), dim3(256), 0, sa, d_pa, d_pa + N, d_pa + 2 * N, d_boxa, P, d_idx2, d_depth, H, W, d_mats, d_mats + 34,
                      d_q, (long)nq, epsilon, w_inside, (float*)nullptr, d_in, d_costa, d_stats, 1);
   if (two)
-    hipLaunchKernelGGL(k_depth_sdf_bvh, dim3(nbq), dim3(256), 0, sb, d_po, d_po + N, d_po + 2 * N, d_boxo, P, d_idx2, d_depth, H, W, d_mats, d_mats + 34,
+    hipLaunchKernelGGL(k_depth_sdf_bvh, dim3(nbq), dim3(256), 0, sb, d_po, d_po + N, d_po + 2 * N, d_boxo, P, d_idx2, d_depth_o, H, W, d_mats, d_mats + 34,
                        d_q, (long)nq, epsilon, w_inside, (float*)nullptr, d_in2, d_costo, (unsigned long long*)nullptr, 1);
   DCHK(hipGetLastError());
   DCHK(hipDeviceSynchronize());

@@ -82,7 +82,7 @@ class DepthPointCloud:
         """:64-91 — float32 costs (``vis`` is ignored: no viewer here).  Asked at the voxel centres of a grid that was sized
         from a depth cloud (``robot.workspace_points`` still lazy), the answer stays on the device (depth_scene.py)."""
         if isinstance(query_points, LazyWorkspacePoints):
-            return LazyCostField(self, query_points.robot, epsilon, w_inside)
+            return LazyCostField(self, query_points.robot, epsilon, w_inside, grid_dpc=query_points.grid_dpc)
         return self._run(query_points, epsilon, w_inside)[2]
 
     def get_sdf_in_batches(self, query_points, batch_size=1000000):

@@ -1,24 +1,35 @@
 """Device-resident per-object perception (SURVEY.md 8 rows f-2 / f-3 / a1 together).
 
-The reference's driver (examples/pybullet_gto_planning.py:176-190) builds two ``DepthPointCloud`` objects from one depth
-image, sizes the grid from the first one's points and asks each for its cost field at the grid's voxel centres; the two
-fields then travel into ``IKSolver.solve_ik`` and ``GTOPlanner.plan_goalset``.  Through the same calls, this module keeps
-everything on the GPU: ``DepthPointCloud.points``, ``GTORobotModel.workspace_points`` and ``get_sdf_cost(...)`` hand out
-lazy stand-ins; the first consumer that needs a scene makes ONE ``gto_scene_from_depth`` call (image up once, both
-fields, voxel records and distance fields resident) and every solver handle shares that scene.  A stand-in turns into the
-numpy array the reference would have returned the moment anything treats it as one (``np.asarray``, arithmetic,
-indexing), so code outside this package sees no difference but the time.
+The reference's driver (examples/pybullet_gto_planning.py:176-190) builds two ``DepthPointCloud`` objects: one from the
+depth image (all pixels), which also sizes the grid, and one from ``depth_obstacle`` (a copy of the image with the
+target's pixels pushed to the threshold) with the target's mask; it asks each for its cost field at the grid's voxel
+centres, and the two fields then travel into ``IKSolver.solve_ik`` and ``GTOPlanner.plan_goalset``.  Through the same
+calls, this module keeps everything on the GPU: ``DepthPointCloud.points``, ``GTORobotModel.workspace_points`` and
+``get_sdf_cost(...)`` hand out lazy stand-ins; the first consumer that needs a scene makes ONE ``gto_scene_from_depth``
+call (both images up once, both fields, voxel records and distance fields resident) and every solver handle shares that
+scene, each reading the half (or halves) it was handed.  A stand-in turns into the numpy array the reference would have
+returned the moment anything treats it as one (``np.asarray``, arithmetic, comparison, indexing, assignment), so code
+outside this package sees no difference but the time.
 """
 from __future__ import annotations
 
+from collections import namedtuple
+
 import numpy as np
+from numpy.lib.mixins import NDArrayOperatorsMixin
 
 DEPTH_SCENE = 2  # scene id of the resident depth scene on the robot model's utility handle (0: a solver's own, 1: scratch)
 
+# where a lazy cost field lives: scene `sid` of `handle`, as field number `half` (0: sdf_cost_all, 1: sdf_cost_obstacle) of the
+# build number `gen` of that scene (a later build of the scene moves the generation: borrowed copies are stale then)
+Resident = namedtuple("Resident", "handle sid half gen")
 
-class _LazyArray:
-    """Base of the stand-ins: behaves as the array it stands for once anybody looks."""
+
+class _LazyArray(NDArrayOperatorsMixin):
+    """Base of the stand-ins: behaves as the array it stands for once anybody looks.  Operators (``lazy * 2``, ``-lazy``,
+    ``lazy < 0``) and ufuncs go through ``__array_ufunc__`` and return plain arrays of the materialised value."""
     _value = None
+    __array_priority__ = 100.0
 
     def _materialize(self):
         raise NotImplementedError
@@ -28,6 +39,12 @@ class _LazyArray:
             self._value = self._materialize()
         return self._value if dtype is None else self._value.astype(dtype, copy=False)
 
+    def __array_ufunc__(self, ufunc, method, *inputs, **kwargs):
+        inputs = tuple(x.__array__() if isinstance(x, _LazyArray) else x for x in inputs)
+        if "out" in kwargs:
+            kwargs["out"] = tuple(x.__array__() if isinstance(x, _LazyArray) else x for x in kwargs["out"])
+        return getattr(ufunc, method)(*inputs, **kwargs)
+
     def __getattr__(self, name):  # shape, dtype, min, reshape, ...: whatever the real array has
         if name.startswith("_"):
             raise AttributeError(name)
@@ -35,6 +52,13 @@ class _LazyArray:
 
     def __getitem__(self, k):
         return self.__array__()[k]
+
+    def __setitem__(self, k, v):  # (an edited field is an array of the caller's from then on: it no longer names a resident scene)
+        self.__array__()[k] = v
+        self._edited = True
+
+    def __iter__(self):
+        return iter(self.__array__())
 
     def __len__(self):
         return len(self.__array__())
@@ -55,6 +79,7 @@ class LazyWorkspacePoints(_LazyArray):
 
     def __init__(self, robot):
         self.robot = robot
+        self.grid_dpc = robot.__dict__.get("_pending_depth")  # the cloud this grid is sized from
 
     def _materialize(self):
         self.robot._resolve_depth_field()
@@ -63,20 +88,64 @@ class LazyWorkspacePoints(_LazyArray):
 
 class LazyCostField(_LazyArray):
     """``DepthPointCloud.get_sdf_cost(robot.workspace_points)``: a float32 cost per voxel, resident in a scene."""
+    _edited = False
 
-    def __init__(self, dpc, robot, epsilon, w_inside):
+    def __init__(self, dpc, robot, epsilon, w_inside, grid_dpc=None):
         self.dpc, self.robot, self.epsilon, self.w_inside = dpc, robot, float(epsilon), float(w_inside)
+        self.grid_dpc = grid_dpc if grid_dpc is not None else robot.__dict__.get("_pending_depth")
+
+    def resident(self):
+        """Where this field lives on the device (`Resident`), building the scene on first use: the grid's cloud (all
+        pixels) gives the first field, this field's cloud the second, in ONE gto_scene_from_depth call.  None if the field
+        cannot be kept resident (another camera than the grid's cloud, an edited array): the caller then takes the array."""
+        if self._edited or self.grid_dpc is None:
+            return None
+        return self.robot._depth_scene_for(self.dpc, self.epsilon, self.w_inside, self.grid_dpc)
 
     def ensure_scene(self):
-        """(handle, scene id) of the resident scene that holds this field: built on first use from this cloud's image and
-        mask (the cloud of all pixels is the same image without the mask, so one build serves both fields)."""
-        return self.robot._depth_scene_for(self.dpc, self.epsilon, self.w_inside)
+        """(handle, scene id) of the resident scene that holds this field (see `resident` for which half)."""
+        r = self.resident()
+        if r is None:
+            raise RuntimeError("this cost field is not resident on the device")
+        return r.handle, r.sid
 
     def _materialize(self):
-        h, sid = self.ensure_scene()
-        c_all, c_obs = h.scene_fields(sid)
-        return c_all if self.dpc.target_mask is None else c_obs
+        r = self.resident()
+        if r is None:  # the host path: the field as the reference computes it, at the grid's voxel centres
+            self.robot._resolve_depth_field()
+            return self.dpc._run(self.robot._workspace_points_now(), self.epsilon, self.w_inside)[2]
+        c_all, c_obs = r.handle.scene_fields(r.sid)
+        return c_obs if r.half else c_all
+
+
+def resident_of(field):
+    """`Resident` of a cost field argument, or None for anything that is not a resident lazy field."""
+    return field.resident() if isinstance(field, LazyCostField) else None
 
 
 def same_image(a, b) -> bool:
-    return a is b or (a.shape == b.shape and np.array_equal(a, b))
+    return a is b or (a is not None and b is not None and a.shape == b.shape and np.array_equal(a, b))
+
+
+class CloudSnapshot:
+    """What a resident scene was built from: copies of a DepthPointCloud's inputs (the caller may edit its arrays in
+    place afterwards; the comparison is by value)."""
+
+    def __init__(self, dpc):
+        self.depth = np.array(dpc.depth, copy=True)
+        self.mask = None if dpc.target_mask is None else np.array(dpc.target_mask, copy=True)
+        self.K = np.array(dpc.intrinsic_matrix, copy=True)
+        self.cam = np.array(dpc.camera_pose, copy=True)
+        self.threshold = float(dpc.threshold)
+
+    def matches(self, dpc) -> bool:
+        return (self.threshold == float(dpc.threshold) and same_camera(self, dpc) and same_image(self.depth, dpc.depth) and
+                ((self.mask is None) == (dpc.target_mask is None)) and (self.mask is None or same_image(self.mask, dpc.target_mask)))
+
+
+def same_camera(a, b) -> bool:
+    ka, ca = (a.K, a.cam) if isinstance(a, CloudSnapshot) else (a.intrinsic_matrix, a.camera_pose)
+    kb, cb = (b.K, b.cam) if isinstance(b, CloudSnapshot) else (b.intrinsic_matrix, b.camera_pose)
+    da = a.depth.shape
+    db = b.depth.shape
+    return da == db and np.array_equal(ka, kb) and np.array_equal(ca, cb)

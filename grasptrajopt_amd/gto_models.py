@@ -160,6 +160,7 @@ class GTORobotModel:
 
     # ------------------------------------------------------------------ voxel grid (gto/gto_models.py:135-201)
     def _setup_field(self, lo, hi):
+        self._pending_depth = None  # a grid given as numbers: no depth cloud is waiting to size one
         m, r = self.field_margin, self.grid_resolution
         self.origin = np.array([lo[0] - m, lo[1] - m, lo[2] - m]).reshape((1, 3))
         axes = [np.arange(lo[a] - m, hi[a] + m, r) for a in range(3)]
@@ -176,14 +177,14 @@ class GTORobotModel:
 
     def setup_points_field(self, points):
         from .depth_scene import LazyCloudPoints
-        if isinstance(points, LazyCloudPoints):
+        if isinstance(points, LazyCloudPoints) and points.dpc.target_mask is None:
             # the cloud is still on the device: the grid is sized there, when the first consumer needs a scene
-            # (depth_scene.py); until then the geometry attributes are pending
+            # (depth_scene.py); until then the geometry attributes are pending.  (The resident build sizes the grid from the
+            # cloud of ALL pixels, as the driver does: a masked cloud takes the host path below.)
             for a in self._FIELD_ATTRS:
                 self.__dict__.pop(a, None)
             self._pending_depth = points.dpc
             return
-        self._pending_depth = None
         points = np.asarray(points)
         self.workspace_bounds = np.stack((points.min(0), points.max(0)), axis=1)
         self._setup_field(self.workspace_bounds[:, 0], self.workspace_bounds[:, 1])
@@ -202,7 +203,10 @@ class GTORobotModel:
         """Geometry of the pending depth grid: from the resident scene if a consumer has built one, else by building it
         from the cloud of all pixels."""
         if "field_shape" not in self.__dict__:
-            self._depth_scene_for(self._pending_depth, 0.02, 1.0)
+            pend = self.__dict__.get("_pending_depth")
+            if pend is None:
+                raise RuntimeError("call setup_points_field() or setup_workspace_field() first")
+            self._depth_scene_for(pend, 0.02, 1.0, pend)
 
     def _workspace_points_now(self):
         """The voxel centres as gto/gto_models.py:159-165 lays them out, from the resident grid's geometry."""
@@ -211,26 +215,44 @@ class GTORobotModel:
         axes = [np.arange(lo[a] - m, hi[a] + m, r) for a in range(3)]
         return np.array(np.meshgrid(*axes, indexing="ij")).reshape((3, -1)).T
 
-    def _depth_scene_for(self, dpc, epsilon, w_inside):
-        """(handle, scene id) of the resident scene built from `dpc`'s depth image: one gto_scene_from_depth call per image
-        (both cost fields; the field of all pixels does not depend on the mask), shared by every solver handle."""
-        from .depth_scene import DEPTH_SCENE, same_image
+    def _depth_scene_for(self, dpc, epsilon, w_inside, grid_dpc=None):
+        """Where the cost field of cloud `dpc` on the grid sized from cloud `grid_dpc` lives on the device: a
+        depth_scene.Resident (handle, scene id, half, generation), or None if it cannot be resident.
+
+        The resident scene is what the driver builds per object (examples/pybullet_gto_planning.py:176-190): field 0 =
+        the cost field of the grid's cloud (all pixels of the depth image), field 1 = the cost field of a second cloud
+        (the obstacle image with the target's mask) on the same grid, ONE gto_scene_from_depth call for both.  It is keyed by
+        value on both clouds' inputs: a field is only ever served from the build it belongs to (its own image, mask and
+        threshold; the grid it was asked on), as the half it is."""
+        from .depth_scene import DEPTH_SCENE, CloudSnapshot, Resident, same_camera
+        grid = grid_dpc if grid_dpc is not None else dpc
+        if grid.target_mask is not None:
+            return None  # (setup_points_field never leaves a masked cloud pending)
         h = self._util_handle()
-        key = (float(self.grid_resolution), float(self.field_margin), float(epsilon), float(w_inside), float(dpc.threshold))
+        key = (float(self.grid_resolution), float(self.field_margin), float(epsilon), float(w_inside))
         c = self.__dict__.get("_depth_scene")
-        if c is not None and c["key"] == key and same_image(c["depth"], dpc.depth) and np.array_equal(c["K"], dpc.intrinsic_matrix) and \
-                np.array_equal(c["cam"], dpc.camera_pose) and (dpc.target_mask is None or (c["mask"] is not None and same_image(c["mask"], dpc.target_mask))):
-            return h, DEPTH_SCENE
-        shape, origin, bounds = h.scene_from_depth(DEPTH_SCENE, dpc.depth, dpc.intrinsic_matrix, dpc.camera_pose, dpc.target_mask,
-                                                   dpc.threshold, self.grid_resolution, self.field_margin, epsilon, w_inside)
-        self._depth_scene = {"key": key, "depth": dpc.depth, "K": dpc.intrinsic_matrix, "cam": dpc.camera_pose, "mask": dpc.target_mask}
+        cache_ok = c is not None and c["key"] == key and c["grid"].matches(grid) and c["gen"] == h.scene_generation(DEPTH_SCENE)
+        if cache_ok and c["grid"].matches(dpc):
+            return Resident(h, DEPTH_SCENE, 0, c["gen"])
+        if cache_ok and c["obs"] is not None and c["obs"].matches(dpc):
+            return Resident(h, DEPTH_SCENE, 1, c["gen"])
+        is_grid_cloud = dpc is grid or CloudSnapshot(grid).matches(dpc)
+        if not is_grid_cloud and not (same_camera(grid, dpc) and float(grid.threshold) == float(dpc.threshold)):
+            return None  # another camera or cut-off than the grid's cloud: one call cannot serve both; the host path does
+        obs = None if is_grid_cloud else dpc
+        shape, origin, bounds = h.scene_from_depth(
+            DEPTH_SCENE, grid.depth, grid.intrinsic_matrix, grid.camera_pose, None if obs is None else obs.target_mask, grid.threshold,
+            self.grid_resolution, self.field_margin, epsilon, w_inside,
+            depth_obstacle=None if obs is None or obs.depth is grid.depth else obs.depth)
+        self._depth_scene = {"key": key, "grid": CloudSnapshot(grid), "obs": None if obs is None else CloudSnapshot(obs),
+                             "gen": h.scene_generation(DEPTH_SCENE)}
         pend = self.__dict__.get("_pending_depth")
-        if pend is not None and same_image(pend.depth, dpc.depth):  # this IS the grid setup_points_field was asked for
+        if pend is not None and (pend is grid or self._depth_scene["grid"].matches(pend)):  # this IS the grid setup_points_field was asked for
             self.workspace_bounds = bounds
             self.origin = np.asarray(origin, dtype=np.float64).reshape((1, 3))
             self.field_shape = tuple(int(x) for x in shape)
             self.field_size = int(np.prod(shape))
-        return h, DEPTH_SCENE
+        return Resident(h, DEPTH_SCENE, 0 if obs is None else 1, self._depth_scene["gen"])
 
     def field_geometry(self):
         if not hasattr(self, "field_shape"):
@@ -289,15 +311,16 @@ class GTORobotModel:
         if plan.shape[1] != h.T:
             raise NotImplementedError(f"plans must have T={h.T} waypoints on this handle")
         sid = self.SCRATCH_SCENE
-        if hasattr(sdf_cost_obstacle, "ensure_scene"):  # resident on the device (depth_scene.py)
-            src, ssid = sdf_cost_obstacle.ensure_scene()
-            if src is h:
-                sid = ssid
+        from .depth_scene import resident_of
+        r = resident_of(sdf_cost_obstacle)
+        if r is not None:  # resident on the device (depth_scene.py): the half this field is serves as the obstacle field
+            if r.handle is h and r.half == 1:
+                sid = r.sid
             else:
-                h.share_scene(sid, src, ssid)
+                h.share_scene(sid, r.handle, r.sid, all_from=r.half, obs_from=r.half)
         else:
             shape, origin, res = self.field_geometry()
-            h.set_scene(sid, sdf_cost_obstacle, None, shape, origin, res, values_only=True)  # scored, never solved on
+            h.set_scene(sid, np.asarray(sdf_cost_obstacle), None, shape, origin, res, values_only=True)  # scored, never solved on
         cost, dist = h.plan_cost(sid, plan[None], base_position)
         return float(cost[0]), float(dist[0])
 

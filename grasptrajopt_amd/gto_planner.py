@@ -55,8 +55,8 @@ class GTOPlanner:
     def plan(self, qc, RT, sdf_cost_obstacle, base_position, q_solution=None, use_standoff=True, axis_standoff="x"):
         """gto/gto_planner.py:145-182.  As in the reference, ``sdf_cost_all`` is not passed here and
         therefore defaults to zeros for the waypoints before the standoff."""
-        if hasattr(sdf_cost_obstacle, "ensure_scene"):
-            sdf_cost_obstacle.ensure_scene()
+        if hasattr(sdf_cost_obstacle, "resident"):  # a field that is resident on the device: its scene (and with it the grid
+            sdf_cost_obstacle.resident()          # geometry the problem is sized by) before anything else
         self.setup_optimization(goal_size=1, use_standoff=use_standoff, axis_standoff=axis_standoff)
         qc = np.asarray(qc, dtype=np.float64)
         tf_goal = np.zeros((16, 1))
@@ -77,8 +77,8 @@ class GTOPlanner:
                      use_standoff=True, axis_standoff="x", interpolate=True):
         """gto/gto_planner.py:185-245."""
         for fld in (sdf_cost_obstacle, sdf_cost_all):  # fields that are resident on the device: their scene (and with it the
-            if hasattr(fld, "ensure_scene"):           # grid geometry the problem is sized by) before anything else
-                fld.ensure_scene()
+            if hasattr(fld, "resident"):               # grid geometry the problem is sized by) before anything else; the
+                fld.resident()                         # obstacle field first: its build holds both fields
         RTs = np.asarray(RTs, dtype=np.float64)
         qc = np.asarray(qc, dtype=np.float64)
         n = RTs.shape[0]

@@ -44,12 +44,15 @@ class IKSolver:
             if sdf_cost_obstacle is None:
                 raise ValueError("collision_avoidance=True needs sdf_cost_obstacle")
             sid = 0  # the IK solver owns its handle
-            if hasattr(sdf_cost_obstacle, "ensure_scene"):  # resident on the device (depth_scene.py): shared, not uploaded
-                src, ssid = sdf_cost_obstacle.ensure_scene()
-                h.share_scene(sid, src, ssid)
+            from .depth_scene import resident_of
+            r = resident_of(sdf_cost_obstacle)
+            if r is not None:  # resident on the device (depth_scene.py): shared, not uploaded; whichever half of its scene the
+                # field is, it is what this solver reads as the obstacle field (shared again on every call: a later build of
+                # the resident scene leaves no stale pointer behind)
+                h.share_scene(sid, r.handle, r.sid, all_from=r.half, obs_from=r.half)
             else:
                 shape, origin, res = self.robot.field_geometry()
-                h.set_scene(sid, sdf_cost_obstacle, None, shape, origin, res)
+                h.set_scene(sid, np.asarray(sdf_cost_obstacle), None, shape, origin, res)
         q, f, iters, status = h.solve_ik_batch(sid, q_0, RTs.reshape(B, 16), base, self.max_iter)
         # errors as the reference reports them (gto/ik_solver.py:88-93)
         tf = h.eval_fk(q)[:, self._fe]

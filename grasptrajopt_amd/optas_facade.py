@@ -252,22 +252,26 @@ class CasADiSolver(Solver):
         # the handle (and its scene 0) is shared by every solver with the same role / links / T on this robot model: another
         # planner's upload replaces the field under this solver, so "already uploaded" is only true while this solver was the
         # last one to write the scene
-        if getattr(self, "_scene_dirty", True) or getattr(self._handle, "_scene0_owner", None) is not self:
-            from .depth_scene import LazyCostField
-            robot, p = self.opt.robot, self._p_dict
-            la, lo = p.get("sdf_cost_all"), p.get("sdf_cost_obstacle")
-            if isinstance(la, LazyCostField) and isinstance(lo, LazyCostField) and la.dpc.target_mask is None and \
-                    la.ensure_scene() == lo.ensure_scene():
-                # both fields are the two halves of one resident depth scene: the solver's scene becomes that scene (no copy,
-                # nothing through the host)
-                src, sid = lo.ensure_scene()
-                self._handle.share_scene(self.SCENE_ID, src, sid)
+        from .depth_scene import resident_of
+        p = self._p_dict
+        la, lo = p.get("sdf_cost_all"), p.get("sdf_cost_obstacle")
+        shared = getattr(self, "_shared_from", None)  # (handle, scene id, generation) of the resident scene this solver borrows
+        stale = shared is not None and shared[0].scene_generation(shared[1]) != shared[2]  # rebuilt since: the borrowed pointers are gone
+        if getattr(self, "_scene_dirty", True) or stale or getattr(self._handle, "_scene0_owner", None) is not self:
+            robot = self.opt.robot
+            ro, ra = resident_of(lo), resident_of(la)  # the obstacle field first: its build holds both fields
+            if ro is not None and ra is not None and ra[0] is ro[0] and (ra.sid, ra.gen) == (ro.sid, ro.gen):
+                # both fields live in ONE build of one resident scene: the solver's scene becomes that scene, each field the
+                # half it is (no copy, nothing through the host)
+                self._handle.share_scene(self.SCENE_ID, ro.handle, ro.sid, all_from=ra.half, obs_from=ro.half)
+                self._shared_from = (ro.handle, ro.sid, ro.gen)
             else:
                 shape, origin, res = robot.field_geometry()
                 # parameters that were never set are zeros (optas/mx_container.py:121): plan() leaves sdf_cost_all out
                 c_all = p.get("sdf_cost_all", np.zeros(int(np.prod(shape))))
                 c_obs = p.get("sdf_cost_obstacle", np.zeros(int(np.prod(shape))))
                 self._handle.set_scene(self.SCENE_ID, np.asarray(c_all), np.asarray(c_obs), shape, origin, res)
+                self._shared_from = None
             self._handle._scene0_owner = self
             self._scene_dirty = False
         return self.SCENE_ID

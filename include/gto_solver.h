@@ -191,6 +191,13 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
  * scene, and replacing or dropping the scene in `src` invalidates the borrowed entry.
  */
 int gto_share_scene(gto_handle* dst, int32_t dst_id, gto_handle* src, int32_t src_id);
+/* The same with a choice of halves: `dst`'s sdf_cost_all is `src`'s field number all_from, its sdf_cost_obstacle `src`'s
+ * field number obs_from (0: the source's sdf_cost_all, 1: its sdf_cost_obstacle; gto_share_scene = (0, 1)).  For a
+ * caller that holds ONE field of a resident scene and hands it to an entry point that reads the obstacle half
+ * (IKSolver.solve_ik and GTORobotModel.compute_plan_cost take `sdf_cost_obstacle`, gto/ik_solver.py:78,
+ * gto/gto_models.py:204): whichever half the field is, it is the half the entry point reads. */
+int gto_share_scene_halves(gto_handle* dst, int32_t dst_id, gto_handle* src, int32_t src_id, int32_t all_from,
+                           int32_t obs_from);
 
 /*
  * Inverse kinematics for B goal poses of link_ee: the pre-step that produces the
@@ -339,12 +346,16 @@ int gto_depth_sdf_cost(int device, const float* depth, int32_t height, int32_t w
  * gto_depth_sdf_cost calls) -> scene `scene_id` of the handle with its voxel records and distance fields.  The image is
  * uploaded once, back-projection and query ordering are shared by the two fields, and nothing but the geometry returns
  * to the host: shape_out [3], origin_out [3], bounds_out [6] = (min x, y, z, max x, y, z) of the first cloud.
- * target_mask == NULL: one cloud, sdf_cost_obstacle = sdf_cost_all.
+ * depth_obstacle [height*width] or NULL: the image of the SECOND cloud (the driver's `depth_obstacle`, :187-189: a copy of
+ * the depth image with the target's pixels pushed to the threshold); its points are back-projected from it, without the
+ * pixels of target_mask, and its visibility test (depth_point_cloud.py:126-141) reads it.  NULL: the second cloud is
+ * `depth` without the masked pixels.  target_mask == NULL and depth_obstacle == NULL: one cloud, sdf_cost_obstacle =
+ * sdf_cost_all.
  */
 int gto_scene_from_depth(gto_handle* h, int32_t scene_id, const float* depth, int32_t H, int32_t W, const double* K,
                          const double* Kinv, const double* cam_pose, const double* cam_inv, const uint8_t* target_mask,
-                         double threshold, double grid_res, double margin, float epsilon, float w_inside,
-                         int32_t* shape_out, double* origin_out, double* bounds_out);
+                         const float* depth_obstacle, double threshold, double grid_res, double margin, float epsilon,
+                         float w_inside, int32_t* shape_out, double* origin_out, double* bounds_out);
 /* The two float32 cost fields of a resident scene, device to host (either pointer may be NULL). */
 int gto_get_scene_fields(gto_handle* h, int32_t scene_id, float* c_all_out, float* c_obs_out);
 

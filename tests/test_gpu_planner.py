@@ -323,14 +323,21 @@ def _depth_scene_inputs():
     return depth, K, cam, target
 
 
-@pytest.mark.parametrize("res", [0.05, 0.031])
-def test_device_resident_depth_scene_equals_the_host_path(oracle_mod, res):
-    """examples/pybullet_gto_planning.py:176-190, 242-272, 291 called the reference's way: two DepthPointCloud objects from one
-    image, setup_points_field(points), get_sdf_cost(workspace_points) twice, IK of the grasps, plan_goalset.  Left lazy, all
+@pytest.mark.parametrize("res,pattern", [(0.05, "one_image"), (0.031, "one_image"), (0.05, "driver"), (0.04, "driver")])
+def test_device_resident_depth_scene_equals_the_host_path(oracle_mod, res, pattern):
+    """examples/pybullet_gto_planning.py:176-190, 242-272, 291 called the reference's way: two DepthPointCloud objects,
+    setup_points_field(points), get_sdf_cost(workspace_points) twice, IK of the grasps, plan_goalset.  Left lazy, all
     of it stays on the GPU (ONE gto_scene_from_depth call: depth_scene.py); forced through numpy (the host path of rounds
-    2-3: points, grid and fields as arrays) it must give the same grid, bit-identical fields and the same IK and plan."""
+    2-3: points, grid and fields as arrays) it must give the same grid, bit-identical fields and the same IK and plan.
+    pattern "driver": the obstacle cloud is built as the driver builds it (:187-189), from a COPY of the image with the
+    target's pixels pushed to the threshold; "one_image": both clouds from the same array."""
     cfg = cfg_of("panda")
     depth, K, cam, target = _depth_scene_inputs()
+    thr = 2.0
+    depth_obstacle = depth
+    if pattern == "driver":
+        depth_obstacle = depth.copy()
+        depth_obstacle[target.astype(bool)] = thr
     n_goals = 12
     qc = np.array(cfg["default_pose"])
     out = {}
@@ -338,8 +345,11 @@ def test_device_resident_depth_scene_equals_the_host_path(oracle_mod, res):
         robot = g.GTORobotModel(desc=g.load_builtin("panda"), time_derivs=[0, 1], param_joints=cfg["param_joints"],
                                 collision_link_names=cfg["collision_link_names"], device=0)
         robot.grid_resolution = res
-        dpc_all = g.DepthPointCloud(depth, K, cam, target_mask=None, threshold=2.0)
-        dpc_obs = g.DepthPointCloud(depth, K, cam, target_mask=target, threshold=2.0)
+        builds = []
+        uh = robot._util_handle()
+        real_build = uh.scene_from_depth
+        uh.scene_from_depth = lambda *a, **k: (builds.append(k.get("depth_obstacle") is not None), real_build(*a, **k))[1]
+        dpc_all = g.DepthPointCloud(depth, K, cam, target_mask=None, threshold=thr)
         pts = dpc_all.points
         if path == "host":
             pts = np.asarray(pts)  # the array the reference's DepthPointCloud hands out
@@ -348,19 +358,27 @@ def test_device_resident_depth_scene_equals_the_host_path(oracle_mod, res):
         if path == "host":
             assert isinstance(wp, np.ndarray)
         c_all = dpc_all.get_sdf_cost(wp)
+        dpc_obs = g.DepthPointCloud(depth_obstacle, K, cam, target_mask=target, threshold=thr)
         c_obs = dpc_obs.get_sdf_cost(wp)
         if path == "device":
             assert not isinstance(c_all, np.ndarray) and not isinstance(c_obs, np.ndarray)  # nothing came to the host
         ik = g.IKSolver(robot, cfg["link_ee"], cfg["link_gripper"], collision_avoidance=True)
         RT, _ = syn.make_goals(robot.desc, robot._util_handle().eval_fk, cfg["link_ee"], n_goals, seed=11, zlim=(0.15, 0.6))
         q_ik, ep, er, cost_ik, it, st = ik.solve_ik_batch(qc, RT, c_obs, [0.0, 0.0, 0.0])
+        # the other field handed to an entry point that reads "the obstacle field": it is that field that must be read
+        q_ik_all, _, _, cost_ik_all, it_all, _ = ik.solve_ik_batch(qc, RT, c_all, [0.0, 0.0, 0.0])
         planner = g.GTOPlanner(robot, cfg["link_ee"], cfg["link_gripper"], standoff_distance=-0.1, standoff_offset=-10)
         planner.max_iter = 25
         plan, dQ, cost = planner.plan_goalset(qc, RT, c_all, c_obs, [0.0, 0.0, 0.0], q_ik.T.astype(np.float32),
                                               use_standoff=True, axis_standoff=cfg["axis_standoff"], interpolate=True)
         pc, pd_ = robot.compute_plan_cost(plan, c_obs, [0.0, 0.0, 0.0])
+        pc_all_first, _ = robot.compute_plan_cost(plan, c_all, [0.0, 0.0, 0.0])
+        if path == "device":
+            assert len(builds) == 1, f"{len(builds)} builds of the resident scene for one object"
+            assert builds[0] == (pattern == "driver")  # the obstacle image went up with the call iff it is another image
         out[path] = dict(shape=robot.field_geometry()[0], origin=robot.field_geometry()[1], bounds=np.asarray(robot.workspace_bounds),
                          wp=np.asarray(robot.workspace_points), c_all=np.asarray(c_all), c_obs=np.asarray(c_obs), q_ik=q_ik, it=it,
+                         q_ik_all=q_ik_all, it_all=it_all, cost_ik_all=cost_ik_all, pc_all=pc_all_first,
                          plan=plan, cost=cost, seed=planner.seed_index, pc=pc, size=robot.field_size)
         robot.close()
     h_, d_ = out["host"], out["device"]
@@ -371,9 +389,64 @@ def test_device_resident_depth_scene_equals_the_host_path(oracle_mod, res):
     np.testing.assert_array_equal(h_["c_all"], d_["c_all"])    # bit-identical float32 fields
     np.testing.assert_array_equal(h_["c_obs"], d_["c_obs"])
     assert (h_["c_all"] != h_["c_obs"]).any()
+    # the field of all pixels sees the target object: voxels inside it cost something there and nothing in the obstacle field
+    assert ((d_["c_all"] > 0) & (d_["c_obs"] == 0)).sum() > 0
     np.testing.assert_array_equal(h_["q_ik"], d_["q_ik"])
     np.testing.assert_array_equal(h_["it"], d_["it"])
+    np.testing.assert_array_equal(h_["q_ik_all"], d_["q_ik_all"])
+    np.testing.assert_array_equal(h_["it_all"], d_["it_all"])
+    np.testing.assert_array_equal(h_["cost_ik_all"], d_["cost_ik_all"])
     assert h_["seed"] == d_["seed"]
     np.testing.assert_array_equal(h_["plan"], d_["plan"])
     np.testing.assert_array_equal(h_["cost"], d_["cost"])
     assert h_["pc"] == d_["pc"]
+    assert h_["pc_all"] == d_["pc_all"]
+
+
+def test_resident_depth_scene_is_rebuilt_not_reused_across_images(oracle_mod):
+    """Two objects, one robot model (the driver's loop, examples/pybullet_gto_planning.py:160-300): the second object's
+    fields come from another image.  A field of the FIRST object used after the second object's scene was built (its
+    handles hold pointers into the first build's buffers) must still be its own field: the resident scene is keyed by
+    value on both clouds, borrowers share again when its generation has moved."""
+    cfg = cfg_of("panda")
+    depth, K, cam, target = _depth_scene_inputs()
+    depth2 = depth.copy()
+    depth2[300:380, 100:180] -= 0.15  # another box on the table
+    qc = np.array(cfg["default_pose"])
+    robot = g.GTORobotModel(desc=g.load_builtin("panda"), time_derivs=[0, 1], param_joints=cfg["param_joints"],
+                            collision_link_names=cfg["collision_link_names"], device=0)
+    fields = []
+    for d in (depth, depth2):
+        dobs = d.copy()
+        dobs[target.astype(bool)] = 2.0
+        dpc_all = g.DepthPointCloud(d, K, cam, target_mask=None, threshold=2.0)
+        robot.setup_points_field(dpc_all.points)
+        wp = robot.workspace_points
+        fields.append((dpc_all.get_sdf_cost(wp), g.DepthPointCloud(dobs, K, cam, target_mask=target, threshold=2.0).get_sdf_cost(wp), dpc_all))
+    ik = g.IKSolver(robot, cfg["link_ee"], cfg["link_gripper"], collision_avoidance=True)
+    RT, _ = syn.make_goals(robot.desc, robot._util_handle().eval_fk, cfg["link_ee"], 6, seed=5, zlim=(0.15, 0.6))
+    (a1, o1, p1), (a2, o2, p2) = fields
+    q2, _, _, c2, it2, _ = ik.solve_ik_batch(qc, RT, o2, [0.0, 0.0, 0.0])   # builds object 2's scene
+    planner = g.GTOPlanner(robot, cfg["link_ee"], cfg["link_gripper"], standoff_distance=-0.1, standoff_offset=-10)
+    planner.max_iter = 10
+    plan2, _, f2 = planner.plan_goalset(qc, RT, a2, o2, [0.0, 0.0, 0.0], q2.T.astype(np.float32), axis_standoff=cfg["axis_standoff"])
+    solver2 = planner.solver
+    # object 1's obstacle field now: the resident scene is rebuilt from object 1's images (on object 1's grid)
+    q1, _, _, c1, it1, _ = ik.solve_ik_batch(qc, RT, o1, [0.0, 0.0, 0.0])
+    # ... and the planner's solver of object 2, which borrowed the scene of the build that is gone, shares again
+    sol = solver2.solve()
+    np.testing.assert_array_equal(sol[f"{robot.get_name()}/q"].toarray(), plan2)
+    # the same calls with the fields as host arrays
+    robot_h = g.GTORobotModel(desc=g.load_builtin("panda"), time_derivs=[0, 1], param_joints=cfg["param_joints"],
+                              collision_link_names=cfg["collision_link_names"], device=0)
+    ik_h = g.IKSolver(robot_h, cfg["link_ee"], cfg["link_gripper"], collision_avoidance=True)
+    robot_h.setup_points_field(np.asarray(p2.points))
+    q2h, _, _, c2h, it2h, _ = ik_h.solve_ik_batch(qc, RT, np.asarray(o2), [0.0, 0.0, 0.0])
+    robot_h.setup_points_field(np.asarray(p1.points))
+    q1h, _, _, c1h, it1h, _ = ik_h.solve_ik_batch(qc, RT, np.asarray(o1), [0.0, 0.0, 0.0])
+    np.testing.assert_array_equal(q2, q2h)
+    np.testing.assert_array_equal(q1, q1h)
+    np.testing.assert_array_equal(it1, it1h)
+    assert (np.asarray(o1) != np.asarray(o2)).any() or np.asarray(o1).shape != np.asarray(o2).shape
+    robot.close()
+    robot_h.close()
