@@ -1226,7 +1226,7 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
       }
     } else {
       if (h->profiling && (rc = prof_begin(h, st, GTO_PROF_STEP, in_flight))) { rc_loop = rc; break; }
-      hipLaunchKernelGGL(k_lm_step_wide<16>, dim3(in_flight), dim3(256), h->lm_lds, st, h->d_rb, bp, sp, B, (double*)h->zws.p);
+      hipLaunchKernelGGL(k_lm_step_wide<16>, dim3(in_flight), dim3(GTO_WIDE_NT), h->lm_lds, st, h->d_rb, bp, sp, B, (double*)h->zws.p);
       if (h->profiling && (rc = prof_end(h, st))) { rc_loop = rc; break; }
     }
   }

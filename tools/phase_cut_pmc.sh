@@ -15,6 +15,7 @@ cd $GRAFT_REPO_ROOT
 python - $out <<'PY'
 import csv, glob, os, sys, collections
 out = sys.argv[1]
+GRID = int(os.environ.get("PHASE_CUT_GRID", 384 * 16 * 256))  # threads of the evaluation launch: B x 16 waypoint groups x 256
 rows = collections.defaultdict(dict)
 for d in sorted(glob.glob(os.path.join(out, "c*_*"))):
     if not os.path.isdir(d):
@@ -25,7 +26,7 @@ for d in sorted(glob.glob(os.path.join(out, "c*_*"))):
         continue
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(f[0])):
-        if "k_obstacle_gram" in r["Kernel_Name"] and int(r.get("Grid_Size", 0) or 0) % (256 * 16 * 8) == 0 and int(r["Grid_Size"]) >= 256 * 16 * 64:
+        if "k_obstacle_gram" in r["Kernel_Name"] and int(r.get("Grid_Size", 0) or 0) == GRID:
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, v in acc.items():
         v = v[1:] if len(v) > 1 else v  # the first launch is cold
@@ -33,7 +34,7 @@ for d in sorted(glob.glob(os.path.join(out, "c*_*"))):
     t = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)
     if t:
         du = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in csv.DictReader(open(t[0]))
-              if "k_obstacle_gram" in r["Kernel_Name"] and int(r.get("Grid_Size_X", r.get("Grid_Size", 0)) or 0) >= 256 * 16 * 64]
+              if "k_obstacle_gram" in r["Kernel_Name"] and int(r.get("Grid_Size_X", r.get("Grid_Size", 0)) or 0) == GRID]
         if du:
             rows[cut]["us"] = min(du) / 1e3
 names = sorted({k for r in rows.values() for k in r})
