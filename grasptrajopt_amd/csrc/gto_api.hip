@@ -1240,6 +1240,9 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
     HIPCHK(h, hipMemcpy(t, h->dbg, sizeof t, hipMemcpyDeviceToHost));
     fprintf(stderr, "[gto dbg] step-kernel phases (cycles) P0+P1 %lld | P2 %lld | diag %lld | dense %lld | back %lld | P4 %lld | P5 %lld | s_dense %lld\n",
             t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3], t[5] - t[4], t[6] - t[5], t[7] - t[6], t[9]);
+    if (h->np != GTO_NB)
+      fprintf(stderr, "[gto dbg] wide step kernel, sweeps (cycles): downward: %lld in %lld dense inversions, sweep %lld | upward: %lld in %lld dense inversions, sweep %lld\n",
+              t[56], t[57], t[58], t[59], t[60], t[61]);
     fprintf(stderr, "[gto dbg] solve by wave (cycles from the start of P3): downward sweep: diagonal stretch %lld, its dense blocks %lld | upward sweep %lld | meeting block %lld | back substitution from its start: downward wave dense %lld, diagonal stretch %lld | upward wave %lld\n",
             t[3] - t[2], t[41] - t[2], t[17] - t[2], t[42] - t[4], t[18] - t[42], t[19] - t[42], t[26] - t[42]);
     fprintf(stderr, "[gto dbg] sweeps of the other candidates' waves (2..6) done at (cycles from the start of P3, 0 = no candidate): %lld %lld %lld %lld %lld | barrier passed at %lld\n",
