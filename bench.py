@@ -112,6 +112,7 @@ def main(argv=None, emit=True):
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="goal grasps (instances) per GPU per step")
     ap.add_argument("--pipeline", type=int, default=4, help="lanes per GPU: solver handles, each with its stream and host thread")
+    ap.add_argument("--lanes", type=int, default=0, help="lanes INSIDE a solver call (gto_set_lanes), each on a torch stream of its own; 0: the library's default")
     ap.add_argument("--merge", type=int, default=32, help="steps (batches) a lane hands to the solver in one call; the solver keeps "
                     "GTO_SLOTS (384) of their instances in flight and refills slots as instances finish")
     ap.add_argument("--max-iter", type=int, default=100, help="iteration cap (reference IPOPT cap: 100)")
@@ -224,6 +225,10 @@ def main(argv=None, emit=True):
             self.h = _capi.SolverHandle(desc, cfg["link_ee"], cfg["link_gripper"], opts, device=local_rank, n_gripper_points=100)
             self.h.set_mode(mode)
             self.h.set_stream(self.stream.cuda_stream)
+            if args.lanes > 0:
+                self.lane_streams = [self.stream] + [torch.cuda.Stream(dev) for _ in range(args.lanes - 1)]
+                self.h.set_lanes(args.lanes, int(os.environ.get("GTO_LANE_MIN", "256")), int(os.environ.get("GTO_ADOPT", "48")))
+                self.h.set_lane_streams([s_.cuda_stream for s_ in self.lane_streams])
             if first is None:
                 self.h.set_scene(0, sc.c_all, sc.c_obs, sc.shape, sc.origin, sc.res)
             else:

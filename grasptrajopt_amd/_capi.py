@@ -191,6 +191,8 @@ def load_library(path: Optional[str] = None):
         lib.gto_last_kernel_profile.restype = C.c_int
     lib.gto_set_stream.argtypes = [H, C.c_void_p]
     lib.gto_set_mode.argtypes = [H, C.c_int32]
+    lib.gto_set_lanes.argtypes = [H, C.c_int32, C.c_int32, C.c_int32]
+    lib.gto_set_lane_streams.argtypes = [H, C.c_int32, C.POINTER(C.c_void_p)]
     lib.gto_share_scene.argtypes = [H, C.c_int32, H, C.c_int32]
     if hasattr(lib, "gto_share_scene_halves"):  # (an older build named by GTO_HIP_LIB for an A/B run lacks it)
         lib.gto_share_scene_halves.argtypes = [H, C.c_int32, H, C.c_int32, C.c_int32, C.c_int32]
@@ -213,7 +215,7 @@ def load_library(path: Optional[str] = None):
     lib.gto_depth_sdf_cost.argtypes = [C.c_int, _pf, C.c_int32, C.c_int32, _pd, _pd, _pd, _pd, _pu8, C.c_double, _pd, C.c_int64,
                                        C.c_float, C.c_float, _pf, _pu8, _pf, _pd, _pu8]
     for fn in ("gto_create", "gto_set_opts", "gto_set_scene", "gto_set_scene_values", "gto_drop_scene", "gto_solve_batch",
-               "gto_solve_batch_device", "gto_last_kernel_time", "gto_last_kernel_work", "gto_set_profiling", "gto_set_stream", "gto_set_mode", "gto_share_scene",
+               "gto_solve_batch_device", "gto_last_kernel_time", "gto_last_kernel_work", "gto_set_profiling", "gto_set_stream", "gto_set_mode", "gto_set_lanes", "gto_set_lane_streams", "gto_share_scene",
                "gto_eval_fk", "gto_eval_points", "gto_eval_objective", "gto_eval_obstacle_normal_eq", "gto_plan_cost", "gto_solve_ik_batch",
                "gto_solve_base_batch", "gto_eval_base_objective", "gto_depth_sdf_cost"):
         getattr(lib, fn).restype = C.c_int
@@ -225,7 +227,7 @@ def load_library(path: Optional[str] = None):
 EXPORTED_SYMBOLS = (
     "gto_default_opts", "gto_version", "gto_create", "gto_destroy", "gto_last_error", "gto_set_opts",
     "gto_set_scene", "gto_set_scene_values", "gto_drop_scene", "gto_solve_batch", "gto_solve_batch_device",
-    "gto_last_kernel_time", "gto_last_kernel_work", "gto_last_kernel_profile", "gto_set_profiling", "gto_set_stream", "gto_set_mode", "gto_share_scene", "gto_share_scene_halves",
+    "gto_last_kernel_time", "gto_last_kernel_work", "gto_last_kernel_profile", "gto_set_profiling", "gto_set_stream", "gto_set_mode", "gto_set_lanes", "gto_set_lane_streams", "gto_share_scene", "gto_share_scene_halves",
     "gto_eval_fk", "gto_eval_points",
     "gto_eval_objective", "gto_eval_obstacle_normal_eq", "gto_plan_cost", "gto_solve_ik_batch", "gto_solve_base_batch",
     "gto_eval_base_objective", "gto_depth_sdf_cost", "gto_scene_from_depth", "gto_get_scene_fields",
@@ -418,6 +420,15 @@ class SolverHandle:
     def set_mode(self, mode: int):
         """MODE_ROUNDS (default): evaluate / step launches over slots; MODE_SINGLE_LAUNCH: one launch per call."""
         self._check(self.lib.gto_set_mode(self._h, int(mode)), "gto_set_mode")
+
+    def set_lanes(self, max_lanes: int = 4, min_per_lane: int = 256, adopt_below: int = 48):
+        """Lanes of a solve call (include/gto_solver.h, gto_set_lanes): streams the call's instances are dealt to."""
+        self._check(self.lib.gto_set_lanes(self._h, int(max_lanes), int(min_per_lane), int(adopt_below)), "gto_set_lanes")
+
+    def set_lane_streams(self, streams=()):
+        """The lanes' HIP streams (raw handles, e.g. torch.cuda.Stream(...).cuda_stream); () = the handle's own."""
+        arr = (C.c_void_p * max(1, len(streams)))(*[C.c_void_p(int(x)) for x in streams])
+        self._check(self.lib.gto_set_lane_streams(self._h, len(streams), arr), "gto_set_lane_streams")
 
     def set_profiling(self, enabled: bool):
         self._check(self.lib.gto_set_profiling(self._h, int(enabled)), "gto_set_profiling")

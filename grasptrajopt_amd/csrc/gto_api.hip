@@ -4,6 +4,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -25,6 +26,8 @@
 #endif
 
 static std::string g_create_error;
+
+#define GTO_MAX_LANES 8  // lanes of one solve call (streams, list sets, progress words)
 
 struct DevBuf {
   void* p = nullptr;
@@ -111,7 +114,15 @@ struct gto_handle {
   size_t lm_lds = 0;
   int np = GTO_NB;     // block width of the normal equations: 8 (up to eight optimised joints) or 16
   DevBuf zws;          // k_lm_step_wide: block inverses [slots][T-2][np*np]
-  int slots = 384;  // instances in flight inside one solve call (GTO_SLOTS); a finished instance hands its slot to the next one
+  int slots = 384;  // instances in flight per lane of a solve call (GTO_SLOTS); a finished instance hands its slot to the next one
+  // lanes of a solve call (gto_solve_batch_device): at most lanes_max, each with at least lane_min instances; a lane with
+  // at most adopt_below instances left hands them to lane 0 (0: never).  gto_set_lanes / GTO_LANES, GTO_LANE_MIN, GTO_ADOPT
+  int lanes_max = 1, lane_min = 256, adopt_below = 0;
+  hipStream_t lane_stream[GTO_MAX_LANES] = {};
+  hipEvent_t lane_event[GTO_MAX_LANES] = {};
+  hipStream_t user_lane_stream[GTO_MAX_LANES] = {};  // gto_set_lane_streams: the caller's streams for the lanes
+  int n_user_lane_streams = 0;
+  std::mutex* prof_mu = nullptr;  // set while a call with several lanes (host threads) runs: guards the profiling records
 };
 
 #define HIPCHK(h, call)                                                                              \
@@ -239,6 +250,9 @@ int gto_create(const gto_robot_desc* d, const gto_solver_opts* opts, int device,
   if (const char* e = getenv("GTO_DEBUG_CUT")) h->dbg_cut = atoi(e);
   if (h->dbg_cut) fprintf(stderr, "[gto] WARNING: GTO_DEBUG_CUT=%d cuts the obstacle kernel short: timing experiments only, RESULTS ARE GARBAGE\n", h->dbg_cut);
   if (const char* e = getenv("GTO_SLOTS")) h->slots = std::max(1, atoi(e));
+  if (const char* e = getenv("GTO_LANES")) h->lanes_max = std::max(1, std::min(GTO_MAX_LANES, atoi(e)));
+  if (const char* e = getenv("GTO_LANE_MIN")) h->lane_min = std::max(1, atoi(e));
+  if (const char* e = getenv("GTO_ADOPT")) h->adopt_below = std::max(0, atoi(e));
   if (const char* e = getenv("GTO_OBS_TG")) h->obs_tg = h->obs_tg_few = std::max(1, std::min(GTO_MAX_TG, atoi(e)));
   if (const char* e = getenv("GTO_OBS_TG_FEW")) h->obs_tg_few = std::max(1, std::min(GTO_MAX_TG, atoi(e)));
   if (const char* e = getenv("GTO_FEW_INSTANCES")) h->few_instances = atoi(e);
@@ -640,6 +654,10 @@ void gto_destroy(gto_handle* h) {
   for (auto& b : h->pin_out) if (b.p) (void)hipHostFree(b.p);
   for (auto e : h->ev) (void)hipEventDestroy(e);
   if (h->stream && h->own_stream) (void)hipStreamDestroy(h->stream);
+  for (int l = 0; l < GTO_MAX_LANES; ++l) {
+    if (h->lane_stream[l]) (void)hipStreamDestroy(h->lane_stream[l]);
+    if (h->lane_event[l]) (void)hipEventDestroy(h->lane_event[l]);
+  }
   delete h;
 }
 
@@ -868,6 +886,24 @@ int gto_set_mode(gto_handle* h, int32_t mode) {
   return GTO_OK;
 }
 
+int gto_set_lanes(gto_handle* h, int32_t max_lanes, int32_t min_per_lane, int32_t adopt_below) {
+  if (!h) return GTO_ERR_INVALID_ARG;
+  if (max_lanes < 1 || max_lanes > GTO_MAX_LANES || min_per_lane < 1 || adopt_below < 0)
+    return fail(h, GTO_ERR_INVALID_ARG, "gto_set_lanes: 1 <= max_lanes <= 8, min_per_lane >= 1, adopt_below >= 0");
+  h->lanes_max = max_lanes, h->lane_min = min_per_lane, h->adopt_below = adopt_below;
+  return GTO_OK;
+}
+
+int gto_set_lane_streams(gto_handle* h, int32_t n, void* const* streams) {
+  if (!h) return GTO_ERR_INVALID_ARG;
+  if (n < 0 || n > GTO_MAX_LANES || (n > 0 && !streams)) return fail(h, GTO_ERR_INVALID_ARG, "gto_set_lane_streams: 0 <= n <= 8 streams");
+  for (int i = 0; i < n; ++i)
+    if (!streams[i]) return fail(h, GTO_ERR_INVALID_ARG, "gto_set_lane_streams: null stream");
+  for (int i = 0; i < n; ++i) h->user_lane_stream[i] = (hipStream_t)streams[i];
+  h->n_user_lane_streams = n;
+  return GTO_OK;
+}
+
 int gto_set_stream(gto_handle* h, void* stream) {
   if (!h) return GTO_ERR_INVALID_ARG;
   HIPCHK(h, hipSetDevice(h->device));
@@ -955,18 +991,14 @@ static int ensure_workspace(gto_handle* h, int B) {
   const size_t bstride = (size_t)h->np * h->np + h->np + 8;
   if ((rc = ensure(h, h->blocks, (kcap + 1) * B * T * bstride * sizeof(double)))) return rc;
   if ((rc = ensure(h, h->goalblk, (kcap + 1) * B * 2 * bstride * sizeof(double)))) return rc;
-  if (h->np != GTO_NB && (rc = ensure(h, h->zws, (size_t)std::min(B, h->slots) * (T - 2) * h->np * h->np * sizeof(double)))) return rc;
   if ((rc = ensure(h, h->ssfixed, (size_t)B * 4 * sizeof(double)))) return rc;
-  if ((rc = ensure(h, h->ndone, 64))) return rc;
+  if ((rc = ensure(h, h->ndone, 64 * GTO_MAX_LANES))) return rc;  // a finished-counter per lane, a cache line apart
   if ((rc = ensure(h, h->qf, (size_t)B * T * rb.n_frames * sizeof(double)))) return rc;
-  if ((rc = ensure(h, h->livebuf, (2 * (1 + kcap) * (size_t)std::min(B, h->slots) + 32) * sizeof(int32_t)))) return rc;
-  if ((rc = ensure(h, h->qfs, 2 * (size_t)std::min(B, h->slots) * kcap * T * rb.n_frames * sizeof(double)))) return rc;
   if ((rc = ensure(h, h->wrecbuf, (size_t)(kcap + 1) * B * T * 8 * sizeof(double)))) return rc;
-  if ((rc = ensure(h, h->itembuf, 2 * ((size_t)std::min(B, h->slots) * kcap * (T - 2) + GTO_ITEM_SLACK) * sizeof(int2)))) return rc;
   if (!h->h_ndone) HIPCHK(h, hipHostMalloc((void**)&h->h_ndone, 64));
   if (!h->h_progress) {
-    HIPCHK(h, hipHostMalloc((void**)&h->h_progress, 64, hipHostMallocMapped));
-    std::memset(h->h_progress, 0, 64);  // every word the solve loop reads carries a call tag (never 0)
+    HIPCHK(h, hipHostMalloc((void**)&h->h_progress, 64 * GTO_MAX_LANES, hipHostMallocMapped));  // eight words per lane
+    std::memset(h->h_progress, 0, 64 * GTO_MAX_LANES);  // every word the solve loop reads carries a call tag (never 0)
     HIPCHK(h, hipHostGetDevicePointer((void**)&h->d_progress, h->h_progress, 0));
   }
   return GTO_OK;
@@ -1009,21 +1041,28 @@ static inline int obstacle_grid(int B, int nG) { return 8 * ((B + 7) / 8) * nG; 
 
 // profiling (gto_set_profiling): a pair of HIP events on the launch stream around launch number h->last_launches
 static int prof_begin(gto_handle* h, hipStream_t st, int variant, long long wgs) {
+  if (h->prof_mu) h->prof_mu->lock();  // lanes of one call record into one list: begin .. end is one critical section
   const size_t need = (size_t)(h->last_launches + 1) * 2;
-  while (h->ev.size() < need) {
-    hipEvent_t e;
-    HIPCHK(h, hipEventCreate(&e));
-    h->ev.push_back(e);
+  hipError_t e = hipSuccess;
+  while (h->ev.size() < need && e == hipSuccess) {
+    hipEvent_t ev_;
+    if ((e = hipEventCreate(&ev_)) == hipSuccess) h->ev.push_back(ev_);
   }
-  if (h->ev_variant.size() <= (size_t)h->last_launches) h->ev_variant.resize(h->last_launches + 1), h->ev_wgs.resize(h->last_launches + 1);
-  h->ev_variant[h->last_launches] = variant;
-  h->ev_wgs[h->last_launches] = wgs;
-  HIPCHK(h, hipEventRecord(h->ev[2 * h->last_launches], st));
+  if (e == hipSuccess) {
+    if (h->ev_variant.size() <= (size_t)h->last_launches) h->ev_variant.resize(h->last_launches + 1), h->ev_wgs.resize(h->last_launches + 1);
+    h->ev_variant[h->last_launches] = variant;
+    h->ev_wgs[h->last_launches] = wgs;
+    e = hipEventRecord(h->ev[2 * h->last_launches], st);
+  }
+  if (e != hipSuccess && h->prof_mu) h->prof_mu->unlock();
+  HIPCHK(h, e);
   return GTO_OK;
 }
 static int prof_end(gto_handle* h, hipStream_t st) {
-  HIPCHK(h, hipEventRecord(h->ev[2 * h->last_launches + 1], st));
+  const hipError_t e = hipEventRecord(h->ev[2 * h->last_launches + 1], st);
   h->last_launches++;
+  if (h->prof_mu) h->prof_mu->unlock();
+  HIPCHK(h, e);
   return GTO_OK;
 }
 
@@ -1101,28 +1140,103 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
   h->last_ms = 0.0;
   if (h->dbg) HIPCHK(h, hipMemsetAsync(h->dbg + 40, 0, 152 * sizeof(long long), st));
 
-  // At most W instances are in flight; the step kernel of an instance that finishes puts the next one of the call that
-  // has not started into the next round's live list, so every round works on a full house until the batch runs out,
+  // At most W instances per lane are in flight; the step kernel of an instance that finishes puts the next one of its lane
+  // that has not started into the next round's live list, so every round works on a full house until the lane runs out,
   // instead of dragging the tail of its slowest instances through ever emptier rounds.
-  const int W = std::min(B, h->slots);
-  bp.live = (int32_t*)h->livebuf.p;
-  bp.jobs = bp.live + 2 * W;
-  bp.nlive = bp.jobs + 2 * W * sp.kcap;
-  bp.next = bp.nlive + 4;
-  bp.qfs = (double*)h->qfs.p;
-  bp.items = h->np == GTO_NB ? (int2*)h->itembuf.p : nullptr;
-  bp.cap = W;
-  bp.n_total = B;
-  HIPCHK(h, hipMemsetAsync(bp.n_done, 0, sizeof(int32_t), st));
-  // the finished-counter and the round counter reach the host through two words in pinned memory that the step kernel
+  //
+  // LANES.  A call's instances are dealt to up to h->lanes_max lanes (contiguous ranges of at least h->lane_min), each
+  // with a stream and lists of its own over the ONE workspace of the call (everything about an instance is indexed by its
+  // id in the batch): one lane's obstacle launch overlaps another's step launch while the GPU is full.  One host thread
+  // feeds all of them round-robin.  Towards the end of the call every lane is down to a handful of stragglers whose
+  // iterations are one dependent round each; four such chains sharing the command processor advance at 35-55 us a round
+  // where one alone takes 21-27, so a lane whose remaining instances are all in flight and at most h->adopt_below hands
+  // them to lane 0 (k_adopt), which then runs ONE chain for everybody.
+  const int L = std::max(1, std::min(std::min(h->lanes_max, GTO_MAX_LANES), B / std::max(1, h->lane_min)));
+  const int kcap = sp.kcap, nF = h->rb.n_frames;
+  struct LaneCtx {
+    hipStream_t st = nullptr;
+    BatchPtrs bp;
+    SolveParams sp;
+    int lo = 0, n = 0, W = 0, cap = 0;  // first instance, instances, in flight at the start, list capacity
+    int room = 0;                       // positions its lists can have in use: W + what it adopted
+    int n_resp = 0;                     // instances whose end this lane's finished-counter counts (own + adopted)
+    int k = 0, known_done = 0, seen_round = -1, k_prev = 1;
+    bool items_ready = false, pb_off = false, handed = false;
+    long end_us = 0, few_us = 0;  // (GTO_LANE_DEBUG) when the lane's thread returned / enqueued its first few-instance round, from the start of the threads
+    unsigned long long* h_prog = nullptr;
+  };
+  std::vector<LaneCtx> lanes(L);
+  const int adopt_room = L > 1 ? (L - 1) * std::max(0, h->adopt_below) : 0;
+  size_t off_live[GTO_MAX_LANES + 1] = {0}, off_qfs[GTO_MAX_LANES + 1] = {0}, off_items[GTO_MAX_LANES + 1] = {0}, lane_zws[GTO_MAX_LANES + 1] = {0};
+  for (int l = 0; l < L; ++l) {
+    LaneCtx& ln = lanes[l];
+    ln.lo = (int)((long long)B * l / L);
+    ln.n = (int)((long long)B * (l + 1) / L) - ln.lo;
+    ln.W = std::min(ln.n, h->slots);
+    ln.cap = ln.W + (l == 0 ? adopt_room : 0);
+    ln.n_resp = ln.n;
+    ln.room = ln.W;
+    off_live[l + 1] = off_live[l] + 2 * (size_t)(1 + kcap) * ln.cap + 32;
+    off_qfs[l + 1] = off_qfs[l] + 2 * (size_t)ln.cap * kcap * T * nF;
+    off_items[l + 1] = off_items[l] + 2 * ((size_t)ln.cap * kcap * (T - 2) + GTO_ITEM_SLACK);
+    lane_zws[l + 1] = lane_zws[l] + (size_t)ln.cap;
+  }
+  if ((rc = ensure(h, h->livebuf, off_live[L] * sizeof(int32_t)))) return rc;
+  if ((rc = ensure(h, h->qfs, off_qfs[L] * sizeof(double)))) return rc;
+  if ((rc = ensure(h, h->itembuf, off_items[L] * sizeof(int2)))) return rc;
+  if (h->np != GTO_NB && (rc = ensure(h, h->zws, lane_zws[L] * (size_t)(T - 2) * h->np * h->np * sizeof(double)))) return rc;
+  for (int l = 0; l < L; ++l) {
+    LaneCtx& ln = lanes[l];
+    ln.sp = sp;
+    ln.bp = bp;
+    ln.bp.live = (int32_t*)h->livebuf.p + off_live[l];
+    ln.bp.jobs = ln.bp.live + 2 * ln.cap;
+    ln.bp.nlive = ln.bp.jobs + 2 * ln.cap * kcap;
+    ln.bp.next = ln.bp.nlive + 4;
+    ln.bp.qfs = (double*)h->qfs.p + off_qfs[l];
+    ln.bp.items = h->np == GTO_NB ? (int2*)h->itembuf.p + off_items[l] : nullptr;
+    ln.bp.n_done = (int32_t*)h->ndone.p + 16 * l;
+    ln.bp.cap = ln.cap;
+    ln.bp.b0 = ln.lo;
+    ln.bp.w0 = ln.W;
+    ln.bp.n_total = ln.lo + ln.n;
+    ln.h_prog = h->h_progress + 8 * l;
+    ln.bp.progress = h->d_progress + 8 * l;
+    // One lane: the caller's stream.  Several: streams of the handle's own, created one after the other -- the runtime deals
+    // streams to its few hardware queues (GPU_MAX_HW_QUEUES, default 4) in the order of their creation, and two lanes on
+    // one queue run one after the other (the caller's stream next to three new ones: 126 k trajectories/s instead of 225 k);
+    // the caller's stream carries the start and the end of the call and waits in between.
+    if (L == 1) ln.st = st;
+    else if (l < h->n_user_lane_streams) ln.st = h->user_lane_stream[l];  // gto_set_lane_streams
+    else {
+      if (!h->lane_stream[l]) {
+        // Streams of the greatest priority by default: the runtime gives them hardware queues of their own, one per stream
+        // in the order of creation, so four lanes sit behind four dispatcher pipes.  Streams of the default priority share
+        // the process's four queues with every other stream it has created, and two lanes whose queues sit behind one pipe
+        // split its workgroup dispatch rate (the evaluation launch, five thousand mostly empty workgroups, 75 us instead
+        // of 48; rocprofv3 queue ids 1 and 5 in gpurun_out traces of round 5): 118 k instead of 196 k trajectories/s for
+        // one call of 1280 instances.  GTO_LANE_PRIO=0 default priority, 2 least.
+        static const int prio_mode = getenv("GTO_LANE_PRIO") ? atoi(getenv("GTO_LANE_PRIO")) : 1;
+        int lo_p = 0, hi_p = 0;
+        HIPCHK(h, hipDeviceGetStreamPriorityRange(&lo_p, &hi_p));  // (least, greatest): greatest is the smaller number
+        if (prio_mode == 1) HIPCHK(h, hipStreamCreateWithPriority(&h->lane_stream[l], hipStreamNonBlocking, hi_p));
+        else if (prio_mode == 2) HIPCHK(h, hipStreamCreateWithPriority(&h->lane_stream[l], hipStreamNonBlocking, lo_p));
+        else HIPCHK(h, hipStreamCreateWithFlags(&h->lane_stream[l], hipStreamNonBlocking));
+      }
+      ln.st = h->lane_stream[l];
+    }
+    if (!h->lane_event[l]) HIPCHK(h, hipEventCreateWithFlags(&h->lane_event[l], hipEventDisableTiming));
+  }
+  HIPCHK(h, hipMemsetAsync(h->ndone.p, 0, 16 * sizeof(int32_t) * L, st));
+  // the finished-counter and the round counter reach the host through words in pinned memory that the step kernel
   // writes; the tag tells this call's values from what the last launches of the previous call may still be writing
   h->progress_tag = h->progress_tag + 1 ? h->progress_tag + 1 : 1;
-  bp.progress = h->d_progress;
-  bp.progress_tag = (unsigned long long)h->progress_tag << 32;
+  for (int l = 0; l < L; ++l) lanes[l].bp.progress_tag = (unsigned long long)h->progress_tag << 32;
   if (h->profiling) {
     if ((rc = ensure(h, h->counters, GTO_PROF_VARIANTS * 64 * sizeof(unsigned long long)))) return rc;
+    HIPCHK(h, hipMemsetAsync(h->counters.p, 0, GTO_PROF_VARIANTS * 64 * sizeof(unsigned long long), st));
     bp.work = (unsigned long long*)h->counters.p;  // 64 cells per kernel variant (launch_obstacle picks the variant's)
-    HIPCHK(h, hipMemsetAsync(bp.work, 0, GTO_PROF_VARIANTS * 64 * sizeof(unsigned long long), st));
+    for (int l = 0; l < L; ++l) lanes[l].bp.work = bp.work;
   }
   // The broad phase ahead of the obstacle launch, in the rounds that fill the GPU: the step kernel settles the waypoint
   // groups none of whose bounding spheres can reach a non-zero voxel record and lists the others (prebroad_tail); the
@@ -1130,106 +1244,225 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
   // pass in the step kernel's dead LDS, at most GTO_PB_PARK parked frames in its serial walk over the kinematic tree.
   const int pb_tg = std::max(1, std::min(h->obs_tg, T - 2)), pb_ng = (T - 2 + pb_tg - 1) / pb_tg;
   const PbLayout pbl(T, h->rb.n_frames, h->pb_C, h->rb.pb_npar);
-  const bool pb_ok = h->prebroad && bp.items != nullptr && pb_ng <= 64 && h->obs_interleave != 1 && h->rb.n_xst <= GTO_PB_PARK && pbl.pw >= 1 &&
-                     h->pb_C >= 1 && std::min(W, B) > h->few_instances;
+  const bool pb_able = h->prebroad && h->np == GTO_NB && pb_ng <= 64 && h->obs_interleave != 1 && h->rb.n_xst <= GTO_PB_PARK && pbl.pw >= 1 && h->pb_C >= 1;
+  for (int l = 0; l < L; ++l) {
+    SolveParams& lsp = lanes[l].sp;
+    lsp.pb_tg = pb_tg, lsp.pb_ng = pb_ng, lsp.pb_pw = std::max(1, pbl.pw), lsp.pb_tab0 = pbl.tab0;
+    lsp.pb_verify = h->dbg_cut == 10;
+  }
   sp.pb_tg = pb_tg, sp.pb_ng = pb_ng, sp.pb_pw = std::max(1, pbl.pw), sp.pb_tab0 = pbl.tab0;
-  sp.pb_verify = h->dbg_cut == 10;
-  if (h->np == GTO_NB) hipLaunchKernelGGL(k_lm_init<GTO_NB>, dim3(B), dim3(256), 0, st, h->d_rb, bp, sp, B, 0);
-  else hipLaunchKernelGGL(k_lm_init<16>, dim3(B), dim3(256), 0, st, h->d_rb, bp, sp, B, 0);
+  for (int l = 0; l < L; ++l) {  // seeds, goal terms of the seeds, the lane's lists of round 0
+    if (h->np == GTO_NB) hipLaunchKernelGGL(k_lm_init<GTO_NB>, dim3(lanes[l].n), dim3(256), 0, st, h->d_rb, lanes[l].bp, lanes[l].sp, B, 0);
+    else hipLaunchKernelGGL(k_lm_init<16>, dim3(lanes[l].n), dim3(256), 0, st, h->d_rb, lanes[l].bp, lanes[l].sp, B, 0);
+  }
   {
-    BatchPtrs bpi = bp;
-    bpi.live = nullptr;  // the init pass indexes the batch directly
+    BatchPtrs bpi = bp;  // the init pass indexes the batch directly
     if ((rc = launch_obstacle(h, st, bpi, sp, B, 0, 4, 1, false))) return rc;
+  }
+  if (L > 1) {
+    HIPCHK(h, hipEventRecord(h->lane_event[0], st));
+    for (int l = 0; l < L; ++l) HIPCHK(h, hipStreamWaitEvent(lanes[l].st, h->lane_event[0], 0));
   }
   // one round = evaluate the candidate trial trajectories of the instances in flight (obstacle kernel) +
   // accept/solve/new candidates (step kernel).  An instance may start late: enough rounds for every position to serve its
   // share one after the other.
-  const int max_rounds = ((B + W - 1) / W + 1) * (sp.max_iter + 2);
-  int known_done = 0, seen_round = -1;
-  int k_prev = 1;  // candidates per instance the last step launch may have generated
-  bool items_ready = false, pb_off = false;
-  auto read_progress = [&]() {
-    const unsigned long long p0 = __atomic_load_n(h->h_progress, __ATOMIC_RELAXED), p1 = __atomic_load_n(h->h_progress + 1, __ATOMIC_RELAXED);
-    if ((unsigned)(p0 >> 32) == h->progress_tag) known_done = std::max(known_done, (int)(p0 & 0xffffffffull));
-    if ((unsigned)(p1 >> 32) == h->progress_tag) seen_round = std::max(seen_round, (int)(p1 & 0xffffffffull));
+  auto read_progress = [&](LaneCtx& ln) {
+    const unsigned long long p0 = __atomic_load_n(ln.h_prog, __ATOMIC_RELAXED), p1 = __atomic_load_n(ln.h_prog + 1, __ATOMIC_RELAXED);
+    if ((unsigned)(p0 >> 32) == h->progress_tag) ln.known_done = std::max(ln.known_done, (int)(p0 & 0xffffffffull));
+    if ((unsigned)(p1 >> 32) == h->progress_tag) ln.seen_round = std::max(ln.seen_round, (int)(p1 & 0xffffffffull));
   };
   // naps of the throttle below: tens of microseconds, which the default timer slack of a thread (50 us) would double
   const int old_slack = prctl(PR_GET_TIMERSLACK);
   if (old_slack > 1000) (void)prctl(PR_SET_TIMERSLACK, 1000UL);
   int rc_loop = GTO_OK;
-  for (int k = 0; k <= max_rounds; ++k) {
-    // instances in flight, as far as the host knows (the finished-counter it has seen is a few rounds old: an upper bound)
-    read_progress();
-    int in_flight = std::min(W, B - known_done);
-    bool few = in_flight <= h->few_instances;
-    // throttle: never more than `ahead` rounds in front of the last step launch seen running, so that the launches stay
-    // sized to what is left and the empty rounds after the last instance finishes stay few; the queue never drains
-    // (sleep-poll, not a blocking wait: the runtime spins in those, one host core per lane)
-    const int ahead = few ? h->ahead_few : h->ahead;
-    for (long naps = 0; k - seen_round > ahead + 1; ++naps) {
-      std::this_thread::sleep_for(std::chrono::microseconds(few ? 10 : 50));
-      read_progress();
-      if ((naps & 1023) == 1023) {  // a stream that went idle or failed without reaching the round: do not wait for ever
-        const hipError_t qe = hipStreamQuery(st);
-        if (qe != hipErrorNotReady) {
-          read_progress();
-          if (k - seen_round > ahead + 1) {
-            h->err = qe == hipSuccess ? "solve loop: the stream went idle before the rounds it was given ran" : std::string("solve loop: ") + hipGetErrorString(qe);
-            rc_loop = GTO_ERR_HIP;
-            break;
-          }
-        }
-      }
-    }
-    if (rc_loop) break;
-    if (known_done >= B) break;
-    in_flight = std::min(W, B - known_done);
-    few = in_flight <= h->few_instances;
+  const auto tp_start = std::chrono::steady_clock::now();
+  // one round of lane ln: returns GTO_OK or an error
+  auto enqueue_round = [&](LaneCtx& ln, int lane_index) -> int {
+    const int k = ln.k;
+    const int in_flight = std::min(ln.room, ln.n_resp - ln.known_done);
+    const bool few = in_flight <= h->few_instances;
+    if (few && !ln.few_us) ln.few_us = (long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - tp_start).count();
     const int tg = few ? h->obs_tg_few : h->obs_tg;
-    sp.interleave = h->obs_interleave == 1 || (h->obs_interleave == 2 && few);
-    const bool itemized = items_ready && !few;
-    items_ready = false;
-    sp.round = k;
-    sp.parity = k & 1;
+    SolveParams& lsp = ln.sp;
+    lsp.interleave = h->obs_interleave == 1 || (h->obs_interleave == 2 && few);
+    const bool itemized = ln.items_ready && !few;
+    ln.items_ready = false;
+    lsp.round = k;
+    lsp.parity = k & 1;
     // the goal workgroups skip fresh instances themselves: k_lm_init already produced the seed's goal terms
-    sp.k_eval = k_prev;
-    if ((rc = launch_obstacle(h, st, bp, sp, B, 2, T - 2, 0, h->profiling, true, in_flight * k_prev, tg, few && h->obs_deep && in_flight <= h->obs_deep_max, itemized))) { rc_loop = rc; break; }
+    lsp.k_eval = ln.k_prev;
+    int rc_;
+    if ((rc_ = launch_obstacle(h, ln.st, ln.bp, lsp, B, 2, T - 2, 0, h->profiling, true, in_flight * ln.k_prev, tg, few && h->obs_deep && in_flight <= h->obs_deep_max, itemized))) return rc_;
     if (h->np == GTO_NB) {
       if (few && h->step_nw_few == 8) {
         // few instances in flight: eight waves per instance and candidate trial points ahead of their evaluation
         const int k_budget = std::max(1, h->spec_jobs / std::max(1, in_flight));
-        sp.k_acc = in_flight <= std::min(h->spec_deep, h->spec_few) ? std::min(std::min(h->spec_acc, k_budget), h->spec_kmax) : 1;
-        sp.k_rej = in_flight <= h->spec_few ? std::min(std::max(std::min(h->spec_rej, k_budget), h->spec_rej_few), h->spec_kmax) : 1;
-        const int kl = std::max(sp.k_acc, sp.k_rej);
-        sp.pb_next = 0;
-        if (h->profiling && (rc = prof_begin(h, st, GTO_PROF_STEP_FEW, in_flight))) { rc_loop = rc; break; }
-        hipLaunchKernelGGL((k_lm_step<8, GTO_KSPEC>), dim3(in_flight), dim3(512), lm_lds_bytes(T, kl), st, h->d_rb, h->d_pbchunks, bp, sp, B);
-        if (h->profiling && (rc = prof_end(h, st))) { rc_loop = rc; break; }
-        k_prev = kl;
+        lsp.k_acc = in_flight <= std::min(h->spec_deep, h->spec_few) ? std::min(std::min(h->spec_acc, k_budget), h->spec_kmax) : 1;
+        lsp.k_rej = in_flight <= h->spec_few ? std::min(std::max(std::min(h->spec_rej, k_budget), h->spec_rej_few), h->spec_kmax) : 1;
+        const int kl = std::max(lsp.k_acc, lsp.k_rej);
+        lsp.pb_next = 0;
+        if (h->profiling && (rc_ = prof_begin(h, ln.st, GTO_PROF_STEP_FEW, in_flight))) return rc_;
+        hipLaunchKernelGGL((k_lm_step<8, GTO_KSPEC>), dim3(in_flight), dim3(512), lm_lds_bytes(T, kl), ln.st, h->d_rb, h->d_pbchunks, ln.bp, lsp, B);
+        if (h->profiling && (rc_ = prof_end(h, ln.st))) return rc_;
+        ln.k_prev = kl;
       } else {
-        sp.k_acc = sp.k_rej = 1;
+        lsp.k_acc = lsp.k_rej = 1;
+        const bool pb_ok = pb_able && std::min(ln.W, ln.n) > h->few_instances;
         // a call in which the broad phase settles next to nothing (a robot inside a shelf) stops running it: the last
         // itemized round the host has seen listed more than 1 - GTO_PB_MIN_GAIN of its (job, group) pairs
-        if (pb_ok && !pb_off && !sp.pb_verify) {
-          const unsigned long long p2 = __atomic_load_n(h->h_progress + 2, __ATOMIC_RELAXED);
+        if (pb_ok && !ln.pb_off && !lsp.pb_verify) {
+          const unsigned long long p2 = __atomic_load_n(ln.h_prog + 2, __ATOMIC_RELAXED);
           if ((unsigned)(p2 >> 32) == h->progress_tag) {
             const double jobs_seen = (double)((p2 >> 20) & 0xfffull), items_seen = (double)(p2 & 0xfffffull);
-            if (jobs_seen > 0 && items_seen > 0 && jobs_seen < 4095 && k >= 12 && items_seen > (1.0 - h->pb_min_gain) * jobs_seen * pb_ng) pb_off = true;
+            if (jobs_seen > 0 && items_seen > 0 && jobs_seen < 4095 && k >= 12 && items_seen > (1.0 - h->pb_min_gain) * jobs_seen * pb_ng) ln.pb_off = true;
           }
         }
-        sp.pb_next = pb_ok && !pb_off && !few;
-        if (h->profiling && (rc = prof_begin(h, st, GTO_PROF_STEP, in_flight))) { rc_loop = rc; break; }
-        hipLaunchKernelGGL((k_lm_step<4, 1>), dim3(in_flight), dim3(256), h->lm_lds, st, h->d_rb, h->d_pbchunks, bp, sp, B);
-        if (h->profiling && (rc = prof_end(h, st))) { rc_loop = rc; break; }
-        k_prev = 1;
-        items_ready = sp.pb_next != 0;
+        lsp.pb_next = pb_ok && !ln.pb_off && !few;
+        if (h->profiling && (rc_ = prof_begin(h, ln.st, GTO_PROF_STEP, in_flight))) return rc_;
+        hipLaunchKernelGGL((k_lm_step<4, 1>), dim3(in_flight), dim3(256), h->lm_lds, ln.st, h->d_rb, h->d_pbchunks, ln.bp, lsp, B);
+        if (h->profiling && (rc_ = prof_end(h, ln.st))) return rc_;
+        ln.k_prev = 1;
+        ln.items_ready = lsp.pb_next != 0;
       }
     } else {
-      if (h->profiling && (rc = prof_begin(h, st, GTO_PROF_STEP, in_flight))) { rc_loop = rc; break; }
-      hipLaunchKernelGGL(k_lm_step_wide<16>, dim3(in_flight), dim3(GTO_WIDE_NT), h->lm_lds, st, h->d_rb, bp, sp, B, (double*)h->zws.p);
-      if (h->profiling && (rc = prof_end(h, st))) { rc_loop = rc; break; }
+      if (h->profiling && (rc_ = prof_begin(h, ln.st, GTO_PROF_STEP, in_flight))) return rc_;
+      hipLaunchKernelGGL(k_lm_step_wide<16>, dim3(in_flight), dim3(GTO_WIDE_NT), h->lm_lds, ln.st, h->d_rb, ln.bp, lsp, B,
+                         (double*)h->zws.p + (size_t)lane_zws[lane_index] * (T - 2) * h->np * h->np);
+      if (h->profiling && (rc_ = prof_end(h, ln.st))) return rc_;
+    }
+    ln.k++;
+    return GTO_OK;
+  };
+  // One host thread per lane (lane 0: the caller's), as many as the call has lanes: a round of a lane with few instances
+  // in flight lasts 25-50 us and takes two launches to enqueue, which one thread cannot do for four lanes.
+  struct Handover { int lane, parity, count, k_prev; };
+  std::mutex mu;                     // hand-over requests, the error string, the profiling records
+  std::vector<Handover> requests;
+  int reserved = 0;                  // instances granted to lane 0 whose k_adopt it has not enqueued yet
+  std::atomic<int> rem0_pub{lanes[0].n}, others_open{L - 1}, failed{0};
+  const int adopt_limit = std::min(h->few_instances, lanes[0].cap);
+  h->prof_mu = L > 1 ? &mu : nullptr;
+  // waits until lane ln may enqueue its next round (throttle: never more than `ahead` rounds in front of the last step
+  // launch seen running, so that the launches stay sized to what is left and the empty rounds after the last instance
+  // finishes stay few; sleep-poll, not a blocking wait: the runtime spins in those, one host core per lane)
+  auto throttle = [&](LaneCtx& ln) -> int {
+    for (long naps = 0;; ++naps) {
+      read_progress(ln);
+      const bool few = std::min(ln.room, ln.n_resp - ln.known_done) <= h->few_instances;
+      if (ln.k - ln.seen_round <= (few ? h->ahead_few : h->ahead) + 1 || failed.load(std::memory_order_relaxed)) return GTO_OK;
+      std::this_thread::sleep_for(std::chrono::microseconds(few ? 10 : 50));
+      if ((naps & 1023) == 1023) {  // a stream that went idle or failed without reaching the round: do not wait for ever
+        const hipError_t qe = hipStreamQuery(ln.st);
+        if (qe != hipErrorNotReady) {
+          read_progress(ln);
+          if (ln.k - ln.seen_round > (few ? h->ahead_few : h->ahead) + 1) {
+            std::lock_guard<std::mutex> g(mu);
+            h->err = qe == hipSuccess ? "solve loop: the stream went idle before the rounds it was given ran" : std::string("solve loop: ") + hipGetErrorString(qe);
+            return GTO_ERR_HIP;
+          }
+        }
+      }
+    }
+  };
+  auto lane_main = [&](int l) {
+    LaneCtx& ln = lanes[l];
+    (void)hipSetDevice(h->device);
+    const int old_slack_ = prctl(PR_GET_TIMERSLACK);
+    if (l > 0 && old_slack_ > 1000) (void)prctl(PR_SET_TIMERSLACK, 1000UL);
+    int rc_ = GTO_OK;
+    for (;;) {
+      if (failed.load(std::memory_order_relaxed)) break;
+      if ((rc_ = throttle(ln))) break;
+      int remaining = ln.n_resp - ln.known_done;
+      if (l == 0) {
+        // hand-overs granted since the last round: behind the lane's last launch (its event) and behind this lane's
+        {
+          std::lock_guard<std::mutex> g(mu);
+          for (const Handover& r : requests) {
+            LaneCtx& src = lanes[r.lane];
+            if (hipStreamWaitEvent(ln.st, h->lane_event[r.lane], 0) != hipSuccess) { h->err = "solve loop: hand-over between lanes failed"; rc_ = GTO_ERR_HIP; break; }
+            hipLaunchKernelGGL(k_adopt, dim3(1), dim3(256), 0, ln.st, src.bp, r.parity, ln.bp, ln.k & 1, kcap, T * nF, src.n_resp, r.count);
+            ln.n_resp += r.count;
+            ln.room = std::min(ln.cap, ln.room + r.count);
+            ln.k_prev = std::max(ln.k_prev, r.k_prev);
+            ln.items_ready = false;
+            reserved -= r.count;
+          }
+          requests.clear();
+          remaining = ln.n_resp - ln.known_done;
+          rem0_pub.store(std::max(0, remaining), std::memory_order_relaxed);
+        }
+        if (rc_) break;
+        if (remaining <= 0) {
+          if (others_open.load(std::memory_order_acquire) == 0) {
+            std::lock_guard<std::mutex> g(mu);
+            if (requests.empty()) break;
+            continue;
+          }
+          std::this_thread::sleep_for(std::chrono::microseconds(10));
+          continue;
+        }
+      } else {
+        if (remaining <= 0) break;
+        // hand-over: everything this lane has left is in flight (remaining <= W) and few, and lane 0 has room
+        if (h->adopt_below > 0 && remaining <= h->adopt_below && remaining <= ln.W && ln.k > 0) {
+          std::lock_guard<std::mutex> g(mu);
+          const int rem0 = rem0_pub.load(std::memory_order_relaxed);
+          if (rem0 <= lanes[0].W && rem0 + reserved + remaining <= adopt_limit) {
+            if (hipEventRecord(h->lane_event[l], ln.st) != hipSuccess) { h->err = "solve loop: hand-over between lanes failed"; rc_ = GTO_ERR_HIP; break; }
+            reserved += remaining;
+            requests.push_back({l, ln.k & 1, remaining, ln.k_prev});
+            ln.handed = true;
+            break;
+          }
+        }
+      }
+      const int max_rounds = ((ln.n_resp + ln.W - 1) / std::max(1, ln.W) + 1) * (sp.max_iter + 2) + 8;
+      if (ln.k > max_rounds) {
+        std::lock_guard<std::mutex> g(mu);
+        h->err = "solve loop: a lane ran out of rounds";
+        rc_ = GTO_ERR_HIP;
+        break;
+      }
+      if ((rc_ = enqueue_round(ln, l))) break;
+    }
+    if (rc_) failed.store(rc_, std::memory_order_relaxed);
+    ln.end_us = (long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - tp_start).count();
+    if (l > 0) {
+      others_open.fetch_sub(1, std::memory_order_release);
+      if (old_slack_ > 1000) (void)prctl(PR_SET_TIMERSLACK, (unsigned long)old_slack_);
+    }
+  };
+  {
+    static const bool lane_dbg = getenv("GTO_LANE_DEBUG") != nullptr;
+    const auto tp0 = std::chrono::steady_clock::now();
+    std::vector<std::thread> workers;
+    for (int l = 1; l < L; ++l) workers.emplace_back(lane_main, l);
+    const auto tp1 = std::chrono::steady_clock::now();
+    lane_main(0);
+    const auto tp2 = std::chrono::steady_clock::now();
+    for (auto& w : workers) w.join();
+    const auto tp3 = std::chrono::steady_clock::now();
+    if (lane_dbg) {
+      auto us = [](auto a, auto b) { return (long)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count(); };
+      fprintf(stderr, "[gto lanes] B %d L %d: threads started %ld us | lane 0 returned %ld us | joined %ld us | rounds", B, L, us(tp0, tp1), us(tp0, tp2), us(tp0, tp3));
+      for (int l = 0; l < L; ++l) fprintf(stderr, " %d%s@%ld(few@%ld)", lanes[l].k, lanes[l].handed ? "h" : "", lanes[l].end_us, lanes[l].few_us);
+      fprintf(stderr, "\n");
     }
   }
+  h->prof_mu = nullptr;
+  rc_loop = failed.load();
+  // the other lanes' work is behind the finalisation on the caller's stream
+  for (int l = 0; l < L && L > 1 && !rc_loop; ++l)
+    if (!lanes[l].handed) {
+      if (hipEventRecord(h->lane_event[l], lanes[l].st) != hipSuccess || hipStreamWaitEvent(st, h->lane_event[l], 0) != hipSuccess) {
+        h->err = "solve loop: joining the lanes failed";
+        rc_loop = GTO_ERR_HIP;
+      }
+    }
+  if (rc_loop)  // leave nothing of this call running on streams the caller does not know about
+    for (int l = 0; l < L && L > 1; ++l) (void)hipStreamSynchronize(lanes[l].st);
+  bp.live = lanes[0].bp.live, bp.cap = lanes[0].bp.cap;  // (what the debug print below and k_lm_finalize see: lists are not read there)
   if (old_slack > 1000) (void)prctl(PR_SET_TIMERSLACK, (unsigned long)old_slack);
   if (rc_loop) return rc_loop;
   hipLaunchKernelGGL(k_lm_finalize, dim3(B), dim3(64), 0, st, h->d_rb, bp, sp, B, Q_out, dQ_out, cost_out, iters_out, status_out);

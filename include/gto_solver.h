@@ -247,6 +247,26 @@ int gto_solve_base_batch(gto_handle* h, int32_t B, int32_t n_max, const int32_t*
 int gto_set_mode(gto_handle* h, int32_t mode);
 
 /*
+ * Lanes of a solve call.  gto_solve_batch / gto_solve_batch_device deal the instances of a call to up to `max_lanes`
+ * lanes (contiguous ranges of at least `min_per_lane` instances; default 4 and 256), each with a HIP stream and lists
+ * of its own over the one workspace of the call, fed round-robin by the calling thread: one lane's evaluation launch
+ * overlaps another's step launch while the GPU is full.  A lane with at most `adopt_below` instances left (default 48;
+ * 0: never) hands them to lane 0, which runs the stragglers of the whole call as one chain of launches.  Lane 0 runs on
+ * the handle's stream (the `stream` argument of gto_solve_batch_device); the call's results are ordered behind all
+ * lanes on that stream.  Results do not depend on any of the three numbers (tests/test_gpu_parity.py).  The reference
+ * has no counterpart: gto/gto_planner.py:185-245 solves one instance per call.
+ */
+int gto_set_lanes(gto_handle* h, int32_t max_lanes, int32_t min_per_lane, int32_t adopt_below);
+/*
+ * The lanes' streams.  By default the handle creates a non-blocking stream per lane.  The runtime deals streams to a few
+ * hardware queues (GPU_MAX_HW_QUEUES, default 4) and the queues to the dispatcher's pipes; which stream lands where
+ * depends on every stream the process has created, and two lanes behind one pipe run 1.5x slower.  A caller that manages
+ * its streams (torch.cuda.Stream, one per lane) hands them over here: lane l of every following call runs on streams[l]
+ * (n = 0: the handle's own again).  The streams stay the caller's; they must outlive the calls.
+ */
+int gto_set_lane_streams(gto_handle* h, int32_t n, void* const* streams);
+
+/*
  * Bind the handle to the caller's HIP stream (e.g. torch.cuda.current_stream().cuda_stream): every
  * launch and copy of every entry point then goes to that stream and the handle creates none of its
  * own.  NULL gives the handle a private non-blocking stream again (the state after gto_create).

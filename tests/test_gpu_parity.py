@@ -402,6 +402,31 @@ def test_launch_geometry_does_not_change_results(capi, oracle_mod, monkeypatch, 
     h.close()
 
 
+@pytest.mark.parametrize("robot,B,T", [("panda", 96, 50), ("fetch", 40, 30), ("fetch_mobile", 24, 20)])
+def test_lanes_of_a_call_do_not_change_results(capi, oracle_mod, robot, B, T):
+    """gto_set_lanes: the instances of a call dealt to several lanes (streams and lists of their own over one workspace,
+    one host thread), and the lanes' last instances handed to lane 0 (k_adopt), are scheduling: every instance gets
+    bit-for-bit the trajectory, cost, iteration count and status of the call that runs as one lane.  Covered: uneven
+    ranges, more lanes than the GPU has hardware queues, hand-over of everything at once (adopt_below >= a lane's share)
+    and of the last stragglers only, no hand-over, the wide step kernel (position-indexed scratch per lane), a second call
+    on the same handle with other lane settings (buffers are re-dealt)."""
+    prob = Problem(robot, B=B, scene_seed=3, T=T, n_goals=2 if robot == "panda" else 1)
+    opts = oracle_mod.reference_opts(T=T, standoff_offset=-max(2, T // 5), max_iter=40)
+    h = capi.SolverHandle(prob.desc, prob.cfg["link_ee"], prob.cfg["link_gripper"], opts, device=0)
+    prob.finish(h.eval_fk)
+    h.set_scene(*prob.scene_args())
+    h.set_lanes(1, 1, 0)
+    ref = h.solve_batch(*prob.solve_args())
+    assert len(set(ref[3].tolist())) > 2  # iteration counts differ: lanes empty at different times
+    for lanes, per_lane, adopt in ((4, 8, 0), (4, 8, 6), (3, 7, 1000), (8, 1, 3), (2, B // 2, 2), (4, 8, 1)):
+        h.set_lanes(lanes, per_lane, adopt)
+        for _ in range(2):
+            got = h.solve_batch(*prob.solve_args())
+            for a, b in zip(ref, got):
+                np.testing.assert_array_equal(a, b)
+    h.close()
+
+
 @pytest.mark.parametrize("mode", [0])
 @pytest.mark.parametrize("robot", ["panda", "fetch"])
 def test_hip_lm_ends_where_lbfgsb_ends(capi, oracle_mod, robot, mode):
