@@ -27,6 +27,7 @@
 
 static std::string g_create_error;
 
+#define GTO_SWEEP_WGS 64   // workgroups of the crew behind an itemized obstacle launch laid out over an estimate (launch_obstacle)
 #define GTO_MAX_LANES 8  // lanes of one solve call (streams, list sets, progress words)
 
 struct DevBuf {
@@ -122,6 +123,11 @@ struct gto_handle {
   hipEvent_t lane_event[GTO_MAX_LANES] = {};
   hipStream_t user_lane_stream[GTO_MAX_LANES] = {};  // gto_set_lane_streams: the caller's streams for the lanes
   int n_user_lane_streams = 0;
+  // items (job, group pairs with something to gather) per evaluation job: the largest ratio the rounds of the last call
+  // published (the prior of the next call's launches until its own counts arrive), and of the call that is running
+  double items_per_job_prior = 0.0, items_per_job_call = 0.0;
+  int item_hint_forced = 0;  // GTO_ITEM_HINT: the estimate itself (tests of the crew)
+  int item_grid = 1;  // GTO_ITEM_GRID=0: itemized launches laid out over the upper bound of their item lists
   std::mutex* prof_mu = nullptr;  // set while a call with several lanes (host threads) runs: guards the profiling records
 };
 
@@ -249,6 +255,8 @@ int gto_create(const gto_robot_desc* d, const gto_solver_opts* opts, int device,
   if (const char* e = getenv("GTO_DIST_RELAX")) h->dist_relax = atoi(e) ? 1 : 0;
   if (const char* e = getenv("GTO_DEBUG_CUT")) h->dbg_cut = atoi(e);
   if (h->dbg_cut) fprintf(stderr, "[gto] WARNING: GTO_DEBUG_CUT=%d cuts the obstacle kernel short: timing experiments only, RESULTS ARE GARBAGE\n", h->dbg_cut);
+  if (const char* e = getenv("GTO_ITEM_GRID")) h->item_grid = atoi(e) != 0;
+  if (const char* e = getenv("GTO_ITEM_HINT")) h->item_hint_forced = std::max(0, atoi(e));
   if (const char* e = getenv("GTO_SLOTS")) h->slots = std::max(1, atoi(e));
   if (const char* e = getenv("GTO_LANES")) h->lanes_max = std::max(1, std::min(GTO_MAX_LANES, atoi(e)));
   if (const char* e = getenv("GTO_LANE_MIN")) h->lane_min = std::max(1, atoi(e));
@@ -608,6 +616,7 @@ int gto_create(const gto_robot_desc* d, const gto_solver_opts* opts, int device,
     if ((size_t)lay.total_doubles * sizeof(double) > 150 * 1024) { gto_destroy(h); return fail(nullptr, GTO_ERR_UNSUPPORTED, "robot too large for the obstacle kernel's LDS"); }
     hipError_t e1 = raise_dynamic_lds(w ? (const void*)k_obstacle_gram<16> : (const void*)k_obstacle_gram<GTO_NB>, lds);
     if (!w && e1 == hipSuccess) e1 = raise_dynamic_lds((const void*)k_obstacle_gram<GTO_NB, GTO_OBS_DEEP_PD>, lds);
+    if (!w && e1 == hipSuccess) e1 = raise_dynamic_lds((const void*)k_obstacle_gram<GTO_NB, GTO_OBS_MAIN_PD, true>, lds);
     hipError_t e2 = w ? raise_dynamic_lds((const void*)k_lm_step_wide<16>, h->lm_lds) : raise_dynamic_lds((const void*)k_lm_step<4, 1>, h->lm_lds);
     if (!w && e2 == hipSuccess) e2 = raise_dynamic_lds((const void*)k_lm_step<8, GTO_KSPEC>, lm_lds_bytes(opts->T, h->spec_kmax));
     if (e1 != hipSuccess || e2 != hipSuccess) {
@@ -1068,13 +1077,19 @@ static int prof_end(gto_handle* h, hipStream_t st) {
 
 static int launch_obstacle(gto_handle* h, hipStream_t st, const BatchPtrs& bp, const SolveParams& sp, int B, int t_begin,
                            int nT, int fixed_mode, bool timed, bool with_goal_terms = false, int n_jobs = 0, int tg = 0, bool deep = false,
-                           bool itemized = false) {
+                           bool itemized = false, int items_hint = 0) {
   // waypoints per workgroup: groups of h->obs_tg (the two pinned waypoints form one group)
   const int TG = fixed_mode ? 1 : std::max(1, std::min(tg > 0 ? tg : h->obs_tg, nT));  // the init pass has 4 virtual waypoints
   const ObsGeom geo(h->rb.n_cframes, h->rb.n_frames, h->rb.fk_rounds_c, h->rb.n_links, h->rb.n_opt, h->rb.n_chunks, TG, nT, h->np);
   const int nG = geo.nG;
   const int nb = n_jobs > 0 ? n_jobs : B;  // workgroups are laid out for the evaluation jobs there can be; B stays the batch (strides)
-  const int n_regular = obstacle_grid(nb, nG);
+  int n_regular = obstacle_grid(nb, nG);
+  // Itemized launches: laid out over the caller's estimate of the item list's length instead of its upper bound (nine
+  // tenths of the workgroups of the upper bound find no item and leave; they cost the other lanes' launches dispatch
+  // slots: +7 % trajectories/s without them); a crew of GTO_SWEEP_WGS workgroups behind the launch walks whatever the
+  // estimate missed (the kernel's SWEEP variant), so the result does not depend on it.
+  const bool sweep = itemized && items_hint > 0 && items_hint + GTO_SWEEP_WGS < n_regular && bp.live != nullptr && !fixed_mode && !deep && h->np == GTO_NB;  // (the wide robots' launches are never itemized)
+  if (sweep) n_regular = 8 * ((items_hint + 7) / 8);
   const size_t lds = (size_t)geo.lay.total_doubles * sizeof(double);
   const dim3 grid(n_regular + (with_goal_terms ? 8 * ((nb + 31) / 32) : 0));  // goal-term jobs: four to a workgroup, in front, a multiple of eight workgroups
   const bool deep_v = h->np == GTO_NB && deep;
@@ -1094,13 +1109,17 @@ static int launch_obstacle(gto_handle* h, hipStream_t st, const BatchPtrs& bp, c
   const int32_t* nitems_par = listed && itemized ? bp.nlive + 8 + sp.parity : nullptr;
   if (h->np == GTO_NB && deep)  // few instances in flight: the variant that keeps a wave's record gathers in flight together
     hipLaunchKernelGGL((k_obstacle_gram<GTO_NB, GTO_OBS_DEEP_PD>), grid, dim3(256), lds, st, jobs_par, njobs_par, items_par, nitems_par, geo.nG, geo.m_nG, n_regular, B, h->d_rb, h->d_px, h->d_py, h->d_pz, h->d_chunks, h->d_scenes,
-                       bpl, sp, t_begin, nT, fixed_mode, geo);
+                       bpl, sp, t_begin, nT, fixed_mode, geo, 0);
   else if (h->np == GTO_NB)
     hipLaunchKernelGGL(k_obstacle_gram<GTO_NB>, grid, dim3(256), lds, st, jobs_par, njobs_par, items_par, nitems_par, geo.nG, geo.m_nG, n_regular, B, h->d_rb, h->d_px, h->d_py, h->d_pz, h->d_chunks, h->d_scenes, bpl, sp,
-                       t_begin, nT, fixed_mode, geo);
+                       t_begin, nT, fixed_mode, geo, 0);
   else
     hipLaunchKernelGGL(k_obstacle_gram<16>, grid, dim3(256), lds, st, jobs_par, njobs_par, items_par, nitems_par, geo.nG, geo.m_nG, n_regular, B, h->d_rb, h->d_px, h->d_py, h->d_pz, h->d_chunks, h->d_scenes, bpl, sp,
-                       t_begin, nT, fixed_mode, geo);
+                       t_begin, nT, fixed_mode, geo, 0);
+  if (sweep) {  // the crew: items n_regular, n_regular + 1, ... of the list, if there are any
+    hipLaunchKernelGGL((k_obstacle_gram<GTO_NB, GTO_OBS_MAIN_PD, true>), dim3(GTO_SWEEP_WGS), dim3(256), lds, st, jobs_par, njobs_par, items_par, nitems_par, geo.nG, geo.m_nG, GTO_SWEEP_WGS, B, h->d_rb, h->d_px, h->d_py, h->d_pz,
+                       h->d_chunks, h->d_scenes, bpl, sp, t_begin, nT, fixed_mode, geo, n_regular);
+  }
   if (timed) return prof_end(h, st);
   return GTO_OK;
 }
@@ -1162,6 +1181,7 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
     int n_resp = 0;                     // instances whose end this lane's finished-counter counts (own + adopted)
     int k = 0, known_done = 0, seen_round = -1, k_prev = 1;
     bool items_ready = false, pb_off = false, handed = false;
+    double ratio_max = 0.0;  // items per job, the largest the lane's rounds published
     long end_us = 0, few_us = 0;  // (GTO_LANE_DEBUG) when the lane's thread returned / enqueued its first few-instance round, from the start of the threads
     unsigned long long* h_prog = nullptr;
   };
@@ -1292,7 +1312,22 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
     // the goal workgroups skip fresh instances themselves: k_lm_init already produced the seed's goal terms
     lsp.k_eval = ln.k_prev;
     int rc_;
-    if ((rc_ = launch_obstacle(h, ln.st, ln.bp, lsp, B, 2, T - 2, 0, h->profiling, true, in_flight * ln.k_prev, tg, few && h->obs_deep && in_flight <= h->obs_deep_max, itemized))) return rc_;
+    // length of this round's item list, estimated: what the lane's step launches published last (a few rounds old; the
+    // list changes by a few per cent a round), or, until then, the previous call's ratio of items to jobs
+    int items_hint = 0;
+    if (itemized && h->item_grid) {
+      const unsigned long long p2 = __atomic_load_n(ln.h_prog + 2, __ATOMIC_RELAXED);
+      const int jobs_bound = in_flight * ln.k_prev;
+      if ((unsigned)(p2 >> 32) == h->progress_tag && (p2 & 0xfffffull) > 0 && (p2 & 0xfffffull) < 0xfffffull) {
+        const double items_seen = (double)(p2 & 0xfffffull), jobs_seen = (double)((p2 >> 20) & 0xfffull);
+        items_hint = (int)(1.5 * items_seen) + 256;
+        if (jobs_seen > 0 && jobs_seen < 4095) ln.ratio_max = std::max(ln.ratio_max, items_seen / jobs_seen);
+      } else if (h->items_per_job_prior > 0.0) {
+        items_hint = (int)(1.25 * h->items_per_job_prior * jobs_bound) + 256;
+      }
+      if (h->item_hint_forced > 0) items_hint = h->item_hint_forced;  // (tests: a launch of a few workgroups, the crew does the rest)
+    }
+    if ((rc_ = launch_obstacle(h, ln.st, ln.bp, lsp, B, 2, T - 2, 0, h->profiling, true, in_flight * ln.k_prev, tg, few && h->obs_deep && in_flight <= h->obs_deep_max, itemized, items_hint))) return rc_;
     if (h->np == GTO_NB) {
       if (few && h->step_nw_few == 8) {
         // few instances in flight: eight waves per instance and candidate trial points ahead of their evaluation
@@ -1452,6 +1487,11 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
   }
   h->prof_mu = nullptr;
   rc_loop = failed.load();
+  {
+    double r_ = 0.0;
+    for (int l = 0; l < L; ++l) r_ = std::max(r_, lanes[l].ratio_max);
+    if (r_ > 0.0) h->items_per_job_prior = r_;
+  }
   // the other lanes' work is behind the finalisation on the caller's stream
   for (int l = 0; l < L && L > 1 && !rc_loop; ++l)
     if (!lanes[l].handed) {

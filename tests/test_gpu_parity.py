@@ -294,7 +294,9 @@ def test_slots_hand_over_to_waiting_instances(capi, oracle_mod, monkeypatch, slo
 
 @pytest.mark.parametrize("env", [{"GTO_PREBROAD": "0"}, {"GTO_SLOTS": "96"}, {"GTO_SLOTS": "96", "GTO_PREBROAD": "0"},
                                  {"GTO_OBS_TG": "2"}, {"GTO_OBS_TG": "5"}, {"GTO_FEW_INSTANCES": "16"}, {"GTO_PB_MIN_GAIN": "2"},
-                                 {"GTO_SLOTS": "1", "GTO_FEW_INSTANCES": "0", "GTO_OBS_TG": "1"}])
+                                 {"GTO_SLOTS": "1", "GTO_FEW_INSTANCES": "0", "GTO_OBS_TG": "1"},
+                                 {"GTO_ITEM_GRID": "0"}, {"GTO_ITEM_HINT": "8"}, {"GTO_ITEM_HINT": "40", "GTO_SLOTS": "96"},
+                                 {"GTO_ITEM_HINT": "300", "GTO_OBS_TG": "2"}])
 def test_step_kernel_broad_phase_does_not_change_results(capi, oracle_mod, monkeypatch, env):
     """In the rounds that fill the GPU the step kernel tests the bounding spheres of its new trial trajectory itself
     (prebroad_tail: serial kinematics per lane instead of the obstacle kernel's matrix-core prefix), settles the waypoint
@@ -302,7 +304,10 @@ def test_step_kernel_broad_phase_does_not_change_results(capi, oracle_mod, monke
     laid out over the groups that are left.  Switching that off, refilling positions mid-call (96 positions for 160
     instances; one position and one waypoint per group: the item list at its shortest against the launch's rounding),
     changing the group size, or switching it off mid-call (GTO_PB_MIN_GAIN=2: after round 12) gives bit-for-bit
-    the same trajectories, costs and iteration counts; and they match the oracle, which culls nothing."""
+    the same trajectories, costs and iteration counts; and they match the oracle, which culls nothing.  The itemized launch
+    is laid out over an estimate of the list's length with a crew of 64 looping workgroups behind it for the rest
+    (GTO_ITEM_GRID=0: over the upper bound, no crew; GTO_ITEM_HINT: the estimate itself -- 8: the crew does nearly
+    everything, several items per workgroup)."""
     prob = Problem("panda_5k", B=160, scene_seed=5, n=64, res=0.035, n_goals=1)
     # (a call of 160 would run in the launches for few instances from its first round: the broad phase belongs to the others)
     monkeypatch.setenv("GTO_FEW_INSTANCES", "64")
