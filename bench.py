@@ -199,6 +199,21 @@ def main(argv=None, emit=True):
     mobile = args.robot.endswith("_mobile")      # BASELINE configs[4]: --robot fetch_mobile --T 80 --grid 256 --shelf
     default_pose = np.concatenate([np.zeros(ndof - len(cfg["default_pose"])), np.array(cfg["default_pose"], dtype=np.float64)])
     D, M = max(1, args.pipeline), max(1, args.merge)
+
+    def cpu_quota():
+        try:  # cgroup v2: "max 100000" or "<quota> <period>"
+            q_, p_ = open("/sys/fs/cgroup/cpu.max").read().split()
+            return None if q_ == "max" else round(int(q_) / int(p_), 2)
+        except Exception:
+            return None
+    # every lane is a host thread that sleep-polls two pinned words (about 0.2 of a core each at four lanes); N ranks x D
+    # lanes must fit the CPUs this cgroup may use, or the lanes' naps turn into scheduling delays on every rank
+    quota_ = cpu_quota()
+    lane_decision = f"{D} lanes per rank as asked for"
+    if world > 1 and quota_ is not None and quota_ < world * D:
+        D_new = max(1, min(D, int(quota_ // world)))
+        lane_decision = f"{D_new} lanes per rank: cgroup CPU quota {quota_} < {world} ranks x {D} lanes"
+        D = D_new
     slots = int(os.environ.get("GTO_SLOTS", "384"))  # instances a solver call keeps in flight (gto_api.hip)
     mode = _capi.SolverHandle.MODE_ROUNDS
     kernel_name = "k_obstacle_gram"
@@ -483,12 +498,6 @@ def main(argv=None, emit=True):
     # devices" and whether N x (lanes + polling host threads) fit the host: gathered from every rank
     collective = None
     if world > 1:
-        def cpu_quota():
-            try:  # cgroup v2: "max 100000" or "<quota> <period>"
-                q_, p_ = open("/sys/fs/cgroup/cpu.max").read().split()
-                return None if q_ == "max" else round(int(q_) / int(p_), 2)
-            except Exception:
-                return None
         try:
             bus = torch.cuda.get_device_properties(dev).pci_bus_id
         except Exception:
@@ -508,6 +517,7 @@ def main(argv=None, emit=True):
                       "nccl_version": nccl_v, "ranks": rows_,
                       "distinct_devices": len({(r_["device_index"], r_["pci_bus_id"]) for r_ in rows_}),
                       "cgroup_cpu_quota_cores": cpu_quota(), "host_hardware_threads": os.cpu_count(),
+                      "lanes_per_rank": D, "lane_decision": lane_decision,
                       "host_cpu_cores_busy_all_ranks": round(sum(r_["host_cpu_cores_busy"] for r_ in rows_), 2),
                       "data_path_collectives": "none inside the solve; one all_gather pair (float64 trajectories, int32 iterations/status) of the "
                                                "scene-sharded leg's results, two all_reduce of timings"}
@@ -595,6 +605,21 @@ def main(argv=None, emit=True):
         quality["gate"] = "pass" if gate_ok else "FAIL"
         if not gate_ok:
             rc = 3
+        # what the gate looks at and what it does not (printed, not part of the exit code): the goal thresholds of
+        # examples/pybullet_gto_planning.py:262 (1 cm / 5 deg) are missed by about a fifth of the SINGLE-goal instances --
+        # a property of the reference's objective weights (velocity 0.01 / dt^2 against a goal term that is a sum of 200
+        # squared point distances: the optimum trades a few millimetres of goal error for a shorter path), which the CPU
+        # port shares (cpu_baseline.goal_ok_frac on the same batch) and L-BFGS-B confirmed in round 2
+        # (profiles/r02_goal_miss_check.txt); with goal sets of eight (plan_goalset's call shape) 0.92 reach a goal
+        quality["gate_reasons"] = {
+            "checked": ["max_joint_limit_violation <= 1e-8", "objective_le_seed_frac == 1"] + ([] if args.light else [
+                "stopping tolerance costs a converged instance <= 1e-4 of its objective", "plan_cost_le_seed_frac >= 0.95 (table top)",
+                "central_diff leaves no more plans in collision than zero-gradient", "goal sets of 8 within the joint limits"]),
+            "reported_not_gated": {"goal_ok_frac": quality["goal_ok_frac"],
+                                   "goal_ok_frac_goal_sets_of_8": (quality.get("goal_sets_of_8") or {}).get("goal_ok_frac"),
+                                   "cause": "objective weights of gto/gto_planner.py:84-135 (velocity term against point-matching goal term): the "
+                                            "minimiser of the reference's own objective ends millimetres from a single goal; the CPU port ends at "
+                                            "the same trajectories (cpu_baseline.goal_ok_frac, max_abs_dQ_vs_gpu)"}}
 
         # roofline of the dominant kernel.  SURVEY.md 8d prices the reference's work at 7 float32 (28 B) per surface point
         # and free waypoint; the broad phase proves most of those gathers to be exact zeros and skips them, so only the
@@ -636,6 +661,14 @@ def main(argv=None, emit=True):
                 pm_ = pmc_variants.get(name_, {})
                 row.update({"traffic": pm_.get("hbm_bytes_per_launch"), "fetch_bytes_per_launch": pm_.get("fetch_bytes_per_launch"),
                             "bound": "latency (serial chain of 8x8 block eliminations per instance: DESIGN.md section 5)"})
+            pm_ = pmc_variants.get(name_, {})
+            # issue side of the same PMC passes: vector instructions x 4 cycles over every SIMD's cycles of the launch, waves per
+            # SIMD of the launch, share of the waves' lifetime spent waiting, LDS bank conflicts; and the stamped critical path
+            # of one workgroup (GTO_DEBUG_TIMING, tools/step_stamps.py) over the launch
+            for k_ in ("valu_issue_frac", "waves_per_simd", "waves_waiting_frac", "lds_bank_conflict_cycles_per_lds_inst", "l2_hit_rate",
+                       "critical_path_cycles", "critical_path_over_launch"):
+                if k_ in pm_:
+                    row[k_] = pm_[k_]
             by_variant[name_] = row
         dominant = max((n_ for n_ in by_variant if n_.startswith("k_obstacle")), key=lambda n_: variants[n_][0], default=None)
         if dominant:  # the headline figures are the dominant VARIANT's own (one population of launches)
@@ -652,6 +685,9 @@ def main(argv=None, emit=True):
                     "alg_bytes_skipped_frac": round(1.0 - gathered / max(full_points, 1.0), 4),
                     "avg_launch_us": round(avg_launch_us, 2), "launches": kern_launches_hl,
                     "variants": by_variant,
+                    # the kernel with the largest share of the solve loop's kernel time, whatever bounds it (the
+                    # step kernel, latency / issue bound: no byte model applies, its issue-side fractions are in its row)
+                    "dominant_by_time": (lambda n_: dict(by_variant[n_], kernel=n_))(max(by_variant, key=lambda n_: by_variant[n_]["share_of_solve_loop_kernel_time"])) if by_variant else None,
                     # the timed regime (all lanes in flight, where launches of different lanes stretch each other): the bytes
                     # gathered by the region's calls over the region's wall time
                     "timed_regime": {"alg_bytes_region": int(gathered * 28), "region_ms": round(1e3 * elapsed, 3),
@@ -768,6 +804,13 @@ def main(argv=None, emit=True):
 
         out = {
             "metric": "grasp trajectories/sec", "value": round(value, 2), "unit": "trajectories/s",
+            # which of the two rates `value` is: the device-resident entry point (inputs and outputs in HBM when the timed region
+            # starts and ends); SURVEY.md 8d's literal metric -- the host-pointer entry point with the per-instance H2D / D2H
+            # inside the timing -- is host_api.trajectories_per_s on the same line, measured on the same lanes and regions
+            "metric_definition": {"value": "gto_solve_batch_device: per-instance inputs and outputs resident in HBM (timed region = K steps, barrier + "
+                                           "synchronize on both sides; median of `timed_regions.repeats` regions)",
+                                  "survey_8d_literal": "host_api.trajectories_per_s: gto_solve_batch with host pointers, per-instance H2D / D2H inside the timed "
+                                                       "region, one-time scene upload excluded"},
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             # the timed region (exactly `steps` steps, barrier + synchronize on both sides) is run `repeats` times; value and

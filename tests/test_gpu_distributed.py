@@ -144,3 +144,28 @@ def test_bench_two_ranks_dry_run_on_one_device():
     assert ss["instances"] == 2 * 6 * 8 and ss["all_instances_returned"] and ss["own_shard_round_trip_exact"]
     assert ss["max_joint_limit_violation"] <= 1e-8
     assert d["pipeline"]["lane_results_reproducible_alone"] and d["quality"]["gate"] == "pass"
+
+
+def test_bench_eight_ranks_dry_run_on_one_device():
+    """The 8-rank code path without an 8-GPU box: bench.py as the driver launches it for N = 8, with
+    gloo and all eight ranks on the one device: spawn path, shard_by_scene over eight ranks (4 scenes each), the gather of
+    eight shards with every instance back in order and the rank's own shard bit-exact through the gather, the `collective`
+    object with eight rows and the lane decision (lanes per rank = min(asked, cgroup quota / ranks))."""
+    import json
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--backend", "gloo", "--same-device", "--steps", "4", "--warmup", "1",
+           "--merge", "1", "--repeats", "1", "--scenes-per-gpu", "4", "--no-cpu-baseline"]
+    res = subprocess.run(cmd, env=dict(os.environ, MASTER_ADDR="127.0.0.1"), capture_output=True, text=True, timeout=1500)
+    assert res.returncode == 0, (res.stdout + res.stderr)[-3000:]
+    d = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 8 and d["steps"] == 4 and d["scaling"] == "weak"
+    ss = d["scene_sharded"]
+    assert ss["instances"] == 8 * 4 * 8 and ss["all_instances_returned"] and ss["own_shard_round_trip_exact"]
+    assert ss["max_joint_limit_violation"] <= 1e-8
+    col = d["collective"]
+    assert col["world_size"] == 8 and len(col["ranks"]) == 8 and sorted(r["rank"] for r in col["ranks"]) == list(range(8))
+    assert 1 <= col["lanes_per_rank"] <= 4 and col["lane_decision"]
+    q = col["cgroup_cpu_quota_cores"]
+    if q is not None and q < 32:
+        assert col["lanes_per_rank"] == max(1, min(4, int(q // 8)))
+    assert col["host_cpu_cores_busy_all_ranks"] > 0
+    assert d["quality"]["gate"] == "pass"

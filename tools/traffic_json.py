@@ -12,11 +12,18 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 entries = []
 tag = sys.argv[1]
+stamps = {}
+sp_ = os.path.join(ROOT, "profiles", f"{tag}_step_stamps.json")
+if os.path.exists(sp_):
+    stamps = json.load(open(sp_)).get("variants", {})
 for d in sys.argv[2:]:
     size = int(os.path.basename(d.rstrip("/")).split("_")[-1])
     js = json.load(open(os.path.join(d, "pmc_summary.json")))
     # the variant for the launches that fill the GPU (the one the roofline is quoted on); the variant for few instances in flight only if there is no other
-    cands = [v for n, v in js.items() if "k_obstacle_gram<8, 1>" in n] or [v for n, v in js.items() if "k_obstacle_gram" in n]
+    # (names as the C ABI's profile reports them: the crew variant behind an itemized launch is a row of its own)
+    norm = lambda n: n.replace(", false>", ">").replace(", true>", ">crew").replace(", ", ",")
+    js = {norm(n): v for n, v in js.items()}
+    cands = [v for n, v in js.items() if n.startswith("k_obstacle_gram<8,1>") and "crew" not in n] or [v for n, v in js.items() if "k_obstacle_gram" in n]
     k = max(cands, key=lambda v: v.get("launches", 0) * v.get("mean_us", 0.0))
     us = k["mean_us"]
     variants = {}
@@ -29,7 +36,16 @@ for d in sys.argv[2:]:
                 "l2_hit_rate": round(v_.get("TCC_HIT_sum", 0.0) / max(v_.get("TCC_REQ_sum", 1.0), 1.0), 3),
                 "waves_waiting_frac": round(v_.get("SQ_WAIT_ANY", 0.0) / max(v_.get("SQ_WAVE_CYCLES", 1.0), 1.0), 3),
                 "valu_insts_per_launch": int(v_.get("SQ_INSTS_VALU", 0)), "salu_insts_per_launch": int(v_.get("SQ_INSTS_SALU", 0)),
-                "mfma_insts_per_launch": int(v_.get("SQ_INSTS_MFMA", 0))}
+                "mfma_insts_per_launch": int(v_.get("SQ_INSTS_MFMA", 0)),
+                # issue side: vector instructions x 4 cycles over the cycles of all 1024 SIMDs during the launch; waves of the launch
+                # per SIMD; LDS bank-conflict cycles per LDS instruction
+                "valu_issue_frac": round(4 * v_.get("SQ_INSTS_VALU", 0.0) / max(1024 * v_.get("mean_us", 0.0) * 1e-6 * 2.4e9, 1.0), 4),
+                "waves_per_simd": round(v_.get("SQ_WAVES", 0.0) / 1024.0, 3),
+                "lds_bank_conflict_cycles_per_lds_inst": round(v_.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(v_.get("SQ_INSTS_LDS", 1.0), 1.0), 3)}
+            st_ = stamps.get(n_.replace(", ", ","))
+            if st_:  # stamped critical path of one workgroup (tools/step_stamps.py) over the launch's duration in the same ticks
+                variants[n_.replace(", ", ",")]["critical_path_cycles"] = st_["critical_path_cycles"]
+                variants[n_.replace(", ", ",")]["critical_path_over_launch"] = round(st_["critical_path_cycles"] / max(v_.get("mean_us", 0.0) * st_["ticks_per_us"], 1.0), 3)
     simd_cycles = 1024 * us * 1e-6 * 2.4e9  # 256 CUs x 4 SIMDs at 2.4 GHz
     entries.append({
         "robot": "panda_5k", "grid": 128, "mode": "rounds", "instances_per_call": size, "slots": 384,
