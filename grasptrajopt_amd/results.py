@@ -85,3 +85,42 @@ def summarize(results_scene: dict, in_collision: Optional[Callable[[str, str, st
     mean = {k: (sums[k] / counts[k] if counts[k] else None) for k in TIME_KEYS}
     return {"per_object": per_object, "total_success": total_success, "total_collision": total_collision,
             "total_trial": trials, "mean_time": mean, "total_time": sum(v for v in mean.values() if v is not None)}
+
+
+def plan_shape_statistics(plans, opt_index, lower, upper, standoff_waypoint=None) -> Dict[str, np.ndarray]:
+    """Per-plan statistics of joint trajectories `plans` (n, ndof, T) that need nothing but the plan itself -- what can be
+    compared between the reference's stored plans (examples/results_iros2024/*.json: outputs without their inputs) and plans
+    solved here on other inputs (tests/test_plan_statistics_cpu.py).  The reference's objective
+    (gto/gto_planner.py:84-135) has a velocity term, a goal term at the last waypoint and a standoff term at waypoint
+    T + standoff_offset; its minimiser in joint space is two constant-speed stretches joined at the standoff waypoint.
+      v0           speed of the first step over the plan's mean speed (initial velocity is constrained to zero)
+      cv_pre/post  coefficient of variation of the step lengths before / after the standoff waypoint (0: constant speed)
+      plateau      mean step length before over mean step length after the standoff waypoint
+      pre_share    share of the joint-space path length covered before the standoff waypoint
+      path_ratio   joint-space path length over the distance between the first and the last configuration (>= 1)
+      chord_dev    largest distance of the waypoints before the standoff waypoint from the straight line between the first free
+                   waypoint and the standoff waypoint, over that line's length (0: a straight line in joint space)
+      on_bound     share of waypoints with an optimised joint within 1e-6 of a limit"""
+    P = np.asarray(plans, dtype=np.float64)
+    o = np.asarray(opt_index)
+    Q = P[:, o, :]
+    T = Q.shape[2]
+    ts = T - 10 if standoff_waypoint is None else int(standoff_waypoint)  # reference: standoff_offset = -10
+    step = np.linalg.norm(np.diff(Q, axis=2), axis=1)  # (n, T - 1)
+    tiny = 1e-300
+    pre, post = step[:, 1:ts - 1], step[:, ts + 1:T - 2]
+    L = step.sum(axis=1)
+    a, b = Q[:, :, 1], Q[:, :, ts]
+    tt = np.linspace(0.0, 1.0, ts)
+    chord = a[:, :, None] + (b - a)[:, :, None] * tt[None, None, :]
+    lo, hi = np.asarray(lower)[None, :, None], np.asarray(upper)[None, :, None]
+    return {
+        "v0": step[:, 0] / np.maximum(step.mean(axis=1), tiny),
+        "cv_pre": pre.std(axis=1) / np.maximum(pre.mean(axis=1), tiny),
+        "cv_post": post.std(axis=1) / np.maximum(post.mean(axis=1), tiny),
+        "plateau": pre.mean(axis=1) / np.maximum(post.mean(axis=1), tiny),
+        "pre_share": step[:, :ts].sum(axis=1) / np.maximum(L, tiny),
+        "path_ratio": L / np.maximum(np.linalg.norm(Q[:, :, -1] - Q[:, :, 0], axis=1), tiny),
+        "chord_dev": np.linalg.norm(Q[:, :, 1:ts + 1] - chord, axis=1).max(axis=1) / np.maximum(np.linalg.norm(b - a, axis=1), tiny),
+        "on_bound": ((np.abs(Q - lo) <= 1e-6) | (np.abs(Q - hi) <= 1e-6)).any(axis=1).mean(axis=1),
+    }

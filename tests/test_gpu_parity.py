@@ -1092,17 +1092,18 @@ def test_baseline_config3_one_gpus_share_256_scenes_resident(capi, oracle_mod):
 
 @pytest.mark.parametrize("mode", [0])
 def test_fetch_shelf_256_instances(capi, oracle_mod, mode):
-    """BASELINE configs[2]: Fetch arm, shelf scene, 256 (scene, grasp) instances, T = 50.  Shelf scenes are planned from
-    interpolate=False seeds (gto/gto_planner.py:216-219, examples/pybullet_gto_planning.py:98-109): the arm holds qc until
-    the standoff waypoint and jumps to the IK solution.  Oracle on a sample, size-independent properties on all 256."""
+    """BASELINE configs[2] at size: Fetch arm, shelf scene, 256 (scene, grasp) instances, T = 50, 128^3 field at the bench's
+    resolution, the reference's iteration cap of 100.  Shelf scenes are planned from interpolate=False seeds
+    (gto/gto_planner.py:216-219, examples/pybullet_gto_planning.py:98-109): the arm holds qc until the standoff waypoint
+    and jumps to the IK solution.  Oracle on a sample of seven (every usable core), size-independent properties on all 256."""
     from grasptrajopt_amd import synthetic as syn
     from grasptrajopt_amd.robot_desc import load_builtin
     cfg = cfg_of("fetch")
     d = load_builtin("fetch")
-    opts = oracle_mod.reference_opts(max_iter=40)
+    opts = oracle_mod.reference_opts(max_iter=100)
     h = capi.SolverHandle(d, cfg["link_ee"], cfg["link_gripper"], opts, device=0)
     h.set_mode(mode)
-    sc = syn.make_scene(11, n=64, res=0.035, origin=(-0.3, -1.12, 0.0), table_z=0.75, shelf=True)
+    sc = syn.make_scene(11, n=128, res=2.24 / 128, origin=(-0.3, -1.12, 0.0), table_z=0.75, shelf=True)
     assert sc.objects[-1][0] == "shelf"
     h.set_scene(0, sc.c_all, sc.c_obs, sc.shape, sc.origin, sc.res)
     B, T = 256, 50
@@ -1131,7 +1132,7 @@ def test_fetch_shelf_256_instances(capi, oracle_mod, mode):
     o = oracle_mod.Oracle(d, cfg["link_ee"], cfg["link_gripper"], opts)
     o.set_scene(0, sc.c_all, sc.c_obs, sc.shape, sc.origin, sc.res)
     sel = [0, 31, 64, 100, 129, 200, 255]
-    Qo, _, fo_, ito, sto = o.solve_batch(0, qc[sel], RT[sel].reshape(-1, 1, 16), 1, S, [0.0, 0.0, 0.0], Q0[sel])
+    Qo, _, fo_, ito, sto = o.solve_batch(0, qc[sel], RT[sel].reshape(-1, 1, 16), 1, S, [0.0, 0.0, 0.0], Q0[sel], n_threads=o.usable_cores())
     np.testing.assert_array_equal(it[sel], ito)
     np.testing.assert_array_equal(st[sel], sto)
     np.testing.assert_allclose(Q[sel], Qo, rtol=0, atol=1e-6)
@@ -1294,10 +1295,10 @@ def test_mobile_fetch_baseline_config4_size(capi, oracle_mod):
     """BASELINE configs[4]: mobile Fetch, 10 optimised joints, T = 80 waypoints, 256^3 cost field (1.2 GB resident with its
     voxel records and distance fields), shelf scene.  Oracle on a sample, invariants and objective consistency on all."""
     from grasptrajopt_amd import synthetic as syn
-    T, B = 80, 16
+    T, B = 80, 64
     prob = Problem("fetch_mobile", B=B, scene_seed=8, n=256, res=0.0175, T=T, shelf=True, table_z=0.75, scene_origin=(-1.6, -2.24, -0.2))
     assert prob.scene.shape == (256, 256, 256)
-    opts = oracle_mod.reference_opts(T=T, standoff_offset=-16, max_iter=30)
+    opts = oracle_mod.reference_opts(T=T, standoff_offset=-16, max_iter=100)  # the bench's batch of 64 at the reference's cap
     h = capi.SolverHandle(prob.desc, prob.cfg["link_ee"], prob.cfg["link_gripper"], opts, device=0)
     prob.finish(h.eval_fk)
     h.set_scene(*prob.scene_args())
@@ -1307,8 +1308,8 @@ def test_mobile_fetch_baseline_config4_size(capi, oracle_mod):
     np.testing.assert_allclose(fg + fo + fv, f, rtol=1e-10)
     o = oracle_mod.Oracle(prob.desc, prob.cfg["link_ee"], prob.cfg["link_gripper"], opts)
     o.set_scene(*prob.scene_args())
-    sel = [0, 7, 15]
-    Qo, _, fo_, ito, sto = o.solve_batch(0, prob.qc[sel], prob.goals[sel], 1, prob.S, prob.base[sel], prob.Q0[sel])
+    sel = [0, 7, 15, 40, 63]
+    Qo, _, fo_, ito, sto = o.solve_batch(0, prob.qc[sel], prob.goals[sel], 1, prob.S, prob.base[sel], prob.Q0[sel], n_threads=o.usable_cores())
     np.testing.assert_array_equal(it[sel], ito)
     np.testing.assert_array_equal(st[sel], sto)
     np.testing.assert_allclose(Q[sel], Qo, rtol=0, atol=1e-6)

@@ -47,9 +47,9 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
 out = {"what": "clock64 ticks of instance 0's workgroup (GTO_DEBUG_TIMING), last launch of the call that wrote them; ticks_per_us: the "
                "shader clock the counter runs at (2.4 GHz; GRBM_GUI_ACTIVE over the launch duration gives 2.4-2.5)", "variants": {}}
 ph, tl, a, b, err = run(320, 6)
-steps, tail = sum(a[:7]), sum(x for x in b if x > 0)
-out["variants"]["k_lm_step<4,1>"] = {"critical_path_cycles": steps + tail, "ticks_per_us": 2400, "step_phases": ph, "tail_phases": tl,
-                                     "cycles_step_part": steps, "cycles_tail_broad_phase": tail}
+steps, tail = sum(a[:7]), sum(x for x in b if x > 0)  # (the P5 stamp is taken behind the tail: steps includes it)
+out["variants"]["k_lm_step<4,1>"] = {"critical_path_cycles": steps, "ticks_per_us": 2400, "step_phases": ph, "tail_phases": tl,
+                                     "cycles_tail_broad_phase": tail, "cycles_without_tail": steps - tail}
 ph, tl, a, b, err2 = run(1, 100)
 out["variants"]["k_lm_step<8,4>"] = {"critical_path_cycles": sum(a[:7]), "ticks_per_us": 2400, "step_phases": ph}
 json.dump(out, open(os.path.join(ROOT, "profiles", f"{tag}_step_stamps.json"), "w"), indent=1)
