@@ -236,7 +236,10 @@ def main(argv=None, emit=True):
     # steps, grasp sets of its own) in HBM and its own outputs; a call solves m <= M of them at once
     class Lane:
         def __init__(self, first=None):
-            self.stream = torch.cuda.Stream(dev)
+            # streams of the greatest priority: the runtime gives them hardware queues of their own, in the order of their first
+            # use, so the lanes sit behind different dispatcher pipes whatever other streams the process has created (a lane
+            # whose queue shares a pipe with another's runs its evaluation launches 1.5x slower: DESIGN.md section 6)
+            self.stream = torch.cuda.Stream(dev, priority=int(os.environ.get("GTO_BENCH_STREAM_PRIO", "-1")))
             self.h = _capi.SolverHandle(desc, cfg["link_ee"], cfg["link_gripper"], opts, device=local_rank, n_gripper_points=100)
             self.h.set_mode(mode)
             self.h.set_stream(self.stream.cuda_stream)
