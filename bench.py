@@ -639,8 +639,8 @@ def main(argv=None, emit=True):
         tj = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tj):  # PMC figures are quoted only for the workload, mode and call size they were measured on
             for tr in json.load(open(tj)).get("entries", []):
-                if (args.robot, args.grid, B * max(plan), slots, args.mode) == (tr.get("robot"), tr.get("grid"), tr.get("instances_per_call"),
-                                                                                 tr.get("slots"), tr.get("mode", "rounds")):
+                if (args.robot, args.grid, B * max(plan), slots, args.mode, bool(args.shelf)) == (tr.get("robot"), tr.get("grid"), tr.get("instances_per_call"),
+                                                                                                    tr.get("slots"), tr.get("mode", "rounds"), bool(tr.get("shelf", False))):
                     traffic = tr.get("hbm_bytes_per_launch")
                     issue = tr.get("issue")
                     pmc_variants = tr.get("variants", {})
@@ -782,9 +782,9 @@ def main(argv=None, emit=True):
                     other_configs[key_] = {"argv": " ".join(argv_), "trajectories_per_s": r_["value"], "ms_per_step": r_["ms_per_step"],
                                            "timed_regions": r_["timed_regions"], "workload": r_["config"]["workload"],
                                            "iters_mean": r_["iters_mean"], "iters_max": r_["iters_max"], "status_counts": r_["status_counts"],
-                                           "roofline": {k_: r_["roofline"][k_] for k_ in ("kernel", "achieved", "frac", "points_gathered_per_launch",
+                                           "roofline": {k_: r_["roofline"][k_] for k_ in ("kernel", "achieved", "frac", "traffic", "points_gathered_per_launch",
                                                                                          "alg_bytes_per_launch", "alg_bytes_skipped_frac", "avg_launch_us", "launches",
-                                                                                         "timed_regime")},
+                                                                                         "timed_regime", "issue", "dominant_by_time")},
                                            "kernel_variants": r_["roofline"]["variants"],
                                            "oracle_check": r_["oracle_check"], "gate": r_["quality"]["gate"],
                                            "seconds": round(time.perf_counter() - t_oc, 2)}

@@ -5,7 +5,7 @@
 # file name's companion STAMP and inside every text file; tools/run_evidence.sh (local) refuses to start from a dirty tree
 # and copies what is worth judging to profiles/.
 # usage (through tools/run_evidence.sh): tools/evidence.sh <tag> <git head>
-tag=${1:-r04}; head=${2:-unknown}
+tag=${1:-r05}; head=${2:-unknown}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/evidence; mkdir -p $out
 cd $root
@@ -35,9 +35,24 @@ python tools/serial_latency.py > $out/${tag}_serial_latency.txt 2>&1
 python tools/planner_latency.py > $out/${tag}_planner_latency.txt 2>&1
 python tools/pipeline_latency.py > $out/${tag}_pipeline_latency.txt 2>&1
 st $out/${tag}_rounds_steps20.txt $out/${tag}_timeline_steps20.txt $out/${tag}_serial_latency.txt $out/${tag}_planner_latency.txt $out/${tag}_pipeline_latency.txt
-# PMC passes (counters in runs of their own: --kernel-trace --pmc only) at the driver's call size and at the default's
+# PMC passes (counters in runs of their own: --kernel-trace --pmc only) at the driver's call size and at the default's, and of
+# BASELINE configs[2] (Fetch in the shelf) and configs[4] (mobile Fetch, 256^3) at the call sizes of the line's other_configs
 bash tools/pmc_pass.sh pmc_320 20 5 > /dev/null 2>&1; cp gpurun_out/pmc_320/pmc_summary.txt $out/${tag}_pmc_320.txt
 bash tools/pmc_pass.sh pmc_2048 32 32 > /dev/null 2>&1; cp gpurun_out/pmc_2048/pmc_summary.txt $out/${tag}_pmc_2048.txt
-st $out/${tag}_pmc_320.txt $out/${tag}_pmc_2048.txt
-python tools/traffic_json.py $tag gpurun_out/pmc_320 gpurun_out/pmc_2048 > /dev/null && cp profiles/traffic.json $out/traffic.json
+bash tools/pmc_pass.sh pmc_cfg2_2048 8 8 --robot fetch --batch 256 --shelf --light --no-next-rows --no-other-configs --repeats 1 > /dev/null 2>&1; cp gpurun_out/pmc_cfg2_2048/pmc_summary.txt $out/${tag}_pmc_cfg2_2048.txt
+bash tools/pmc_pass.sh pmc_cfg4_512 8 8 --robot fetch_mobile --T 80 --grid 256 --shelf --batch 64 --light --no-next-rows --no-other-configs --repeats 1 > /dev/null 2>&1; cp gpurun_out/pmc_cfg4_512/pmc_summary.txt $out/${tag}_pmc_cfg4_512.txt
+st $out/${tag}_pmc_320.txt $out/${tag}_pmc_2048.txt $out/${tag}_pmc_cfg2_2048.txt $out/${tag}_pmc_cfg4_512.txt
+# stamped critical path of a step-kernel workgroup (GTO_DEBUG_TIMING), next to the PMC figures of the same variants
+python tools/step_stamps.py $tag > $out/${tag}_step_stamps.log 2>&1; cp profiles/${tag}_step_stamps.json $out/ 2>/dev/null
+python tools/traffic_json.py $tag gpurun_out/pmc_320 gpurun_out/pmc_2048 gpurun_out/pmc_cfg2_2048:fetch:128:shelf gpurun_out/pmc_cfg4_512:fetch_mobile:256:shelf > /dev/null && cp profiles/traffic.json $out/traffic.json
+# where the obstacle kernel's instructions go on the shelf workload (cumulative cuts, PMC per cut)
+bash tools/phase_cut_pmc.sh cut_cfg2 --robot fetch --shelf > /dev/null 2>&1; cp gpurun_out/cut_cfg2/phase_cut_pmc.txt $out/${tag}_phase_cut_cfg2.txt; st $out/${tag}_phase_cut_cfg2.txt
+# lanes inside one call (gto_set_lanes): kernel trace of one call of 1280 instances on four lanes, without and with the hand-over
+cd /tmp
+for ad in 0 48; do rm -rf /tmp/tl_ln; GTO_ADOPT=$ad timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/tl_ln -o p -- python $root/bench.py --steps 20 --warmup 2 --repeats 2 --no-cpu-baseline --no-next-rows --merged-launches-only --pipeline 1 --merge 20 --lanes 4 > $out/${tag}_lanes.log 2>&1
+  csv=$(ls /tmp/tl_ln/*kernel_trace.csv /tmp/tl_ln/*/*kernel_trace.csv 2>/dev/null | head -1); python $root/tools/lane_trace.py $csv 1280 > $out/${tag}_lanes_one_call_adopt$ad.txt 2>&1; st $out/${tag}_lanes_one_call_adopt$ad.txt; done
+cd $root
+# the rerun of the line with the fresh traffic.json / stamps in place (roofline.variants carry the PMC figures of THIS commit)
+b bench_steps20 --gpus 1 --steps 20 --warmup 5
+b bench --gpus 1
 ls -la $out

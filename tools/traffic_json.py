@@ -16,14 +16,18 @@ stamps = {}
 sp_ = os.path.join(ROOT, "profiles", f"{tag}_step_stamps.json")
 if os.path.exists(sp_):
     stamps = json.load(open(sp_)).get("variants", {})
-for d in sys.argv[2:]:
+for spec in sys.argv[2:]:
+    # <dir>[:robot[:grid[:shelf]]]   (default panda_5k, 128, table top): BASELINE configs[2] is fetch:128:shelf, configs[4] fetch_mobile:256:shelf
+    parts = spec.split(":")
+    d, robot_, grid_, shelf_ = parts[0], (parts[1] if len(parts) > 1 else "panda_5k"), int(parts[2]) if len(parts) > 2 else 128, len(parts) > 3 and parts[3] == "shelf"
     size = int(os.path.basename(d.rstrip("/")).split("_")[-1])
     js = json.load(open(os.path.join(d, "pmc_summary.json")))
     # the variant for the launches that fill the GPU (the one the roofline is quoted on); the variant for few instances in flight only if there is no other
     # (names as the C ABI's profile reports them: the crew variant behind an itemized launch is a row of its own)
     norm = lambda n: n.replace(", false>", ">").replace(", true>", ">crew").replace(", ", ",")
     js = {norm(n): v for n, v in js.items()}
-    cands = [v for n, v in js.items() if n.startswith("k_obstacle_gram<8,1>") and "crew" not in n] or [v for n, v in js.items() if "k_obstacle_gram" in n]
+    cands = [v for n, v in js.items() if (n.startswith("k_obstacle_gram<8,1>") or n.startswith("k_obstacle_gram<16,1>")) and "crew" not in n] or [v for n, v in js.items() if "k_obstacle_gram" in n]
+    kname = [n for n, v in js.items() if v is max(cands, key=lambda v: v.get("launches", 0) * v.get("mean_us", 0.0))][0]
     k = max(cands, key=lambda v: v.get("launches", 0) * v.get("mean_us", 0.0))
     us = k["mean_us"]
     variants = {}
@@ -48,10 +52,10 @@ for d in sys.argv[2:]:
                 variants[n_.replace(", ", ",")]["critical_path_over_launch"] = round(st_["critical_path_cycles"] / max(v_.get("mean_us", 0.0) * st_["ticks_per_us"], 1.0), 3)
     simd_cycles = 1024 * us * 1e-6 * 2.4e9  # 256 CUs x 4 SIMDs at 2.4 GHz
     entries.append({
-        "robot": "panda_5k", "grid": 128, "mode": "rounds", "instances_per_call": size, "slots": 384,
-        "source": f"profiles/{tag}_pmc_{size}.txt (tools/pmc_pass.sh: rocprofv3 --kernel-trace --pmc, separate passes, bench.py --pipeline 1 "
+        "robot": robot_, "grid": grid_, "shelf": bool(shelf_), "mode": "rounds", "instances_per_call": size, "slots": 384,
+        "source": f"profiles/{tag}_{os.path.basename(d.rstrip('/'))}.txt (tools/pmc_pass.sh: rocprofv3 --kernel-trace --pmc, separate passes, bench.py --pipeline 1 "
                   f"--merged-launches-only with calls of {size} instances)",
-        "kernel": "k_obstacle_gram<8,1>", "variants": variants, "launches": k["launches"], "mean_launch_us_profiled": round(us, 2),
+        "kernel": kname, "variants": variants, "launches": k["launches"], "mean_launch_us_profiled": round(us, 2),
         "FETCH_SIZE_KB_mean_per_launch": round(k["FETCH_SIZE"], 1), "WRITE_SIZE_KB_mean_per_launch": round(k["WRITE_SIZE"], 1),
         "correction": "FETCH_SIZE doubled (gfx950 counts 128-B requests at 64 B, MI355X_MICROARCH.md); WRITE_SIZE uncalibrated, taken as is",
         "hbm_bytes_per_launch": int(round((2 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024)),
