@@ -244,7 +244,7 @@ def main(argv=None, emit=True):
             self.h.set_mode(mode)
             self.h.set_stream(self.stream.cuda_stream)
             if args.lanes > 0:
-                self.lane_streams = [self.stream] + [torch.cuda.Stream(dev) for _ in range(args.lanes - 1)]
+                self.lane_streams = [self.stream] + [torch.cuda.Stream(dev, priority=int(os.environ.get("GTO_BENCH_STREAM_PRIO", "-1"))) for _ in range(args.lanes - 1)]
                 self.h.set_lanes(args.lanes, int(os.environ.get("GTO_LANE_MIN", "256")), int(os.environ.get("GTO_ADOPT", "48")))
                 self.h.set_lane_streams([s_.cuda_stream for s_ in self.lane_streams])
             if first is None:

@@ -452,7 +452,10 @@ class SolverHandle:
         out = {}
         if not hasattr(self.lib, "gto_last_kernel_profile"):
             return out
-        for v, name in enumerate(self.PROF_VARIANTS):
+        names = self.PROF_VARIANTS
+        if self.desc.n_opt > 8:  # the kernels of the robots with nine to sixteen optimised joints (one step kernel, no few-instance variants)
+            names = ("k_obstacle_gram<16,1>", "k_obstacle_gram<16,8>", "k_lm_step_wide<16>", "k_lm_step<8,4>")
+        for v, name in enumerate(names):
             ms, n, wg, pts = C.c_double(), C.c_int32(), C.c_uint64(), C.c_uint64()
             self._check(self.lib.gto_last_kernel_profile(self._h, v, C.byref(ms), C.byref(n), C.byref(wg), C.byref(pts)), "gto_last_kernel_profile")
             out[name] = (ms.value, n.value, wg.value, pts.value)
