@@ -35,7 +35,9 @@ def main():
         opts = _capi.default_opts()
         opts.T, opts.standoff_offset, opts.max_iter = T, -max(2, T // 5), int(rng.choice([5, 30, 100]))
         h = _capi.SolverHandle(prob.desc, prob.cfg["link_ee"], prob.cfg["link_gripper"], opts, device=0)
-        h.set_mode(int(rng.integers(0, 2)))
+        h.set_mode(0)
+        # lanes inside the call (gto_set_lanes): any setting, same results as far as the invariants below can tell
+        h.set_lanes(int(rng.integers(1, 9)), int(rng.choice([1, 8, 64, 256])), int(rng.choice([0, 3, 48, 1000])))
         prob.finish(h.eval_fk)
         for rep in range(int(rng.integers(1, 4))):  # replace the scene a few times (spare buffers), sometimes values-only ids
             h.set_scene(0, prob.scene.c_all, prob.scene.c_obs, prob.scene.shape, prob.scene.origin, prob.scene.res)
