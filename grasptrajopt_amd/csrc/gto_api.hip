@@ -127,6 +127,7 @@ struct gto_handle {
   // published (the prior of the next call's launches until its own counts arrive), and of the call that is running
   double items_per_job_prior = 0.0, items_per_job_call = 0.0;
   int item_hint_forced = 0;  // GTO_ITEM_HINT: the estimate itself (tests of the crew)
+  int hot_variants = 1;  // GTO_OBS_HOT=0: the solve loop's evaluation launches use the general kernel variants
   int item_grid = 1;  // GTO_ITEM_GRID=0: itemized launches laid out over the upper bound of their item lists
   std::mutex* prof_mu = nullptr;  // set while a call with several lanes (host threads) runs: guards the profiling records
 };
@@ -256,6 +257,7 @@ int gto_create(const gto_robot_desc* d, const gto_solver_opts* opts, int device,
   if (const char* e = getenv("GTO_DEBUG_CUT")) h->dbg_cut = atoi(e);
   if (h->dbg_cut) fprintf(stderr, "[gto] WARNING: GTO_DEBUG_CUT=%d cuts the obstacle kernel short: timing experiments only, RESULTS ARE GARBAGE\n", h->dbg_cut);
   if (const char* e = getenv("GTO_ITEM_GRID")) h->item_grid = atoi(e) != 0;
+  if (const char* e = getenv("GTO_OBS_HOT")) h->hot_variants = atoi(e) != 0;
   if (const char* e = getenv("GTO_ITEM_HINT")) h->item_hint_forced = std::max(0, atoi(e));
   if (const char* e = getenv("GTO_SLOTS")) h->slots = std::max(1, atoi(e));
   if (const char* e = getenv("GTO_LANES")) h->lanes_max = std::max(1, std::min(GTO_MAX_LANES, atoi(e)));
@@ -617,6 +619,8 @@ int gto_create(const gto_robot_desc* d, const gto_solver_opts* opts, int device,
     hipError_t e1 = raise_dynamic_lds(w ? (const void*)k_obstacle_gram<16> : (const void*)k_obstacle_gram<GTO_NB>, lds);
     if (!w && e1 == hipSuccess) e1 = raise_dynamic_lds((const void*)k_obstacle_gram<GTO_NB, GTO_OBS_DEEP_PD>, lds);
     if (!w && e1 == hipSuccess) e1 = raise_dynamic_lds((const void*)k_obstacle_gram<GTO_NB, GTO_OBS_MAIN_PD, true>, lds);
+    if (e1 == hipSuccess) e1 = raise_dynamic_lds(w ? (const void*)k_obstacle_gram<16, GTO_OBS_MAIN_PD, false, true> : (const void*)k_obstacle_gram<GTO_NB, GTO_OBS_MAIN_PD, false, true>, lds);
+    if (!w && e1 == hipSuccess) e1 = raise_dynamic_lds((const void*)k_obstacle_gram<GTO_NB, GTO_OBS_DEEP_PD, false, true>, lds);
     hipError_t e2 = w ? raise_dynamic_lds((const void*)k_lm_step_wide<16>, h->lm_lds) : raise_dynamic_lds((const void*)k_lm_step<4, 1>, h->lm_lds);
     if (!w && e2 == hipSuccess) e2 = raise_dynamic_lds((const void*)k_lm_step<8, GTO_KSPEC>, lm_lds_bytes(opts->T, h->spec_kmax));
     if (e1 != hipSuccess || e2 != hipSuccess) {
@@ -1107,7 +1111,17 @@ static int launch_obstacle(gto_handle* h, hipStream_t st, const BatchPtrs& bp, c
   const size_t items_cap = (size_t)bp.cap * sp.kcap * (sp.T - 2) + GTO_ITEM_SLACK;
   const int2* items_par = listed && itemized ? bp.items + (size_t)sp.parity * items_cap : nullptr;
   const int32_t* nitems_par = listed && itemized ? bp.nlive + 8 + sp.parity : nullptr;
-  if (h->np == GTO_NB && deep)  // few instances in flight: the variant that keeps a wave's record gathers in flight together
+  const bool hot = !fixed_mode && sp.grad_mode == GTO_GRAD_CENTRAL_DIFF && h->hot_variants;
+  if (hot && h->np == GTO_NB && deep)
+    hipLaunchKernelGGL((k_obstacle_gram<GTO_NB, GTO_OBS_DEEP_PD, false, true>), grid, dim3(256), lds, st, jobs_par, njobs_par, items_par, nitems_par, geo.nG, geo.m_nG, n_regular, B, h->d_rb, h->d_px, h->d_py, h->d_pz, h->d_chunks, h->d_scenes,
+                       bpl, sp, t_begin, nT, fixed_mode, geo, 0);
+  else if (hot && h->np == GTO_NB)
+    hipLaunchKernelGGL((k_obstacle_gram<GTO_NB, GTO_OBS_MAIN_PD, false, true>), grid, dim3(256), lds, st, jobs_par, njobs_par, items_par, nitems_par, geo.nG, geo.m_nG, n_regular, B, h->d_rb, h->d_px, h->d_py, h->d_pz, h->d_chunks, h->d_scenes, bpl, sp,
+                       t_begin, nT, fixed_mode, geo, 0);
+  else if (hot)
+    hipLaunchKernelGGL((k_obstacle_gram<16, GTO_OBS_MAIN_PD, false, true>), grid, dim3(256), lds, st, jobs_par, njobs_par, items_par, nitems_par, geo.nG, geo.m_nG, n_regular, B, h->d_rb, h->d_px, h->d_py, h->d_pz, h->d_chunks, h->d_scenes, bpl, sp,
+                       t_begin, nT, fixed_mode, geo, 0);
+  else if (h->np == GTO_NB && deep)  // few instances in flight: the variant that keeps a wave's record gathers in flight together
     hipLaunchKernelGGL((k_obstacle_gram<GTO_NB, GTO_OBS_DEEP_PD>), grid, dim3(256), lds, st, jobs_par, njobs_par, items_par, nitems_par, geo.nG, geo.m_nG, n_regular, B, h->d_rb, h->d_px, h->d_py, h->d_pz, h->d_chunks, h->d_scenes,
                        bpl, sp, t_begin, nT, fixed_mode, geo, 0);
   else if (h->np == GTO_NB)
