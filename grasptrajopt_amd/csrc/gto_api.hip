@@ -745,6 +745,9 @@ static int set_scene_impl(gto_handle* h, int32_t id, const float* c_all, const f
   if (!c_all || !shape || !origin) return fail(h, GTO_ERR_INVALID_ARG, "null argument");
   if (id < 0 || id >= 65536) return fail(h, GTO_ERR_INVALID_ARG, "scene_id out of range [0,65536)");
   if (shape[0] < 1 || shape[1] < 1 || shape[2] < 1 || !(res > 0)) return fail(h, GTO_ERR_INVALID_ARG, "bad field geometry");
+  // (the gather loop forms the voxel offset with 24-bit multiply-adds: iz + nz (iy + ny ix))
+  if ((long long)shape[0] * shape[1] > (1ll << 24) || shape[2] >= (1 << 24) || (long long)shape[0] * shape[1] * shape[2] >= (1ll << 32))
+    return fail(h, GTO_ERR_UNSUPPORTED, "field too large: nx ny <= 2^24, nz < 2^24 and fewer than 2^32 voxels");
   const size_t nvox = (size_t)shape[0] * shape[1] * shape[2];
   if (nvox >= ((size_t)1 << 31)) return fail(h, GTO_ERR_UNSUPPORTED, "field larger than 2^31 voxels");
   HIPCHK(h, hipSetDevice(h->device));
