@@ -338,6 +338,16 @@ int gto_create(const gto_robot_desc* d, const gto_solver_opts* opts, int device,
     rpy2r(d->visual_rpy + 3 * l, R);
     rt2aff(R, d->visual_xyz + 3 * l, rb.vis_origin[l]);
   }
+  for (int v = 0; v < 2; ++v) {
+    const int NPv = v ? 16 : 8;
+    for (int e = 0; e < NPv * NPv + NPv; ++e) {
+      const int i = e < NPv * NPv ? e / NPv : e - NPv * NPv, j = e < NPv * NPv ? e % NPv : i;
+      uint32_t m = 0u;
+      if (i < d->n_opt && j < d->n_opt)
+        for (int l = 0; l < d->n_links; ++l) m |= (((rb.link_anc[l] >> i) & (rb.link_anc[l] >> j) & 1u) << l);
+      rb.entry_links[v][e] = m;
+    }
+  }
   for (int i = 0; i < d->n_frames; ++i) rb.link_of_frame[i] = -1, rb.xst_slot[i] = -1;
   for (int l = 0; l < d->n_links; ++l) {
     if (rb.link_of_frame[rb.link_frame[l]] >= 0) { delete h; return fail(nullptr, GTO_ERR_INVALID_ARG, "two collision links on one frame"); }

@@ -75,6 +75,9 @@ struct RobotDev {
   double axis_unit[GTO_MAX_FRAMES][3];   // unit(axis)              (optas/models.py:653-659)
   int32_t link_frame[GTO_MAX_LINKS];
   uint32_t link_anc[GTO_MAX_LINKS];
+  // per entry of a waypoint's normal-equation block, the links that contribute to it: entry (i, j) of J^T J -> links both
+  // joints sit above, entry i of J^T r (stored behind the NP x NP entries) -> links joint i sits above; [0]: NP = 8, [1]: 16
+  uint32_t entry_links[2][16 * 16 + 16];
   double vis_origin[GTO_MAX_LINKS][12];  // rt2tr(rpy2r(vis_rpy), vis_xyz) (gto/gto_models.py:95-96)
   int32_t opt_index[GTO_MAX_OPT];
   double lower[GTO_MAX_OPT], upper[GTO_MAX_OPT];
