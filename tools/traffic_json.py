@@ -24,7 +24,13 @@ for spec in sys.argv[2:]:
     js = json.load(open(os.path.join(d, "pmc_summary.json")))
     # the variant for the launches that fill the GPU (the one the roofline is quoted on); the variant for few instances in flight only if there is no other
     # (names as the C ABI's profile reports them: the crew variant behind an itemized launch is a row of its own)
-    norm = lambda n: n.replace(", false>", ">").replace(", true>", ">crew").replace(", ", ",")
+    def norm(n):  # k_obstacle_gram<NP, PD, SWEEP, HOT> -> k_obstacle_gram<NP,PD>[crew]; others: blanks out
+        import re
+        m = re.match(r"k_obstacle_gram<(\d+), (\d+)(?:, (true|false))?(?:, (true|false))?>", n)
+        if not m:
+            return n.replace(", ", ",")
+        return f"k_obstacle_gram<{m.group(1)},{m.group(2)}>" + ("crew" if m.group(3) == "true" else "") + ("" if m.group(4) in (None, "true") or m.group(3) == "true" else "general")
+    # the solve loop's launches run the HOT variants; the general ones (init pass, value-only mode) are rows of their own
     js = {norm(n): v for n, v in js.items()}
     cands = [v for n, v in js.items() if (n.startswith("k_obstacle_gram<8,1>") or n.startswith("k_obstacle_gram<16,1>")) and "crew" not in n] or [v for n, v in js.items() if "k_obstacle_gram" in n]
     kname = [n for n, v in js.items() if v is max(cands, key=lambda v: v.get("launches", 0) * v.get("mean_us", 0.0))][0]
