@@ -134,6 +134,7 @@ def main(argv=None, emit=True):
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="torch.distributed backend of the N > 1 run: nccl = RCCL (one GPU per rank); gloo = host-side collectives, "
                          "for dry runs of the multi-rank code on a box with fewer GPUs than ranks")
+    ap.add_argument("--force-dist", action="store_true", help="run the N > 1 code path (process group, barriers, all_reduce of the timings, the scene-sharded leg's all_gather, the collective object) with however many ranks there are, even one: the RCCL branch on a one-GPU box")
     ap.add_argument("--same-device", action="store_true",
                     help="every rank uses device 0 (with --backend gloo: the N > 1 code path on ONE GPU; the rates then say nothing)")
     ap.add_argument("--repeats", type=int, default=5,
@@ -159,6 +160,7 @@ def main(argv=None, emit=True):
     rank = 0 if child else int(os.environ.get("RANK", "0"))
     world = 1 if child else int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    multi = world > 1 or (args.force_dist and not child and "WORLD_SIZE" in os.environ)  # a process group exists
     if world != args.gpus and rank == 0:
         print(f"[bench] WORLD_SIZE={world} != --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
     if not torch.cuda.is_available():
@@ -170,7 +172,7 @@ def main(argv=None, emit=True):
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     comm_dev = dev if args.backend == "nccl" else torch.device("cpu")  # where the tensors of the (few, tiny) collectives live
-    if world > 1:
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -313,7 +315,7 @@ def main(argv=None, emit=True):
     torch.cuda.synchronize(dev)
 
     def barrier():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -433,7 +435,7 @@ def main(argv=None, emit=True):
     per_batch_it = iters.reshape(M, B).sum(axis=1)
     it_timed = float(sum(per_batch_it[:m].sum() for m in plan))
     it_sum = torch.tensor([it_timed], dtype=torch.float64, device=comm_dev)
-    if world > 1:
+    if multi:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         dist.all_reduce(it_sum, op=dist.ReduceOp.SUM)
     el_np = el.cpu().numpy()  # per region: the slowest rank's time
@@ -449,7 +451,7 @@ def main(argv=None, emit=True):
     # ---- BASELINE configs[3]: many scenes x 8 grasps, instances grouped by scene onto ranks, solved through the
     # host-pointer API, results all_gathered (RCCL); every instance of a call reads a different field
     scene_sharded = None
-    if world > 1 or args.scene_sharded:
+    if multi or args.scene_sharded:
         SG = 8
         SP = args.scenes_per_gpu if args.scenes_per_gpu > 0 else (256 if world == 8 else 32)
         n_sc = SP * world
@@ -483,12 +485,12 @@ def main(argv=None, emit=True):
         idx, Qa, _, ca, ia, sa = solve_local_shard(hs_.solve_batch, *sargs, B=nI, rank=rank, world=world, assignment=owner, stats=gstats)
         barrier()
         els = torch.tensor([time.perf_counter() - tss], dtype=torch.float64, device=comm_dev)
-        if world > 1:
+        if multi:
             dist.all_reduce(els, op=dist.ReduceOp.MAX)
         oi_ = desc.opt_index
         scene_sharded = {"workload": f"BASELINE configs[3]: {n_sc} scenes x {SG} grasps, grouped by scene onto {world} rank(s) "
                                      f"({SP} scenes per rank), host-pointer API, every rank builds and solves its own instances only, results "
-                                     + (f"all_gathered over {'RCCL' if args.backend == 'nccl' else 'gloo'}" if world > 1 else "kept on the one rank"),
+                                     + (f"all_gathered over {'RCCL' if args.backend == 'nccl' else 'gloo'}" if multi else "kept on the one rank"),
                          "instances": int(nI), "trajectories_per_s": round(nI / float(els.item()), 1),
                          "scenes_per_rank": int(SP), "fields_resident_gb_this_rank": round(resident_gb, 2),
                          "all_instances_returned": bool(len(idx) == nI and np.array_equal(idx, np.arange(nI))),
@@ -500,7 +502,7 @@ def main(argv=None, emit=True):
     # ---- N > 1: what the collectives ran on, so that the first multi-GPU record shows "RCCL saw N ranks on N distinct
     # devices" and whether N x (lanes + polling host threads) fit the host: gathered from every rank
     collective = None
-    if world > 1:
+    if multi:
         try:
             bus = torch.cuda.get_device_properties(dev).pci_bus_id
         except Exception:
@@ -866,7 +868,7 @@ def main(argv=None, emit=True):
             print(json.dumps(out))
     for ln in reversed(lanes):  # the owner of the shared scene goes last
         ln.h.close()
-    if world > 1 and not child:
+    if multi and not child:
         dist.destroy_process_group()
     if rc and not child:
         raise SystemExit(rc)

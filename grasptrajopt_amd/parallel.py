@@ -44,6 +44,16 @@ def _shard_indices(B: int, world: int, assignment: Optional[np.ndarray]):
     return [np.nonzero(assignment == r)[0] for r in range(world)]
 
 
+def _group_exists() -> bool:
+    """A torch.distributed process group has been initialised in this process (a one-rank group still runs the collective:
+    the RCCL branch can be exercised on a one-GPU box)."""
+    try:
+        import torch.distributed as dist
+        return dist.is_available() and dist.is_initialized()
+    except Exception:
+        return False
+
+
 def gather_results(mine: np.ndarray, result: tuple, B: int, rank: int, world: int, group=None,
                    assignment: Optional[np.ndarray] = None, stats: Optional[dict] = None):
     """all_gather the solved shards (Q, dQ, cost, iters, status of the instances `mine`) so that every rank holds the
@@ -108,7 +118,7 @@ def solve_local_shard(solve_fn: Callable[..., tuple], mine, scene_id, qc, goals,
                           n_goals, standoff, base_pos, Q0.reshape(n, ndof, T))
     else:
         result = (np.empty((0, ndof, T)), np.empty((0, ndof, T - 1)), np.empty(0), np.empty(0, np.int32), np.empty(0, np.int32))
-    if not gather or world == 1:
+    if not gather or (world == 1 and not _group_exists()):
         return (mine,) + tuple(result)
     return gather_results(mine, result, B, rank, world, group, assignment, stats)
 

@@ -65,6 +65,23 @@ def test_two_ranks_all_gather_over_rccl(tmp_path):
     assert r["n"] == 12 and r["equal"]
 
 
+def test_one_rank_over_rccl(tmp_path):
+    """The RCCL branch executed on the hardware that is there: the same worker as the two-rank test with ONE rank -- process
+    group over `nccl` bound to the device, the error-flag all_reduce, the two all_gathers of the result payloads on device
+    tensors, the barrier.  (Two ranks need two devices; this is as far as one device goes.)"""
+    script = tmp_path / "worker1.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, GTO_ROOT=ROOT, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", "29733", str(script)]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    out = res.stdout + res.stderr
+    assert res.returncode == 0, out[-3000:]
+    import json
+    r = json.loads([l for l in out.splitlines() if l.startswith("RESULT")][0][7:])
+    assert r["n"] == 12 and r["equal"]
+
+
 WORKER_GLOO = textwrap.dedent('''
     import os, sys, json
     import numpy as np
@@ -168,4 +185,23 @@ def test_bench_eight_ranks_dry_run_on_one_device():
     if q is not None and q < 32:
         assert col["lanes_per_rank"] == max(1, min(4, int(q // 8)))
     assert col["host_cpu_cores_busy_all_ranks"] > 0
+    assert d["quality"]["gate"] == "pass"
+
+
+def test_bench_rccl_branch_with_one_rank():
+    """bench.py's `nccl` branch on the one device there is: launched as the driver launches the N > 1 runs (torch.distributed.run),
+    with one rank and --force-dist: process group over RCCL bound to the device, barriers, the all_reduce of the timings on
+    device tensors, the scene-sharded leg's all_gather pair on the device, the `collective` object with RCCL's version."""
+    import json
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1", "--master-port", "29747",
+           os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--backend", "nccl", "--steps", "4", "--warmup", "1", "--merge", "1",
+           "--repeats", "1", "--scenes-per-gpu", "4", "--no-cpu-baseline"]
+    res = subprocess.run(cmd, env=dict(os.environ, MASTER_ADDR="127.0.0.1"), capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, (res.stdout + res.stderr)[-3000:]
+    d = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    col = d["collective"]
+    assert col["backend"] == "nccl" and col["is_rccl"] and col["world_size"] == 1 and col["nccl_version"]
+    assert col["ranks"][0]["all_gather"]["backend"] == "nccl" and col["ranks"][0]["all_gather"]["collectives"] == 2
+    ss = d["scene_sharded"]
+    assert ss["instances"] == 4 * 8 and ss["all_instances_returned"] and ss["own_shard_round_trip_exact"]
     assert d["quality"]["gate"] == "pass"
