@@ -1730,6 +1730,15 @@ int gto_solve_base_batch(gto_handle* h, int32_t B, int32_t n_max, const int32_t*
   return GTO_OK;
 }
 
+#ifdef GTO_DEBUG_BASE_TIMING
+// (debug builds only: tools/base_stamps.py) phase stamps of k_base_solve since the last call, then cleared
+int gto_debug_base_stamps(long long* out16) {
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_base_dbg), 16 * sizeof(long long)) != hipSuccess) return GTO_ERR_HIP;
+  long long z[16] = {0};
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_base_dbg), z, sizeof z) == hipSuccess ? GTO_OK : GTO_ERR_HIP;
+}
+#endif
+
 int gto_eval_base_objective(gto_handle* h, int32_t B, int32_t n_max, const int32_t* n_goals, const double* y,
                             const double* q, const double* goals, double effort_weight, double* cost_out) {
   if (!h) return GTO_ERR_INVALID_ARG;

@@ -47,6 +47,8 @@ python tools/step_stamps.py $tag > $out/${tag}_step_stamps.log 2>&1; cp profiles
 python tools/traffic_json.py $tag gpurun_out/pmc_320 gpurun_out/pmc_2048 gpurun_out/pmc_cfg2_2048:fetch:128:shelf gpurun_out/pmc_cfg4_512:fetch_mobile:256:shelf > /dev/null && cp profiles/traffic.json $out/traffic.json
 # where the obstacle kernel's instructions go on the shelf workload (cumulative cuts, PMC per cut)
 bash tools/phase_cut_pmc.sh cut_cfg2 --robot fetch --shelf > /dev/null 2>&1; cp gpurun_out/cut_cfg2/phase_cut_pmc.txt $out/${tag}_phase_cut_cfg2.txt; st $out/${tag}_phase_cut_cfg2.txt
+# where an iteration of the base-placement kernel goes (debug build with phase stamps)
+python tools/base_stamps.py $out/${tag}_base_stamps.txt > /dev/null 2>&1; st $out/${tag}_base_stamps.txt
 # lanes inside one call (gto_set_lanes): kernel trace of one call of 1280 instances on four lanes, without and with the hand-over
 cd /tmp
 for ad in 0 48; do rm -rf /tmp/tl_ln; GTO_ADOPT=$ad timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/tl_ln -o p -- python $root/bench.py --steps 20 --warmup 2 --repeats 2 --no-cpu-baseline --no-next-rows --merged-launches-only --pipeline 1 --merge 20 --lanes 4 > $out/${tag}_lanes.log 2>&1
