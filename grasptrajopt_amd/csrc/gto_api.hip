@@ -267,7 +267,7 @@ int gto_create(const gto_robot_desc* d, const gto_solver_opts* opts, int device,
   if (const char* e = getenv("GTO_OBS_TG_FEW")) h->obs_tg_few = std::max(1, std::min(GTO_MAX_TG, atoi(e)));
   if (const char* e = getenv("GTO_FEW_INSTANCES")) h->few_instances = atoi(e);
   if (const char* e = getenv("GTO_STEP_NW_FEW")) h->step_nw_few = atoi(e) == 8 ? 8 : 4;
-  if (getenv("GTO_DEBUG_TIMING")) { (void)hipMalloc((void**)&h->dbg, 192 * sizeof(long long)); (void)hipMemset(h->dbg, 0, 192 * sizeof(long long)); }
+  if (getenv("GTO_DEBUG_TIMING")) { (void)hipMalloc((void**)&h->dbg, 256 * sizeof(long long)); (void)hipMemset(h->dbg, 0, 256 * sizeof(long long)); }
   RobotDev& rb = h->rb;
   memset(&rb, 0, sizeof rb);
   rb.n_frames = d->n_frames;
@@ -1184,7 +1184,7 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
   const int T = sp.T;
   h->last_launches = 0;
   h->last_ms = 0.0;
-  if (h->dbg) HIPCHK(h, hipMemsetAsync(h->dbg + 40, 0, 152 * sizeof(long long), st));
+  if (h->dbg) HIPCHK(h, hipMemsetAsync(h->dbg + 40, 0, 216 * sizeof(long long), st));
 
   // At most W instances per lane are in flight; the step kernel of an instance that finishes puts the next one of its lane
   // that has not started into the next round's live list, so every round works on a full house until the lane runs out,
@@ -1536,7 +1536,7 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
   HIPCHK(h, hipGetLastError());
   if (h->dbg) {
     HIPCHK(h, hipStreamSynchronize(st));
-    long long t[192];
+    long long t[256];
     HIPCHK(h, hipMemcpy(t, h->dbg, sizeof t, hipMemcpyDeviceToHost));
     fprintf(stderr, "[gto dbg] step-kernel phases (cycles) P0+P1 %lld | P2 %lld | diag %lld | dense %lld | back %lld | P4 %lld | P5 %lld | s_dense %lld\n",
             t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3], t[5] - t[4], t[6] - t[5], t[7] - t[6], t[9]);
@@ -1559,6 +1559,9 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
       for (int i = 64; i < 128; ++i) tot_ += t[i];
       fprintf(stderr, "[gto dbg] regular obstacle workgroups of the call: %lld, none of whose keys got a contribution: %lld | surviving chunks per workgroup (0,1,2,...,63+):", tot_, t[48]);
       for (int i = 64; i < 128; ++i) fprintf(stderr, " %lld", t[i]);
+      fprintf(stderr, "\n");
+      fprintf(stderr, "[gto dbg] ticks those workgroups ran, summed by surviving chunks (0,1,2,...,63+):");
+      for (int i = 192; i < 256; ++i) fprintf(stderr, " %lld", t[i]);
       fprintf(stderr, "\n");
     }
     fprintf(stderr, "[gto dbg] broad phase of the step kernel (GTO_DEBUG_CUT=10, -DGTO_DEBUG_LONGEST_WG: settled groups are looked at anyway): %lld groups settled, %lld of them with a surviving chunk\n", t[49], t[50]);

@@ -49,6 +49,10 @@ python tools/traffic_json.py $tag gpurun_out/pmc_320 gpurun_out/pmc_2048 gpurun_
 bash tools/phase_cut_pmc.sh cut_cfg2 --robot fetch --shelf > /dev/null 2>&1; cp gpurun_out/cut_cfg2/phase_cut_pmc.txt $out/${tag}_phase_cut_cfg2.txt; st $out/${tag}_phase_cut_cfg2.txt
 # where an iteration of the base-placement kernel goes (debug build with phase stamps)
 python tools/base_stamps.py $out/${tag}_base_stamps.txt > /dev/null 2>&1; st $out/${tag}_base_stamps.txt
+# what a workgroup of the obstacle kernel costs by its surviving chunks (debug build with per-workgroup clocks)
+python tools/wg_model.py $out/${tag}_wg_model_cfg2.txt > /dev/null 2>&1; st $out/${tag}_wg_model_cfg2.txt
+python tools/wg_model.py $out/${tag}_wg_model_default.txt --batch 512 > /dev/null 2>&1; st $out/${tag}_wg_model_default.txt
+python tools/wg_model.py $out/${tag}_wg_model_cfg4.txt --robot fetch_mobile --T 80 --grid 256 --shelf --batch 64 --merge 8 > /dev/null 2>&1; st $out/${tag}_wg_model_cfg4.txt
 # lanes inside one call (gto_set_lanes): kernel trace of one call of 1280 instances on four lanes, without and with the hand-over
 cd /tmp
 for ad in 0 48; do rm -rf /tmp/tl_ln; GTO_ADOPT=$ad timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/tl_ln -o p -- python $root/bench.py --steps 20 --warmup 2 --repeats 2 --no-cpu-baseline --no-next-rows --merged-launches-only --pipeline 1 --merge 20 --lanes 4 > $out/${tag}_lanes.log 2>&1
