@@ -83,6 +83,7 @@ struct gto_handle {
   // the obstacles (neighbours in time) land in different workgroups: 0 never, 1 always, 2 (default) in launches with few
   // instances in flight, where the longest workgroup decides the round (+5 % for one batch at a time, -2 % at saturation)
   int obs_interleave = 2;
+  int pb_merge = 4;  // GTO_PB_MERGE: chunks of a link under one sphere of the step kernel's broad phase
   int prebroad = 1;  // GTO_PREBROAD=0: every (job, group) gets a workgroup of the obstacle kernel in every round
   double pb_min_gain = 0.10;  // GTO_PB_MIN_GAIN: a call whose step-kernel broad phase settles less than this share of the groups stops running it
   int obs_tg_few = 2;  // ... when few instances are in flight (one small batch, the tail of a call): lower latency per round; results do not depend on the group size
@@ -251,6 +252,7 @@ int gto_create(const gto_robot_desc* d, const gto_solver_opts* opts, int device,
   if (const char* e = getenv("GTO_SPEC_FEW")) h->spec_few = std::max(0, atoi(e));
   if (const char* e = getenv("GTO_OBS_DEEP")) h->obs_deep = atoi(e) ? 1 : 0;
   if (const char* e = getenv("GTO_PREBROAD")) h->prebroad = atoi(e) != 0;
+  if (const char* e = getenv("GTO_PB_MERGE")) h->pb_merge = std::max(1, atoi(e));
   if (const char* e = getenv("GTO_PB_MIN_GAIN")) h->pb_min_gain = atof(e);
   if (const char* e = getenv("GTO_OBS_INTERLEAVE")) h->obs_interleave = std::max(0, std::min(2, atoi(e)));
   if (const char* e = getenv("GTO_DIST_RELAX")) h->dist_relax = atoi(e) ? 1 : 0;
@@ -364,7 +366,6 @@ int gto_create(const gto_robot_desc* d, const gto_solver_opts* opts, int device,
       const int src = p < 0 ? 0 : (p == i - 1 ? 1 : 2 + rb.xst_slot[p]);
       const bool moving_link = l >= 0 && (rb.frame_anc[rb.link_frame[l]] != 0u);
       rb.pb_ctl[i] = (src & 7) | (((rb.xst_slot[i] + 1) & 7) << 4) | ((moving_link ? 1 : 0) << 8);
-      for (int e = 0; e < 12; ++e) rb.pb_vo[i][e] = moving_link ? (float)rb.vis_origin[l][e] : 0.f;
       rb.pb_par[i] = -1;
       if (rb.joint_type[i] != GTO_JOINT_FIXED && rb.opt_of_frame[i] < 0) rb.pb_par[i] = rb.pb_npar, rb.pb_parf[rb.pb_npar++] = i;
     }
@@ -597,8 +598,25 @@ int gto_create(const gto_robot_desc* d, const gto_solver_opts* opts, int device,
   }
   rb.n_chunks = (int)chunks.size();
   std::vector<PbChunk> pbchunks;
-  for (const Chunk& c : chunks)
-    if (!c.pad) pbchunks.push_back(PbChunk{c.cx, c.cy, c.cz, c.r, rb.link_frame[c.link], 0});
+  // The step kernel's spheres: runs of h->pb_merge consecutive chunks of a moving link under one sphere (the chunks follow a
+  // Morton curve, so a run is a compact patch; centre = mean of its points, radius = the farthest of them).  Coarser than
+  // the obstacle kernel's own test, which stays per chunk and exact: a sphere more lists a group more, never one less.
+  // Centre in the coordinates of the link's FRAME (visual origin applied here, in double: the tail's walk stops at the frames).
+  for (size_t ci = 0; ci < chunks.size();) {
+    const Chunk& c = chunks[ci];
+    if (c.pad) { ++ci; continue; }
+    size_t cj = ci;
+    int i0 = c.start, i1 = c.start;
+    while (cj < chunks.size() && cj - ci < (size_t)h->pb_merge && !chunks[cj].pad && chunks[cj].link == c.link) i1 = chunks[cj].start + chunks[cj].count, ++cj;
+    double cx = 0, cy = 0, cz = 0, r2 = 0;
+    for (int k = i0; k < i1; ++k) cx += px[k], cy += py[k], cz += pz[k];
+    cx /= (i1 - i0), cy /= (i1 - i0), cz /= (i1 - i0);
+    for (int k = i0; k < i1; ++k) r2 = std::max(r2, (px[k] - cx) * (px[k] - cx) + (py[k] - cy) * (py[k] - cy) + (pz[k] - cz) * (pz[k] - cz));
+    const double* V = rb.vis_origin[c.link];
+    pbchunks.push_back(PbChunk{V[0] * cx + V[1] * cy + V[2] * cz + V[3], V[4] * cx + V[5] * cy + V[6] * cz + V[7], V[8] * cx + V[9] * cy + V[10] * cz + V[11],
+                               std::sqrt(r2) * (1.0 + 1e-9) + 1e-12, rb.link_frame[c.link], 0});
+    ci = cj;
+  }
   h->pb_C = (int)pbchunks.size();
   if (pbchunks.empty()) pbchunks.push_back(PbChunk{0, 0, 0, 0, 0, 0});  // (a robot none of whose links moves: the table is never read)
   if (rb.n_chunks > GTO_MAX_ACTIVE) { delete h; return fail(nullptr, GTO_ERR_UNSUPPORTED, "too many surface points (max 16384)"); }

@@ -55,7 +55,6 @@ struct RobotDev {
   int32_t n_cframes, fk_rounds_c;
   int32_t pb_ctl[GTO_MAX_FRAMES];   // control words of the step kernel's serial walk over the tree (gto_kernels.h, GTO_PB_SRC ...)
   double pb_eps;                     // widening of its culling radius, metres (single-precision storage of the transforms)
-  float pb_vo[GTO_MAX_FRAMES][12];   // visual origin of the moving link on a frame (zeros: none), single precision
   int32_t pb_par[GTO_MAX_FRAMES];    // slot of the frame's joint among the actuated joints that are not optimised, or -1
   int32_t pb_parf[GTO_MAX_FRAMES];   // frame of such a slot
   int32_t pb_npar;
