@@ -388,7 +388,7 @@ int gto_create(const gto_robot_desc* d, const gto_solver_opts* opts, int device,
       maxr = std::max(maxr, std::sqrt(pp[0] * pp[0] + pp[1] * pp[1] + pp[2] * pp[2]));
     }
     D += maxp + maxr;
-    rb.pb_eps = 64.0 * d->n_frames * 5.9604644775390625e-08 * D;  // four times the first-order bound 16 F 2^-24 D (gto_kernels.h, PbLayout)
+    rb.pb_eps = 128.0 * d->n_frames * 5.9604644775390625e-08 * D;  // four times the first-order bound 32 F 2^-24 D (gto_kernels.h, PbLayout)
   }
   {  // operand tables of fk_mfma_tree: the full tree, and the compact tree of the obstacle kernel (gto_device.h)
     const int F = d->n_frames, L = d->n_links, n = d->n_opt;
@@ -1582,7 +1582,7 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
       for (int i = 192; i < 256; ++i) fprintf(stderr, " %lld", t[i]);
       fprintf(stderr, "\n");
     }
-    fprintf(stderr, "[gto dbg] broad phase of the step kernel (GTO_DEBUG_CUT=10, -DGTO_DEBUG_LONGEST_WG: settled groups are looked at anyway): %lld groups settled, %lld of them with a surviving chunk\n", t[49], t[50]);
+    fprintf(stderr, "[gto dbg] broad phase of the step kernel (GTO_DEBUG_CUT=10, -DGTO_DEBUG_LONGEST_WG: settled groups are looked at anyway): %lld groups settled, %lld of them with a surviving chunk, %lld with a CONTRIBUTION (must be 0)\n", t[49], t[50], t[55]);
     {
       fprintf(stderr, "[gto dbg] workgroups without a surviving chunk by the index shift their closest chunk tolerates (0,1,2,...,63+):");
       for (int i = 128; i < 192; ++i) fprintf(stderr, " %lld", t[i]);
