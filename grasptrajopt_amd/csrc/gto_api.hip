@@ -1137,7 +1137,7 @@ static int launch_obstacle(gto_handle* h, hipStream_t st, const BatchPtrs& bp, c
   // this round's job list and its length (the kernel's first, preloaded, arguments); null outside the solve loop
   const bool listed = bp.live != nullptr && !fixed_mode;
   const int32_t* jobs_par = listed ? bp.jobs + (size_t)sp.parity * bp.cap * sp.kcap : nullptr;
-  const int32_t* njobs_par = listed ? bp.nlive + 2 + sp.parity : nullptr;
+  const int32_t* njobs_par = listed ? bp.nlive + GTO_NJOBS(sp.parity) : nullptr;
   // rounds behind a step kernel that ran the broad phase itself: the regular workgroups are laid out over its list of (job, group) pairs
   const size_t items_cap = (size_t)bp.cap * sp.kcap * (sp.T - 2) + GTO_ITEM_SLACK;
   const int2* items_par = listed && itemized ? bp.items + (size_t)sp.parity * items_cap : nullptr;
