@@ -83,6 +83,7 @@ struct gto_handle {
   // the obstacles (neighbours in time) land in different workgroups: 0 never, 1 always, 2 (default) in launches with few
   // instances in flight, where the longest workgroup decides the round (+5 % for one batch at a time, -2 % at saturation)
   int obs_interleave = 2;
+  int static_pos = 1;  // GTO_STATIC_POS=0: every instance draws its list positions from the counters in every round
   int pb_merge = 4;  // GTO_PB_MERGE: chunks of a link under one sphere of the step kernel's broad phase
   int prebroad = 1;  // GTO_PREBROAD=0: every (job, group) gets a workgroup of the obstacle kernel in every round
   double pb_min_gain = 0.10;  // GTO_PB_MIN_GAIN: a call whose step-kernel broad phase settles less than this share of the groups stops running it
@@ -253,6 +254,7 @@ int gto_create(const gto_robot_desc* d, const gto_solver_opts* opts, int device,
   if (const char* e = getenv("GTO_OBS_DEEP")) h->obs_deep = atoi(e) ? 1 : 0;
   if (const char* e = getenv("GTO_PREBROAD")) h->prebroad = atoi(e) != 0;
   if (const char* e = getenv("GTO_PB_MERGE")) h->pb_merge = std::max(1, atoi(e));
+  if (const char* e = getenv("GTO_STATIC_POS")) h->static_pos = atoi(e) != 0;
   if (const char* e = getenv("GTO_PB_MIN_GAIN")) h->pb_min_gain = atof(e);
   if (const char* e = getenv("GTO_OBS_INTERLEAVE")) h->obs_interleave = std::max(0, std::min(2, atoi(e)));
   if (const char* e = getenv("GTO_DIST_RELAX")) h->dist_relax = atoi(e) ? 1 : 0;
@@ -1013,6 +1015,7 @@ static SolveParams make_params(const gto_handle* h, int n_max, bool use_standoff
   sp.lambda0 = o.lambda0;
   sp.dbg_cut = h->dbg_cut;
   sp.interleave = h->obs_interleave == 1;
+  sp.static_pos = 0;
   sp.pb_next = 0, sp.pb_tg = 1, sp.pb_ng = 1, sp.pb_pw = 1, sp.pb_verify = 0;
   sp.pb_C = h->pb_C, sp.pb_tab0 = 0, sp.pb_mC = ObsGeom::magic(std::max(1, h->pb_C)), sp.pb_mF = ObsGeom::magic(h->rb.n_frames);
   sp.pb_eps = h->rb.pb_eps;
@@ -1223,6 +1226,7 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
     SolveParams sp;
     int lo = 0, n = 0, W = 0, cap = 0;  // first instance, instances, in flight at the start, list capacity
     int room = 0;                       // positions its lists can have in use: W + what it adopted
+    int span_prev = 0;                  // static positions: positions the current lists span (the last one-candidate launch's grid), 0: compact lists
     int n_resp = 0;                     // instances whose end this lane's finished-counter counts (own + adopted)
     int k = 0, known_done = 0, seen_round = -1, k_prev = 1;
     bool items_ready = false, pb_off = false, handed = false;
@@ -1346,6 +1350,10 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
     const int k = ln.k;
     const int in_flight = std::min(ln.room, ln.n_resp - ln.known_done);
     const bool few = in_flight <= h->few_instances;
+    // positions this round's lists span: compact lists hold the instances in flight; lists of a launch with static positions
+    // keep that launch's span (instances that finished without a successor left void positions behind)
+    const int span = ln.span_prev ? ln.span_prev : in_flight;
+    ln.span_prev = 0;
     if (few && !ln.few_us) ln.few_us = (long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - tp_start).count();
     const int tg = few ? h->obs_tg_few : h->obs_tg;
     SolveParams& lsp = ln.sp;
@@ -1372,7 +1380,7 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
       }
       if (h->item_hint_forced > 0) items_hint = h->item_hint_forced;  // (tests: a launch of a few workgroups, the crew does the rest)
     }
-    if ((rc_ = launch_obstacle(h, ln.st, ln.bp, lsp, B, 2, T - 2, 0, h->profiling, true, in_flight * ln.k_prev, tg, few && h->obs_deep && in_flight <= h->obs_deep_max, itemized, items_hint))) return rc_;
+    if ((rc_ = launch_obstacle(h, ln.st, ln.bp, lsp, B, 2, T - 2, 0, h->profiling, true, span * ln.k_prev, tg, few && h->obs_deep && in_flight <= h->obs_deep_max, itemized, items_hint))) return rc_;
     if (h->np == GTO_NB) {
       if (few && h->step_nw_few == 8) {
         // few instances in flight: eight waves per instance and candidate trial points ahead of their evaluation
@@ -1382,7 +1390,8 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
         const int kl = std::max(lsp.k_acc, lsp.k_rej);
         lsp.pb_next = 0;
         if (h->profiling && (rc_ = prof_begin(h, ln.st, GTO_PROF_STEP_FEW, in_flight))) return rc_;
-        hipLaunchKernelGGL((k_lm_step<8, GTO_KSPEC>), dim3(in_flight), dim3(512), lm_lds_bytes(T, kl), ln.st, h->d_rb, h->d_pbchunks, ln.bp, lsp, B);
+        lsp.static_pos = 0;
+        hipLaunchKernelGGL((k_lm_step<8, GTO_KSPEC>), dim3(span), dim3(512), lm_lds_bytes(T, kl), ln.st, h->d_rb, h->d_pbchunks, ln.bp, lsp, B);
         if (h->profiling && (rc_ = prof_end(h, ln.st))) return rc_;
         ln.k_prev = kl;
       } else {
@@ -1399,7 +1408,9 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
         }
         lsp.pb_next = pb_ok && !ln.pb_off && !few;
         if (h->profiling && (rc_ = prof_begin(h, ln.st, GTO_PROF_STEP, in_flight))) return rc_;
-        hipLaunchKernelGGL((k_lm_step<4, 1>), dim3(in_flight), dim3(256), h->lm_lds, ln.st, h->d_rb, h->d_pbchunks, ln.bp, lsp, B);
+        lsp.static_pos = h->static_pos && L == 1 && !few;
+        hipLaunchKernelGGL((k_lm_step<4, 1>), dim3(span), dim3(256), h->lm_lds, ln.st, h->d_rb, h->d_pbchunks, ln.bp, lsp, B);
+        if (lsp.static_pos) ln.span_prev = span;
         if (h->profiling && (rc_ = prof_end(h, ln.st))) return rc_;
         ln.k_prev = 1;
         ln.items_ready = lsp.pb_next != 0;

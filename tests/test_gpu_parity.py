@@ -296,7 +296,8 @@ def test_slots_hand_over_to_waiting_instances(capi, oracle_mod, monkeypatch, slo
                                  {"GTO_OBS_TG": "2"}, {"GTO_OBS_TG": "5"}, {"GTO_FEW_INSTANCES": "16"}, {"GTO_PB_MIN_GAIN": "2"},
                                  {"GTO_SLOTS": "1", "GTO_FEW_INSTANCES": "0", "GTO_OBS_TG": "1"},
                                  {"GTO_ITEM_GRID": "0"}, {"GTO_ITEM_HINT": "8"}, {"GTO_ITEM_HINT": "40", "GTO_SLOTS": "96"},
-                                 {"GTO_ITEM_HINT": "300", "GTO_OBS_TG": "2"}])
+                                 {"GTO_ITEM_HINT": "300", "GTO_OBS_TG": "2"},
+                                 {"GTO_STATIC_POS": "0"}, {"GTO_STATIC_POS": "0", "GTO_SLOTS": "96"}, {"GTO_PB_MERGE": "1"}, {"GTO_PB_MERGE": "100", "GTO_SLOTS": "96"}])
 def test_step_kernel_broad_phase_does_not_change_results(capi, oracle_mod, monkeypatch, env):
     """In the rounds that fill the GPU the step kernel tests the bounding spheres of its new trial trajectory itself
     (prebroad_tail: serial kinematics per lane instead of the obstacle kernel's matrix-core prefix), settles the waypoint
@@ -307,7 +308,9 @@ def test_step_kernel_broad_phase_does_not_change_results(capi, oracle_mod, monke
     the same trajectories, costs and iteration counts; and they match the oracle, which culls nothing.  The itemized launch
     is laid out over an estimate of the list's length with a crew of 64 looping workgroups behind it for the rest
     (GTO_ITEM_GRID=0: over the upper bound, no crew; GTO_ITEM_HINT: the estimate itself -- 8: the crew does nearly
-    everything, several items per workgroup)."""
+    everything, several items per workgroup).  GTO_STATIC_POS=0: every instance draws its positions in the next round's lists
+    from the lists' counters instead of keeping them (with refills: 96 positions); GTO_PB_MERGE: chunks of a link under one
+    sphere of the step kernel's test (1: the chunks' own spheres, 100: whole links)."""
     prob = Problem("panda_5k", B=160, scene_seed=5, n=64, res=0.035, n_goals=1)
     # (a call of 160 would run in the launches for few instances from its first round: the broad phase belongs to the others)
     monkeypatch.setenv("GTO_FEW_INSTANCES", "64")
