@@ -114,7 +114,7 @@ def main(argv=None, emit=True):
     ap.add_argument("--pipeline", type=int, default=4, help="lanes per GPU: solver handles, each with its stream and host thread")
     ap.add_argument("--lanes", type=int, default=0, help="lanes INSIDE a solver call (gto_set_lanes), each on a torch stream of its own; 0: the library's default")
     ap.add_argument("--merge", type=int, default=32, help="steps (batches) a lane hands to the solver in one call; the solver keeps "
-                    "GTO_SLOTS (384) of their instances in flight and refills slots as instances finish")
+                    "GTO_SLOTS (512) of their instances in flight and refills slots as instances finish")
     ap.add_argument("--max-iter", type=int, default=100, help="iteration cap (reference IPOPT cap: 100)")
     ap.add_argument("--robot", default="panda_5k")
     ap.add_argument("--grid", type=int, default=128)
@@ -216,7 +216,7 @@ def main(argv=None, emit=True):
         D_new = max(1, min(D, int(quota_ // world)))
         lane_decision = f"{D_new} lanes per rank: cgroup CPU quota {quota_} < {world} ranks x {D} lanes"
         D = D_new
-    slots = int(os.environ.get("GTO_SLOTS", "384"))  # instances a solver call keeps in flight (gto_api.hip)
+    slots = int(os.environ.get("GTO_SLOTS", "512"))  # instances a solver call keeps in flight (gto_api.hip)
     mode = _capi.SolverHandle.MODE_ROUNDS
     kernel_name = "k_obstacle_gram"
 

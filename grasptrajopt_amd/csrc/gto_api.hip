@@ -117,7 +117,7 @@ struct gto_handle {
   size_t lm_lds = 0;
   int np = GTO_NB;     // block width of the normal equations: 8 (up to eight optimised joints) or 16
   DevBuf zws;          // k_lm_step_wide: block inverses [slots][T-2][np*np]
-  int slots = 384;  // instances in flight per lane of a solve call (GTO_SLOTS); a finished instance hands its slot to the next one
+  int slots = 512;  // instances in flight per lane of a solve call (GTO_SLOTS); a finished instance hands its slot to the next one
   // lanes of a solve call (gto_solve_batch_device): at most lanes_max, each with at least lane_min instances; a lane with
   // at most adopt_below instances left hands them to lane 0 (0: never).  gto_set_lanes / GTO_LANES, GTO_LANE_MIN, GTO_ADOPT
   int lanes_max = 1, lane_min = 256, adopt_below = 0;

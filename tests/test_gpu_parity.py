@@ -273,7 +273,7 @@ def test_slots_hand_over_to_waiting_instances(capi, oracle_mod, monkeypatch, slo
     every instance gets bit-for-bit the trajectory it gets with all instances in flight from the start, and the
     oracle's iteration counts and status."""
     prob = Problem("panda", B=13, scene_seed=2, n_goals=2)
-    h, o = make_pair(capi, oracle_mod, prob, max_iter=12)  # default: 384 slots, the whole batch in flight
+    h, o = make_pair(capi, oracle_mod, prob, max_iter=12)  # default: 512 slots, the whole batch in flight
     ref = h.solve_batch(*prob.solve_args())
     monkeypatch.setenv("GTO_SLOTS", str(slots))
     h2 = capi.SolverHandle(prob.desc, prob.cfg["link_ee"], prob.cfg["link_gripper"], oracle_mod.reference_opts(max_iter=12), device=0)

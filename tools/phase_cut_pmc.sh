@@ -15,7 +15,7 @@ cd $GRAFT_REPO_ROOT
 python - $out <<'PY'
 import csv, glob, os, sys, collections
 out = sys.argv[1]
-GRID = int(os.environ.get("PHASE_CUT_GRID", 384 * 16 * 256))  # threads of the evaluation launch: B x 16 waypoint groups x 256
+GRID = int(os.environ.get("PHASE_CUT_GRID", int(os.environ.get("GTO_SLOTS", "512")) * 16 * 256))  # threads of the evaluation launch: B x 16 waypoint groups x 256
 rows = collections.defaultdict(dict)
 for d in sorted(glob.glob(os.path.join(out, "c*_*"))):
     if not os.path.isdir(d):

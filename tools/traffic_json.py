@@ -58,7 +58,7 @@ for spec in sys.argv[2:]:
                 variants[n_.replace(", ", ",")]["critical_path_over_launch"] = round(st_["critical_path_cycles"] / max(v_.get("mean_us", 0.0) * st_["ticks_per_us"], 1.0), 3)
     simd_cycles = 1024 * us * 1e-6 * 2.4e9  # 256 CUs x 4 SIMDs at 2.4 GHz
     entries.append({
-        "robot": robot_, "grid": grid_, "shelf": bool(shelf_), "mode": "rounds", "instances_per_call": size, "slots": 384,
+        "robot": robot_, "grid": grid_, "shelf": bool(shelf_), "mode": "rounds", "instances_per_call": size, "slots": int(os.environ.get("GTO_SLOTS", "512")),
         "source": f"profiles/{tag}_{os.path.basename(d.rstrip('/'))}.txt (tools/pmc_pass.sh: rocprofv3 --kernel-trace --pmc, separate passes, bench.py --pipeline 1 "
                   f"--merged-launches-only with calls of {size} instances)",
         "kernel": kname, "variants": variants, "launches": k["launches"], "mean_launch_us_profiled": round(us, 2),
