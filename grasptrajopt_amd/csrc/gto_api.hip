@@ -76,6 +76,13 @@ struct gto_handle {
   int spec_streak = 4;  // GTO_SPEC_STREAK: first candidate accepted this many rounds in a row -> one candidate after the next accepted evaluation (0: off)
   int obs_deep_max = 32;  // GTO_OBS_DEEP_MAX: ... only up to this many instances in flight (two workgroups per CU: beyond that the five-per-CU variant gets through a launch faster)
   int obs_deep = 1;   // GTO_OBS_DEEP: launches with few instances in flight use the obstacle kernel variant with deep gather batches
+  // The tail of a LARGE call (more than spec_deep instances from the start) shares the GPU with the other lanes' launches,
+  // and there an evaluation that turns out not to be needed costs more than the round it might save: fewer candidates
+  // after an accepted evaluation, the single candidate after a shorter run of first-try accepts, three waypoints per
+  // obstacle workgroup (GTO_SPEC_ACC_TAIL, GTO_SPEC_STREAK_TAIL, GTO_OBS_TG_FEW_TAIL; the driver's 20-step call 253 -> 262 k).
+  // A call that is small from its first round (one grasp, a batch of a few) is alone on the GPU and keeps the settings
+  // that give the shortest chain of rounds (one instance: 0.66 ms; with the tail's settings 0.90 ms).
+  int spec_acc_tail = 2, spec_streak_tail = 2, obs_tg_few_tail = 3;
   int spec_few = 64;  // GTO_SPEC_FEW: speculation starts once at most this many instances are in flight: before that the GPU is full and every extra evaluation costs time
   int dbg_cut = 0;
   int dist_relax = 0;  // GTO_DIST_RELAX: build the distance fields by relaxation sweeps instead of the separable passes
@@ -246,9 +253,11 @@ int gto_create(const gto_robot_desc* d, const gto_solver_opts* opts, int device,
   if (const char* e = getenv("GTO_AHEAD")) h->ahead = h->ahead_few = std::max(1, atoi(e));
   if (const char* e = getenv("GTO_SPEC_REJ")) h->spec_rej = std::max(1, std::min(GTO_KSPEC, atoi(e)));
   if (const char* e = getenv("GTO_SPEC_REJ_FEW")) h->spec_rej_few = std::max(1, std::min(GTO_KSPEC, atoi(e)));
-  if (const char* e = getenv("GTO_SPEC_STREAK")) h->spec_streak = std::max(0, atoi(e));
+  if (const char* e = getenv("GTO_SPEC_STREAK")) h->spec_streak = h->spec_streak_tail = std::max(0, atoi(e));
+  if (const char* e = getenv("GTO_SPEC_STREAK_TAIL")) h->spec_streak_tail = std::max(0, atoi(e));
   if (const char* e = getenv("GTO_SPEC_JOBS")) h->spec_jobs = std::max(1, atoi(e));
-  if (const char* e = getenv("GTO_SPEC_ACC")) h->spec_acc = std::max(1, std::min(GTO_KSPEC, atoi(e)));
+  if (const char* e = getenv("GTO_SPEC_ACC")) h->spec_acc = h->spec_acc_tail = std::max(1, std::min(GTO_KSPEC, atoi(e)));
+  if (const char* e = getenv("GTO_SPEC_ACC_TAIL")) h->spec_acc_tail = std::max(1, std::min(GTO_KSPEC, atoi(e)));
   if (const char* e = getenv("GTO_SPEC_DEEP")) h->spec_deep = std::max(0, atoi(e));
   if (const char* e = getenv("GTO_SPEC_FEW")) h->spec_few = std::max(0, atoi(e));
   if (const char* e = getenv("GTO_OBS_DEEP")) h->obs_deep = atoi(e) ? 1 : 0;
@@ -267,8 +276,9 @@ int gto_create(const gto_robot_desc* d, const gto_solver_opts* opts, int device,
   if (const char* e = getenv("GTO_LANES")) h->lanes_max = std::max(1, std::min(GTO_MAX_LANES, atoi(e)));
   if (const char* e = getenv("GTO_LANE_MIN")) h->lane_min = std::max(1, atoi(e));
   if (const char* e = getenv("GTO_ADOPT")) h->adopt_below = std::max(0, atoi(e));
-  if (const char* e = getenv("GTO_OBS_TG")) h->obs_tg = h->obs_tg_few = std::max(1, std::min(GTO_MAX_TG, atoi(e)));
-  if (const char* e = getenv("GTO_OBS_TG_FEW")) h->obs_tg_few = std::max(1, std::min(GTO_MAX_TG, atoi(e)));
+  if (const char* e = getenv("GTO_OBS_TG")) h->obs_tg = h->obs_tg_few = h->obs_tg_few_tail = std::max(1, std::min(GTO_MAX_TG, atoi(e)));
+  if (const char* e = getenv("GTO_OBS_TG_FEW")) h->obs_tg_few = h->obs_tg_few_tail = std::max(1, std::min(GTO_MAX_TG, atoi(e)));
+  if (const char* e = getenv("GTO_OBS_TG_FEW_TAIL")) h->obs_tg_few_tail = std::max(1, std::min(GTO_MAX_TG, atoi(e)));
   if (const char* e = getenv("GTO_FEW_INSTANCES")) h->few_instances = atoi(e);
   if (const char* e = getenv("GTO_STEP_NW_FEW")) h->step_nw_few = atoi(e) == 8 ? 8 : 4;
   if (getenv("GTO_DEBUG_TIMING")) { (void)hipMalloc((void**)&h->dbg, 256 * sizeof(long long)); (void)hipMemset(h->dbg, 0, 256 * sizeof(long long)); }
@@ -657,7 +667,7 @@ int gto_create(const gto_robot_desc* d, const gto_solver_opts* opts, int device,
       gto_destroy(h);
       return fail(nullptr, GTO_ERR_HIP, "hipFuncSetAttribute failed");
     }
-    if (w) h->obs_tg = h->obs_tg_few = std::min(h->obs_tg, 2);  // wider blocks: two waypoints per workgroup keep its LDS small
+    if (w) h->obs_tg = h->obs_tg_few = h->obs_tg_few_tail = std::min(h->obs_tg, 2);  // wider blocks: two waypoints per workgroup keep its LDS small
   }
   *out = h;
   return GTO_OK;
@@ -1355,7 +1365,8 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
     const int span = ln.span_prev ? ln.span_prev : in_flight;
     ln.span_prev = 0;
     if (few && !ln.few_us) ln.few_us = (long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - tp_start).count();
-    const int tg = few ? h->obs_tg_few : h->obs_tg;
+    const bool large_call = ln.n_resp > h->spec_deep;  // (its tail: the other lanes' launches are on the GPU, too)
+    const int tg = few ? (large_call ? h->obs_tg_few_tail : h->obs_tg_few) : h->obs_tg;
     SolveParams& lsp = ln.sp;
     lsp.interleave = h->obs_interleave == 1 || (h->obs_interleave == 2 && few);
     const bool itemized = ln.items_ready && !few;
@@ -1385,7 +1396,8 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
       if (few && h->step_nw_few == 8) {
         // few instances in flight: eight waves per instance and candidate trial points ahead of their evaluation
         const int k_budget = std::max(1, h->spec_jobs / std::max(1, in_flight));
-        lsp.k_acc = in_flight <= std::min(h->spec_deep, h->spec_few) ? std::min(std::min(h->spec_acc, k_budget), h->spec_kmax) : 1;
+        lsp.k_acc = in_flight <= std::min(h->spec_deep, h->spec_few) ? std::min(std::min(large_call ? h->spec_acc_tail : h->spec_acc, k_budget), h->spec_kmax) : 1;
+        lsp.spec_streak = large_call ? h->spec_streak_tail : h->spec_streak;
         lsp.k_rej = in_flight <= h->spec_few ? std::min(std::max(std::min(h->spec_rej, k_budget), h->spec_rej_few), h->spec_kmax) : 1;
         const int kl = std::max(lsp.k_acc, lsp.k_rej);
         lsp.pb_next = 0;
