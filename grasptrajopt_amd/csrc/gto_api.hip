@@ -368,6 +368,9 @@ int gto_create(const gto_robot_desc* d, const gto_solver_opts* opts, int device,
     rb.link_of_frame[rb.link_frame[l]] = l;
   }
   rb.n_xst = 0;
+  rb.frame_free_mask = 0u;
+  for (int i = 0; i < d->n_frames; ++i)
+    if (rb.opt_of_frame[i] < 0) rb.frame_free_mask |= 1u << i;
   for (int i = 0; i < d->n_frames; ++i) {
     const int p = rb.parent[i];
     if (p >= 0 && p != i - 1 && rb.xst_slot[p] < 0) rb.xst_slot[p] = rb.n_xst++;

@@ -68,6 +68,7 @@ struct RobotDev {
   // serial FK walk of k_traj_solve: frames whose transform a later, non-adjacent child needs are parked in LDS
   int32_t xst_slot[GTO_MAX_FRAMES];      // parking slot of this frame's transform, or -1
   int32_t n_xst;
+  uint32_t frame_free_mask;  // bit f: frame f is not the frame of an optimised joint (its joint value never changes in a solve)
   int32_t opt_of_dof[GTO_MAX_DOF];       // optimised-joint slot of actuated joint i, or -1 (parameter joint)
   uint32_t frame_anc[GTO_MAX_FRAMES];    // bit j: optimised joint j moves this frame
   double origin[GTO_MAX_FRAMES][12];     // rt2tr(rpy2r(rpy), xyz)  (optas/models.py:848-857)
