@@ -146,6 +146,20 @@ def test_ranks_on_one_device_hip_solver_equals_single_process(tmp_path, world):
     assert 0 < r["scenes_on_rank0"] < 16 and r["iters_distinct"] > 1
 
 
+def _bench_lines(stdout):
+    """bench.py prints the full record on a `BENCH_DETAIL` line and the compact line the driver parses LAST (under 6 KB,
+    with the contract's keys); the tests read the detail and require the compact line to agree on the headline."""
+    import json
+    lines = stdout.splitlines()
+    compact = json.loads([l for l in lines if l.startswith("{")][-1])
+    assert lines[-1].startswith("{") and len(lines[-1]) < 6000, len(lines[-1])
+    detail = json.loads([l for l in lines if l.startswith("BENCH_DETAIL ")][-1][len("BENCH_DETAIL "):])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "scaling", "dtype", "lib_sha16"):
+        assert compact[k] == detail[k], k
+    assert compact["roofline"]["frac"] == detail["roofline"]["frac"] and compact["quality"]["gate"] == detail["quality"]["gate"]
+    return detail
+
+
 def test_bench_two_ranks_dry_run_on_one_device():
     """bench.py's N > 1 code path (rank environment, barrier + max-over-ranks timing, scene-sharded leg with its gather),
     run as the driver would launch it but with gloo and both ranks on the one device: the JSON line says n_gpus 2, the
@@ -155,7 +169,7 @@ def test_bench_two_ranks_dry_run_on_one_device():
            "--merge", "2", "--repeats", "2", "--scenes-per-gpu", "6", "--no-cpu-baseline"]
     res = subprocess.run(cmd, env=dict(os.environ, MASTER_ADDR="127.0.0.1"), capture_output=True, text=True, timeout=900)
     assert res.returncode == 0, (res.stdout + res.stderr)[-3000:]
-    d = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    d = _bench_lines(res.stdout)
     assert d["n_gpus"] == 2 and d["steps"] == 8 and d["scaling"] == "weak"
     ss = d["scene_sharded"]
     assert ss["instances"] == 2 * 6 * 8 and ss["all_instances_returned"] and ss["own_shard_round_trip_exact"]
@@ -173,7 +187,7 @@ def test_bench_eight_ranks_dry_run_on_one_device():
            "--merge", "1", "--repeats", "1", "--scenes-per-gpu", "4", "--no-cpu-baseline"]
     res = subprocess.run(cmd, env=dict(os.environ, MASTER_ADDR="127.0.0.1"), capture_output=True, text=True, timeout=1500)
     assert res.returncode == 0, (res.stdout + res.stderr)[-3000:]
-    d = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    d = _bench_lines(res.stdout)
     assert d["n_gpus"] == 8 and d["steps"] == 4 and d["scaling"] == "weak"
     ss = d["scene_sharded"]
     assert ss["instances"] == 8 * 4 * 8 and ss["all_instances_returned"] and ss["own_shard_round_trip_exact"]
@@ -198,7 +212,7 @@ def test_bench_rccl_branch_with_one_rank():
            "--repeats", "1", "--scenes-per-gpu", "4", "--no-cpu-baseline"]
     res = subprocess.run(cmd, env=dict(os.environ, MASTER_ADDR="127.0.0.1"), capture_output=True, text=True, timeout=900)
     assert res.returncode == 0, (res.stdout + res.stderr)[-3000:]
-    d = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    d = _bench_lines(res.stdout)
     col = d["collective"]
     assert col["backend"] == "nccl" and col["is_rccl"] and col["world_size"] == 1 and col["nccl_version"]
     assert col["ranks"][0]["all_gather"]["backend"] == "nccl" and col["ranks"][0]["all_gather"]["collectives"] == 2

@@ -162,3 +162,42 @@ def test_bench_call_plan_times_exactly_k_steps():
                         assert len(plan) % lanes == 0 or len(plan) == -(-n // merge)
     assert bench.plan_calls(512, 4, 32) == [32] * 16
     assert bench.plan_calls(5, 4, 32) == [2, 1, 1, 1]
+
+
+def test_bench_final_line_stays_under_six_kilobytes():
+    """The driver parses the LAST stdout line of bench.py and its record keeps an 8 KB tail: round 5's 21.6 KB line came back
+    `parsed: null`.  bench.compact_line() of the largest lines on record (profiles/r05_bench*.json, 21 KB each) has to
+    stay under 6000 bytes and carry every key of the contract, with the roofline recomputable from it."""
+    import importlib.util
+    import json
+    import pathlib
+    root = pathlib.Path(__file__).resolve().parents[1]
+    spec = importlib.util.spec_from_file_location("bench", root / "bench.py")
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for name in ("r05_bench_steps20.json", "r05_bench.json"):
+        full = json.loads((root / "profiles" / name).read_text().strip().splitlines()[-1])
+        assert len(json.dumps(full)) > 20000
+        line = bench.compact_line(full)
+        text = json.dumps(line)
+        assert len(text) < bench.LINE_LIMIT <= 6000, len(text)
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                  "dtype", "data", "config", "roofline", "cpu_baseline", "timed_regions", "host_api", "quality", "other_configs", "lib_sha16"):
+            assert k in line, k
+        assert line["value"] == full["value"] and line["config"]["workload"].startswith("BASELINE configs[1]")
+        rf = line["roofline"]
+        for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "alg_bytes_per_launch", "avg_launch_us",
+                  "alg_bytes_skipped_frac", "traffic_over_alg_bytes", "dominant_by_time"):
+            assert k in rf, k
+        # recomputable: algorithmic bytes per launch over the launch's duration, over the peak
+        assert abs(rf["alg_bytes_per_launch"] / (rf["avg_launch_us"] * 1e-6) / 1e9 / rf["peak"] - rf["frac"]) < 2e-3 * max(rf["frac"], 1e-3) + 1e-4
+        cb = line["cpu_baseline"]
+        assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
+        assert line["quality"]["gate"] == "pass" and 0 < line["quality"]["goal_ok_frac"] <= 1
+        for v in line["other_configs"].values():
+            assert v["oracle_check_ok"] and v["trajectories_per_s"] > 0 and v["frac"] > 0
+    # a line that would still be too long drops its optional objects instead of growing
+    fat = dict(full, other_configs={f"configs[{i}]": v for i in range(40) for v in full["other_configs"].values()})
+    fat["config"] = dict(fat["config"], workload=fat["config"]["workload"] + "x" * 5000)
+    slim = bench.compact_line(fat)
+    assert len(json.dumps(slim)) < 6000 and slim["other_configs"] is None and slim["roofline"]["frac"] == full["roofline"]["frac"]
