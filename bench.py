@@ -322,14 +322,24 @@ def main(argv=None, emit=True):
             return None if q_ == "max" else round(int(q_) / int(p_), 2)
         except Exception:
             return None
-    # every lane is a host thread that sleep-polls two pinned words (about 0.2 of a core each at four lanes); N ranks x D
-    # lanes must fit the CPUs this cgroup may use, or the lanes' naps turn into scheduling delays on every rank
+    # every lane is a host thread that sleep-polls two pinned words: LANE_CORES of a core each, measured (host_cpu_cores_busy
+    # 1.05-1.06 for four lanes on the driver's call, 0.66 on the default run: pipeline.host_cpu_cores_busy of every line);
+    # N ranks x D lanes plus RANK_CORES for a rank's main thread must fit the CPUs this cgroup may use, or the lanes' naps
+    # turn into scheduling delays on every rank.  (Round 5 cut to quota // ranks lanes -- one core per lane, four times
+    # what a lane takes: 2 lanes per rank at quota 16 / 8 ranks, where 8 x (0.5 + 4 x 0.27) = 12.6 cores fit.)
+    LANE_CORES, RANK_CORES = 0.27, 0.5
     quota_ = cpu_quota()
     lane_decision = f"{D} lanes per rank as asked for"
-    if world > 1 and quota_ is not None and quota_ < world * D:
-        D_new = max(1, min(D, int(quota_ // world)))
-        lane_decision = f"{D_new} lanes per rank: cgroup CPU quota {quota_} < {world} ranks x {D} lanes"
-        D = D_new
+    if world > 1 and quota_ is not None:
+        fit = int((quota_ / world - RANK_CORES) / LANE_CORES + 1e-9)
+        if fit < D:
+            D_new = max(1, fit)
+            lane_decision = (f"{D_new} lanes per rank: cgroup CPU quota {quota_} / {world} ranks = {quota_ / world:.2f} cores per rank < "
+                             f"{RANK_CORES} + {D} lanes x {LANE_CORES} cores (measured per lane)")
+            D = D_new
+        else:
+            lane_decision = (f"{D} lanes per rank as asked for: {world} ranks x ({RANK_CORES} + {D} x {LANE_CORES} measured cores per lane) = "
+                             f"{world * (RANK_CORES + D * LANE_CORES):.1f} <= cgroup CPU quota {quota_}")
     slots = int(os.environ.get("GTO_SLOTS", "512"))  # instances a solver call keeps in flight (gto_api.hip)
     mode = _capi.SolverHandle.MODE_ROUNDS
     kernel_name = "k_obstacle_gram"
@@ -470,6 +480,28 @@ def main(argv=None, emit=True):
             run_steps(pipe, min(args.steps, D * M), "host_step")
         host_all, _ = timed_regions("host_step")
     pipe.close()
+    # ---- the same K steps on ONE and on TWO of the lanes (N = 1 lines only): the per-GPU rate a rank would run at if the
+    # host budget of an 8-rank job left it fewer lanes than it asks for (DESIGN.md section 9's prediction rests on these)
+    lane_rates = None
+    if world == 1 and not child and not args.light and not args.merged_launches_only and D > 1:
+        lane_rates = {}
+        for nl in sorted({1, 2, D} - {D}):
+            sub = BatchPipeline(lanes[:nl])
+            D_keep, D = D, nl  # launch_plan splits the K steps over the lanes in use
+            try:
+                run_steps(sub, min(args.steps, nl * M))
+                ts_ = []
+                for _ in range(3):
+                    barrier()
+                    t0_ = time.perf_counter()
+                    run_steps(sub, args.steps)
+                    barrier()
+                    ts_.append(time.perf_counter() - t0_)
+            finally:
+                D = D_keep
+                sub.close()
+            lane_rates[str(nl)] = round(B * args.steps / float(np.median(ts_)), 1)
+        lane_rates[str(D)] = round(B * args.steps / float(np.median(el_all)), 1)
     ln0 = lanes[0]
     # a lane's results do not depend on what the other lanes do: lane 0 solves lane 1's batches again, alone on the GPU
     lanes_reproducible = None
@@ -964,6 +996,8 @@ def main(argv=None, emit=True):
                          "serial_ms_per_step": None if args.merged_launches_only else round(1e3 * serial_elapsed / args.steps, 3),
                          "serial_trajectories_per_s": None if args.merged_launches_only else round(B * args.steps / serial_elapsed, 2),
                          "host_cpu_cores_busy": round(host_cpu / elapsed, 2),
+                         # trajectories/s of the same K steps with 1 / 2 / all lanes (median of 3 regions; the last is `value`)
+                         "lane_rates": lane_rates,
                          "lane_results_reproducible_alone": lanes_reproducible, "merged_equals_single_batch_solves": merged_equals_single},
             "sqp_iters_per_s": round(iters_per_s, 1),
             # SURVEY.md 8d's metric: gto_solve_batch with host pointers, H2D / D2H of the per-instance data inside the timing,

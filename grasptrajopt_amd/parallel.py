@@ -1,4 +1,5 @@
-"""Multi-GPU layer: one process per GPU, instances sharded statically, no data-path collective.
+"""Multi-GPU layer: one process per GPU, instances sharded statically (shard_range / shard_by_scene) or drawn from a
+shared work queue (solve_work_queue), no data-path collective.
 
 Every (scene, goal-set) instance is an independent problem (gto/gto_planner.py:185-245 shares
 nothing across calls), so a node's 8 GPUs each solve a contiguous block of the instance list,
@@ -50,6 +51,22 @@ def _group_exists() -> bool:
     try:
         import torch.distributed as dist
         return dist.is_available() and dist.is_initialized()
+    except Exception:
+        return False
+
+
+def _collective_applies(world: int, group=None) -> bool:
+    """Whether a solve over `world` ranks ends in the collective.  world > 1: always (the caller's `group` has to have that
+    many ranks).  world == 1: only when the group the collective would run on HAS exactly one rank -- the one-rank RCCL
+    branch on a one-GPU box; a world=1 solve inside a larger job (default group of N > 1 ranks, no group passed) keeps its
+    local result instead of entering an N-rank collective with a one-rank receive list."""
+    if world > 1:
+        return True
+    if not _group_exists():
+        return False
+    import torch.distributed as dist
+    try:
+        return dist.get_world_size(group) == 1
     except Exception:
         return False
 
@@ -118,7 +135,7 @@ def solve_local_shard(solve_fn: Callable[..., tuple], mine, scene_id, qc, goals,
                           n_goals, standoff, base_pos, Q0.reshape(n, ndof, T))
     else:
         result = (np.empty((0, ndof, T)), np.empty((0, ndof, T - 1)), np.empty(0), np.empty(0, np.int32), np.empty(0, np.int32))
-    if not gather or (world == 1 and not _group_exists()):
+    if not gather or not _collective_applies(world, group):
         return (mine,) + tuple(result)
     return gather_results(mine, result, B, rank, world, group, assignment, stats)
 
@@ -142,6 +159,127 @@ def solve_sharded(solve_fn: Callable[..., tuple], scene_id, qc, goals, n_goals, 
     mine = _shard_indices(B, world, assignment)[rank]
     return solve_local_shard(solve_fn, mine, scene_id[mine], qc[mine], goals[mine], n_goals[mine],
                              None if so is None else so[mine], base_pos[mine], Q0[mine], B, rank, world, group, gather, assignment)
+
+
+_WQ_CALLS = [0]
+
+
+def _default_store():
+    """The key-value store of the default process group (TCPStore behind torch.distributed.run / init_process_group):
+    its add() is an atomic fetch-and-add served by rank 0's store daemon, for RCCL and gloo groups alike."""
+    import torch.distributed as dist
+    return dist.distributed_c10d._get_default_store()
+
+
+def scene_chunks(scene_id: Sequence[int], max_instances: int = 0) -> list:
+    """The units of the work queue: the instances of one scene (a scene's cost field is then uploaded by exactly one rank,
+    SURVEY.md 8e), split into runs of at most `max_instances` when that is given.  Chunks in the order of first appearance
+    of their scene; indices ascending inside a chunk."""
+    scene_id = np.asarray(scene_id)
+    order, seen = [], {}
+    for i, s in enumerate(scene_id.tolist()):
+        if s not in seen:
+            seen[s] = len(order)
+            order.append([])
+        order[seen[s]].append(i)
+    out = []
+    for idx in order:
+        step = max_instances if max_instances > 0 else len(idx)
+        out += [np.asarray(idx[i:i + step], dtype=np.int64) for i in range(0, len(idx), step)]
+    return out
+
+
+def solve_work_queue(solve_fns, chunks: Sequence[np.ndarray], make_args: Callable[[np.ndarray], tuple], B: int, rank: int, world: int,
+                     group=None, store=None, gather: bool = True, key: Optional[str] = None, stats: Optional[dict] = None):
+    """Dynamic balance across ranks ("a per-GPU work queue"): the chunks (scene_chunks) are claimed one at a
+    time through ONE shared counter -- `store.add(key, 1)`, an atomic fetch-and-add on the process group's key-value store --
+    so a rank that drew instances of 10 iterations takes the next chunk while a rank with 100-iteration instances is still
+    busy; iteration counts of this workload span 10-100 and a static partition ends with its slowest rank.
+
+    solve_fns: one callable (SolverHandle.solve_batch signature) or a list of them -- one claiming thread each (several
+    handles of a GPU keep several chunks in flight, like the lanes of BatchPipeline); make_args(indices) -> the argument
+    tuple (scene_id, qc, goals, n_goals, standoff, base_pos, Q0) of those instances, called by the claiming thread (it is
+    where a rank uploads the scene of a chunk it drew).  Every instance is solved exactly once by somebody; results are
+    the static partition's bit for bit (instances are independent), whatever the order.  With `gather` every rank returns
+    the whole batch in the original order (two padded all_gathers as in gather_results, preceded by an all_gather of the
+    index lists); without, its own instances (indices ascending).  `stats` receives chunks / instances claimed here."""
+    import threading
+    fns = list(solve_fns) if isinstance(solve_fns, (list, tuple)) else [solve_fns]
+    n_chunks = len(chunks)
+    counter = None
+    if world > 1 or _group_exists():
+        store = store if store is not None else _default_store()
+        _WQ_CALLS[0] += 1  # every rank makes the same calls in the same order: the same key everywhere
+        counter = f"gto_wq/{key if key is not None else _WQ_CALLS[0]}"
+    local_next = [0]
+    lock = threading.Lock()
+    got: list = []
+    errors: list = []
+
+    def claim() -> int:
+        if counter is not None:
+            return int(store.add(counter, 1)) - 1
+        with lock:
+            local_next[0] += 1
+            return local_next[0] - 1
+
+    def worker(fn):
+        try:
+            while not errors:
+                c = claim()
+                if c >= n_chunks:
+                    return
+                idx = np.asarray(chunks[c])
+                res = fn(*make_args(idx))
+                with lock:
+                    got.append((c, idx, res))
+        except BaseException as e:  # noqa: BLE001 -- re-raised below, after the other threads have stopped claiming
+            errors.append(e)
+
+    threads = [threading.Thread(target=worker, args=(fn,), name=f"gto-wq-{i}") for i, fn in enumerate(fns[1:], 1)]
+    for t in threads:
+        t.start()
+    worker(fns[0])
+    for t in threads:
+        t.join()
+    err_local = 1 if errors else 0
+    if world > 1 or (gather and _collective_applies(world, group)):
+        import torch
+        import torch.distributed as dist
+        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+        flag = torch.tensor([err_local], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)  # nobody is left waiting in the gather
+        if int(flag.item()):
+            raise RuntimeError("solve_work_queue: a rank failed") from (errors[0] if errors else None)
+    elif errors:
+        raise errors[0]
+    got.sort(key=lambda g: g[0])
+    if got:
+        mine = np.concatenate([g[1] for g in got])
+        res = tuple(np.concatenate([np.asarray(g[2][i]) for g in got]) for i in range(5))
+        order = np.argsort(mine, kind="stable")
+        mine, res = mine[order], tuple(a[order] for a in res)
+    else:
+        a0 = make_args(np.zeros(0, dtype=np.int64))
+        Q0 = np.asarray(a0[6], dtype=np.float64)
+        ndof, T = Q0.shape[-2], Q0.shape[-1]
+        mine = np.zeros(0, dtype=np.int64)
+        res = (np.empty((0, ndof, T)), np.empty((0, ndof, T - 1)), np.empty(0), np.empty(0, np.int32), np.empty(0, np.int32))
+    if stats is not None:
+        stats.update(chunks_total=n_chunks, chunks_claimed=len(got), instances_claimed=int(len(mine)))
+    if not gather or not _collective_applies(world, group):
+        return (mine,) + res
+    import torch.distributed as dist
+    lists = [None] * world
+    dist.all_gather_object(lists, mine.tolist(), group=group)
+    assignment = np.full(B, -1, dtype=np.int32)
+    for r, l_ in enumerate(lists):
+        assignment[np.asarray(l_, dtype=np.int64)] = r
+    if (assignment < 0).any():
+        raise RuntimeError("solve_work_queue: instances nobody claimed (chunks do not cover the batch)")
+    if stats is not None:
+        stats.update(instances_by_rank=[len(l_) for l_ in lists])
+    return gather_results(mine, res, B, rank, world, group, assignment, stats)
 
 
 def merge_batches(batches: Sequence[tuple]):

@@ -109,6 +109,21 @@ WORKER_GLOO = textwrap.dedent('''
     idx, Q, dQ, f, it, st = solve_sharded(h.solve_batch, sid, prob.qc, prob.goals, 1, prob.S, prob.base, prob.Q0, rank=rank,
                                           world=world, assignment=owner)
     scenes_here = int(len(np.unique(sid[owner == rank])))
+    # the same batch through the work queue: chunks = scenes, claimed through the group's store counter; the rank that
+    # draws a chunk uploads its scene (two claiming handles on this rank: two chunks in flight)
+    from grasptrajopt_amd.parallel import scene_chunks, solve_work_queue
+    h2 = _capi.SolverHandle(prob.desc, prob.cfg["link_ee"], prob.cfg["link_gripper"], opts, device=0)
+    S16 = np.broadcast_to(np.asarray(prob.S, dtype=np.float64).reshape(-1, 16), (B, 16))
+    def claimer(hh):
+        def solve(ix_sid, *a):
+            sc = scenes[int(ix_sid[0])]
+            hh.set_scene(int(ix_sid[0]), sc.c_all, sc.c_obs, sc.shape, sc.origin, sc.res)
+            return hh.solve_batch(ix_sid, *a)
+        return solve
+    make = lambda ix: (sid[ix], prob.qc[ix], prob.goals[ix], 1, S16[ix], prob.base[ix], prob.Q0[ix])
+    wst = {}
+    wq = solve_work_queue([claimer(h), claimer(h2)], scene_chunks(sid), make, B, rank, world, stats=wst)
+    wq_eq = all(bool(np.array_equal(a, b)) for a, b in zip((idx, Q, dQ, f, it, st), wq))
     if rank == 0:
         for s in range(n_sc):
             sc = scenes[s]
@@ -116,7 +131,8 @@ WORKER_GLOO = textwrap.dedent('''
         ref = h.solve_batch(sid, prob.qc, prob.goals, 1, prob.S, prob.base, prob.Q0)
         eq = all(bool(np.array_equal(a, b)) for a, b in zip((Q, dQ, f, it, st), ref))
         print("RESULT", json.dumps({"n": int(len(idx)), "equal": eq, "scenes_on_rank0": scenes_here, "iters_distinct": int(len(set(it.tolist()))),
-                                    "world": world}))
+                                    "world": world, "work_queue_equal": wq_eq, "work_queue_by_rank": wst["instances_by_rank"]}))
+    h2.close()
     dist.barrier()
     h.close()
     dist.destroy_process_group()
@@ -144,6 +160,8 @@ def test_ranks_on_one_device_hip_solver_equals_single_process(tmp_path, world):
     r = json.loads([l for l in out.splitlines() if l.startswith("RESULT")][0][7:])
     assert r["world"] == world and r["n"] == 128 and r["equal"]
     assert 0 < r["scenes_on_rank0"] < 16 and r["iters_distinct"] > 1
+    # the work queue (scene chunks claimed through the store counter, two claiming handles per rank): same bits, every instance once
+    assert r["work_queue_equal"] and sum(r["work_queue_by_rank"]) == 128 and len(r["work_queue_by_rank"]) == world
 
 
 def _bench_lines(stdout):
@@ -181,7 +199,7 @@ def test_bench_eight_ranks_dry_run_on_one_device():
     """The 8-rank code path without an 8-GPU box: bench.py as the driver launches it for N = 8, with
     gloo and all eight ranks on the one device: spawn path, shard_by_scene over eight ranks (4 scenes each), the gather of
     eight shards with every instance back in order and the rank's own shard bit-exact through the gather, the `collective`
-    object with eight rows and the lane decision (lanes per rank = min(asked, cgroup quota / ranks))."""
+    object with eight rows and the lane decision (lanes per rank = what fits the cgroup quota at the measured cores per lane)."""
     import json
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--backend", "gloo", "--same-device", "--steps", "4", "--warmup", "1",
            "--merge", "1", "--repeats", "1", "--scenes-per-gpu", "4", "--no-cpu-baseline"]
@@ -196,8 +214,8 @@ def test_bench_eight_ranks_dry_run_on_one_device():
     assert col["world_size"] == 8 and len(col["ranks"]) == 8 and sorted(r["rank"] for r in col["ranks"]) == list(range(8))
     assert 1 <= col["lanes_per_rank"] <= 4 and col["lane_decision"]
     q = col["cgroup_cpu_quota_cores"]
-    if q is not None and q < 32:
-        assert col["lanes_per_rank"] == max(1, min(4, int(q // 8)))
+    if q is not None:  # lanes that fit the quota at the measured 0.27 cores per lane + 0.5 per rank: four at quota 16 / 8 ranks
+        assert col["lanes_per_rank"] == max(1, min(4, int((q / 8 - 0.5) / 0.27 + 1e-9)))
     assert col["host_cpu_cores_busy_all_ranks"] > 0
     assert d["quality"]["gate"] == "pass"
 
