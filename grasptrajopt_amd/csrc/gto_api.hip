@@ -64,6 +64,7 @@ struct gto_handle {
   unsigned long long* d_progress = nullptr;  // its device address
   unsigned progress_tag = 0;
   int ahead = 8;           // GTO_AHEAD: rounds the host may enqueue beyond the last one it has seen running
+  int nap_us = 50, nap_few_us = 10;  // GTO_NAP_US / GTO_NAP_FEW_US: the throttle's naps (the host thread of a lane sleep-polls two pinned words)
   int ahead_few = 4;       // ... in launches with few instances in flight (short rounds: four of them cover the host's launch time, and every round enqueued beyond the last instance's end runs empty)
   // speculation (gto_kernels.h GTO_KSPEC): candidates a step generates ahead of their evaluation in launches with few
   // instances in flight (more work, fewer dependent rounds).  Every candidate is a job of the next obstacle launch, and
@@ -251,6 +252,8 @@ int gto_create(const gto_robot_desc* d, const gto_solver_opts* opts, int device,
   }
   h->opts = *opts;
   if (const char* e = getenv("GTO_AHEAD")) h->ahead = h->ahead_few = std::max(1, atoi(e));
+  if (const char* e = getenv("GTO_NAP_US")) h->nap_us = std::max(1, atoi(e));
+  if (const char* e = getenv("GTO_NAP_FEW_US")) h->nap_few_us = std::max(1, atoi(e));
   if (const char* e = getenv("GTO_SPEC_REJ")) h->spec_rej = std::max(1, std::min(GTO_KSPEC, atoi(e)));
   if (const char* e = getenv("GTO_SPEC_REJ_FEW")) h->spec_rej_few = std::max(1, std::min(GTO_KSPEC, atoi(e)));
   if (const char* e = getenv("GTO_SPEC_STREAK")) h->spec_streak = h->spec_streak_tail = std::max(0, atoi(e));
@@ -1456,7 +1459,7 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
       read_progress(ln);
       const bool few = std::min(ln.room, ln.n_resp - ln.known_done) <= h->few_instances;
       if (ln.k - ln.seen_round <= (few ? h->ahead_few : h->ahead) + 1 || failed.load(std::memory_order_relaxed)) return GTO_OK;
-      std::this_thread::sleep_for(std::chrono::microseconds(few ? 10 : 50));
+      std::this_thread::sleep_for(std::chrono::microseconds(few ? h->nap_few_us : h->nap_us));
       if ((naps & 1023) == 1023) {  // a stream that went idle or failed without reaching the round: do not wait for ever
         const hipError_t qe = hipStreamQuery(ln.st);
         if (qe != hipErrorNotReady) {

@@ -100,7 +100,9 @@ def plan_shape_statistics(plans, opt_index, lower, upper, standoff_waypoint=None
       path_ratio   joint-space path length over the distance between the first and the last configuration (>= 1)
       chord_dev    largest distance of the waypoints before the standoff waypoint from the straight line between the first free
                    waypoint and the standoff waypoint, over that line's length (0: a straight line in joint space)
-      on_bound     share of waypoints with an optimised joint within 1e-6 of a limit"""
+      on_bound     share of waypoints with an optimised joint within 1e-6 of a limit
+      chord        joint-space distance between the first and the last configuration (rad; what a workload's goals have to
+                   look like to be "reference-shaped": bench.py's quality.reference_shaped)"""
     P = np.asarray(plans, dtype=np.float64)
     o = np.asarray(opt_index)
     Q = P[:, o, :]
@@ -123,4 +125,5 @@ def plan_shape_statistics(plans, opt_index, lower, upper, standoff_waypoint=None
         "path_ratio": L / np.maximum(np.linalg.norm(Q[:, :, -1] - Q[:, :, 0], axis=1), tiny),
         "chord_dev": np.linalg.norm(Q[:, :, 1:ts + 1] - chord, axis=1).max(axis=1) / np.maximum(np.linalg.norm(b - a, axis=1), tiny),
         "on_bound": ((np.abs(Q - lo) <= 1e-6) | (np.abs(Q - hi) <= 1e-6)).any(axis=1).mean(axis=1),
+        "chord": np.linalg.norm(Q[:, :, -1] - Q[:, :, 0], axis=1),
     }

@@ -10,7 +10,7 @@ This is input generation (host, numpy); it is not part of the solve path.
 from __future__ import annotations
 
 from dataclasses import dataclass
-from typing import Callable, Optional, Tuple
+from typing import Callable, Optional, Tuple, Sequence
 
 import numpy as np
 
@@ -157,6 +157,69 @@ def make_goals(desc, fk: Callable[[np.ndarray], np.ndarray], link_ee: str, n_goa
                 RTs.append(T[i])
                 qs.append(q[i])
     return np.stack(RTs), np.stack(qs)
+
+
+# Joint-space distance between the first and the last configuration of the reference's 186 stored Panda table-top plans
+# (examples/results_iros2024/GTO_scenereplica_panda_tabletop_*.json; tests/golden/plan_statistics.npz `chord`, made by
+# tests/golden/make_plan_statistics.py): percentiles 0, 5, 10, 25, 50, 75, 90, 95, 100 in rad; Fetch: 184 plans.
+STORED_CHORD_PCT = (0.0, 5.0, 10.0, 25.0, 50.0, 75.0, 90.0, 95.0, 100.0)
+STORED_CHORD_RAD = {"panda": (1.381, 1.637, 1.717, 1.878, 2.166, 2.570, 3.359, 3.482, 4.203),
+                    "fetch": (1.812, 2.257, 2.450, 2.666, 2.925, 3.314, 3.623, 3.915, 4.505)}
+
+
+def make_goal_sets_reference_shaped(desc, fk: Callable[[np.ndarray], np.ndarray], link_ee: str, qc, n_sets: int, set_size: int, seed: int,
+                                    chord_rad: Sequence[float], xlim=(0.25, 0.75), ylim=(-0.5, 0.5), zlim=(0.08, 0.7), spread: float = 0.25,
+                                    collision_cost: Optional[Callable[[np.ndarray], np.ndarray]] = None):
+    """Goal sets shaped like what the reference's driver hands to plan_goalset (examples/pybullet_gto_planning.py:242-293):
+    `set_size` collision-free IK solutions of grasps of ONE object -- here configurations within `spread` rad (per joint,
+    normal) of a set's first configuration, end effector in the same box above the table -- whose first configuration lies
+    at a joint-space distance from qc drawn from the stored plans' distribution (`chord_rad`: values at STORED_CHORD_PCT).
+    The synthetic goals of make_goals are uniform over the joint limits: 2.9-5.0 rad away, the stored plans 1.6-3.5.
+    Returns (RT (n_sets, set_size, 4, 4), q (n_sets, set_size, ndof))."""
+    rng = np.random.default_rng(9000 + seed)
+    qc = np.asarray(qc, dtype=np.float64)
+    oi = np.asarray(desc.opt_index)
+    lo, hi = np.asarray(desc.lower)[oi], np.asarray(desc.upper)[oi]
+    fe = desc.frame_index(link_ee)
+
+    def admissible(q):
+        T = np.asarray(fk(q))[:, fe]
+        p = T[:, :3, 3]
+        ok = ((p[:, 0] > xlim[0]) & (p[:, 0] < xlim[1]) & (p[:, 1] > ylim[0]) & (p[:, 1] < ylim[1]) & (p[:, 2] > zlim[0]) & (p[:, 2] < zlim[1]))
+        if collision_cost is not None and ok.any():
+            idx = np.nonzero(ok)[0]
+            ok[idx[collision_cost(q[idx]) > 0.0]] = False
+        return ok, T
+
+    RT, Qs = np.zeros((n_sets, set_size, 4, 4)), np.tile(qc, (n_sets, set_size, 1))
+    for b in range(n_sets):
+        for _ in range(200):
+            c = float(np.interp(100.0 * rng.random(), STORED_CHORD_PCT, chord_rad))
+            u = rng.standard_normal((64, len(oi)))
+            q = np.tile(qc, (64, 1))
+            q[:, oi] = np.clip(qc[oi] + c * u / np.linalg.norm(u, axis=1, keepdims=True), lo, hi)
+            ok, T = admissible(q)
+            ok &= np.abs(np.linalg.norm(q[:, oi] - qc[oi], axis=1) - c) < 0.05  # (a clipped direction is shorter)
+            if not ok.any():
+                continue
+            i0 = int(np.nonzero(ok)[0][0])
+            members, poses = [q[i0]], [T[i0]]
+            for _ in range(50):
+                qq = np.tile(q[i0], (32, 1))
+                qq[:, oi] = np.clip(q[i0][oi] + spread * rng.standard_normal((32, len(oi))), lo, hi)
+                ok2, T2 = admissible(qq)
+                for j in np.nonzero(ok2)[0]:
+                    if len(members) < set_size:
+                        members.append(qq[j])
+                        poses.append(T2[j])
+                if len(members) == set_size:
+                    break
+            if len(members) == set_size:
+                RT[b], Qs[b] = np.stack(poses), np.stack(members)
+                break
+        else:
+            raise RuntimeError("make_goal_sets_reference_shaped: no admissible goal set found")
+    return RT, Qs
 
 
 def make_seed(qc: np.ndarray, q_goal: np.ndarray, T: int, param_index) -> np.ndarray:

@@ -564,12 +564,19 @@ static void evaluate(const orc_instance* in, const double* Qopt, int want_deriv,
     }
   }
 
-  /* optas.mmin over the goal set (gto/gto_planner.py:105): first minimum */
-  int best = 0;
-  for (int g = 1; g < in->n_goals; ++g)
-    if (goal_cost[g] < goal_cost[best]) best = g;
+  /* optas.mmin over the goal set (gto/gto_planner.py:105): first minimum.  A goal whose cost is not a finite number
+   * (NaN / Inf in its pose) never wins against one that is; a set without a finite cost yields goal 0 and f_goal = +Inf,
+   * which ends the solve with GTO_STATUS_NUMERICAL at the first evaluation (solve_instance). */
+  int best = -1;
+  double best_c = INFINITY;
+  for (int g = 0; g < in->n_goals; ++g)
+    if (goal_cost[g] < best_c) {
+      best = g;
+      best_c = goal_cost[g];
+    }
+  if (best < 0) best = 0;
   ev->goal_argmin = best;
-  ev->f_goal = goal_cost[best];
+  ev->f_goal = best_c;
   ev->f_obs = o->w_obstacle * fobs;
 
   /* velocity term (gto/gto_planner.py:133-135) with the velocities eliminated through the linear
@@ -788,6 +795,13 @@ static void solve_instance(const orc_instance* in, const double* qc, double* Q_o
       memcpy(w.Q, w.Qtry, sizeof(double) * n * T);
       f = f_try;
       eval_swap(&w.cur, &w.tri);
+      /* a seed whose objective is not a finite number (NaN / Inf in a goal pose, in the seed, in a voxel the seed touches):
+       * nothing to descend from -- the iterate is returned as it is (optas/solver.py:135), status NUMERICAL, 0 iterations.
+       * (A TRIAL point with such an objective is a rejected step: f_try < f is false.) */
+      if (!isfinite(f)) {
+        status = GTO_STATUS_NUMERICAL;
+        done = 1;
+      }
     } else if (f_try < f && pred > 0.0) {
       double df = f - f_try, rho = df / pred;
       memcpy(w.Q, w.Qtry, sizeof(double) * n * T);
