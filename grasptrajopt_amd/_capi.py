@@ -106,6 +106,7 @@ def pack_robot_desc(desc: RobotDesc, link_ee: str, link_gripper: str,
 # include/gto_solver.h
 GTO_GRAD_CENTRAL_DIFF, GTO_GRAD_ZERO = 0, 1
 GTO_STATUS_CONVERGED, GTO_STATUS_MAX_ITER, GTO_STATUS_NUMERICAL = 0, 1, 2
+ABI_VERSION = 1006  # include/gto_solver.h GTO_ABI_VERSION (checked against gto_version() when the library is loaded)
 
 _lib = None
 
@@ -167,10 +168,17 @@ def load_library(path: Optional[str] = None):
             "(hipcc --offload-arch=gfx950). There is no CPU fallback for the GTO solve path.")
     _preload_hip_runtime()
     lib = C.CDLL(p)
+    lib.gto_version.restype = C.c_int32
+    # one ABI number for wrapper and library: a library named by GTO_HIP_LIB for an A/B run has to be a build of THIS
+    # interface -- an older one that lacks a symbol, or has it with other arguments (gto_scene_from_depth once got a pointer
+    # in the middle of its signature), is refused here instead of being called with shifted arguments
+    v = int(lib.gto_version())
+    if v != ABI_VERSION:
+        raise RuntimeError(f"{p}: ABI version {v}, this wrapper speaks {ABI_VERSION} (include/gto_solver.h GTO_ABI_VERSION): "
+                           "rebuild the library from this tree (__graft_entry__.build())")
     H = C.c_void_p
     lib.gto_default_opts.argtypes = [C.POINTER(CSolverOpts)]
     lib.gto_default_opts.restype = None
-    lib.gto_version.restype = C.c_int32
     lib.gto_create.argtypes = [C.POINTER(CRobotDesc), C.POINTER(CSolverOpts), C.c_int, C.POINTER(H)]
     lib.gto_destroy.argtypes = [H]
     lib.gto_destroy.restype = None
@@ -186,23 +194,20 @@ def load_library(path: Optional[str] = None):
     lib.gto_last_kernel_time.argtypes = [H, _pd, _pi]
     lib.gto_set_profiling.argtypes = [H, C.c_int32]
     lib.gto_last_kernel_work.argtypes = [H, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
-    if hasattr(lib, "gto_last_kernel_profile"):  # (an older build named by GTO_HIP_LIB for an A/B run lacks it)
-        lib.gto_last_kernel_profile.argtypes = [H, C.c_int32, _pd, _pi, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
-        lib.gto_last_kernel_profile.restype = C.c_int
+    lib.gto_last_kernel_profile.argtypes = [H, C.c_int32, _pd, _pi, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    lib.gto_last_kernel_profile.restype = C.c_int
     lib.gto_set_stream.argtypes = [H, C.c_void_p]
     lib.gto_set_mode.argtypes = [H, C.c_int32]
     lib.gto_set_lanes.argtypes = [H, C.c_int32, C.c_int32, C.c_int32]
     lib.gto_set_lane_streams.argtypes = [H, C.c_int32, C.POINTER(C.c_void_p)]
     lib.gto_share_scene.argtypes = [H, C.c_int32, H, C.c_int32]
-    if hasattr(lib, "gto_share_scene_halves"):  # (an older build named by GTO_HIP_LIB for an A/B run lacks it)
-        lib.gto_share_scene_halves.argtypes = [H, C.c_int32, H, C.c_int32, C.c_int32, C.c_int32]
-        lib.gto_share_scene_halves.restype = C.c_int
-    if hasattr(lib, "gto_scene_from_depth"):  # (an older build named by GTO_HIP_LIB for an A/B run lacks them)
-        lib.gto_scene_from_depth.argtypes = [H, C.c_int32, _pf, C.c_int32, C.c_int32, _pd, _pd, _pd, _pd, C.POINTER(C.c_uint8), _pf, C.c_double,
-                                             C.c_double, C.c_double, C.c_float, C.c_float, _pi, _pd, _pd]
-        lib.gto_scene_from_depth.restype = C.c_int
-        lib.gto_get_scene_fields.argtypes = [H, C.c_int32, _pf, _pf]
-        lib.gto_get_scene_fields.restype = C.c_int
+    lib.gto_share_scene_halves.argtypes = [H, C.c_int32, H, C.c_int32, C.c_int32, C.c_int32]
+    lib.gto_share_scene_halves.restype = C.c_int
+    lib.gto_scene_from_depth.argtypes = [H, C.c_int32, _pf, C.c_int32, C.c_int32, _pd, _pd, _pd, _pd, C.POINTER(C.c_uint8), _pf, C.c_double,
+                                         C.c_double, C.c_double, C.c_float, C.c_float, _pi, _pd, _pd]
+    lib.gto_scene_from_depth.restype = C.c_int
+    lib.gto_get_scene_fields.argtypes = [H, C.c_int32, _pf, _pf]
+    lib.gto_get_scene_fields.restype = C.c_int
     lib.gto_eval_fk.argtypes = [H, C.c_int32, _pd, _pd]
     lib.gto_eval_points.argtypes = [H, C.c_int32, C.c_int32, _pd, _pd, C.c_int32, _pd, _pi, _pd, _pd]
     lib.gto_eval_objective.argtypes = [H, C.c_int32, C.c_int32, _pi, _pd, _pi, _pd, _pd, _pd, _pd, _pd, _pd, _pi]
@@ -421,8 +426,10 @@ class SolverHandle:
         """MODE_ROUNDS (default): evaluate / step launches over slots; MODE_SINGLE_LAUNCH: one launch per call."""
         self._check(self.lib.gto_set_mode(self._h, int(mode)), "gto_set_mode")
 
-    def set_lanes(self, max_lanes: int = 4, min_per_lane: int = 256, adopt_below: int = 48):
-        """Lanes of a solve call (include/gto_solver.h, gto_set_lanes): streams the call's instances are dealt to."""
+    def set_lanes(self, max_lanes: int = 1, min_per_lane: int = 256, adopt_below: int = 0):
+        """Lanes of a solve call (include/gto_solver.h, gto_set_lanes): streams the call's instances are dealt to, one host
+        thread of the call each.  The defaults are the library's (one lane: no thread but the caller's): several lanes are
+        asked for explicitly, e.g. set_lanes(4, 256, 0)."""
         self._check(self.lib.gto_set_lanes(self._h, int(max_lanes), int(min_per_lane), int(adopt_below)), "gto_set_lanes")
 
     def set_lane_streams(self, streams=()):
@@ -450,8 +457,6 @@ class SolverHandle:
     def last_kernel_profile(self):
         """Per kernel variant of the last profiled solve: {name: (ms, launches, workgroups, points gathered)}."""
         out = {}
-        if not hasattr(self.lib, "gto_last_kernel_profile"):
-            return out
         names = self.PROF_VARIANTS
         if self.desc.n_opt > 8:  # the kernels of the robots with nine to sixteen optimised joints (one step kernel, no few-instance variants)
             names = ("k_obstacle_gram<16,1>", "k_obstacle_gram<16,8>", "k_lm_step_wide<16>", "k_lm_step<8,4>")

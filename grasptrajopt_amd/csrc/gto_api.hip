@@ -20,7 +20,7 @@
 
 #include "gto_kernels.h"
 
-#define GTO_VERSION 1000
+#define GTO_VERSION GTO_ABI_VERSION  // include/gto_solver.h
 #ifndef GTO_OBS_DEEP_PD
 #define GTO_OBS_DEEP_PD 8
 #endif

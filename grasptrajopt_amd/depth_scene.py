@@ -42,6 +42,10 @@ class _LazyArray(NDArrayOperatorsMixin):
     def __array_ufunc__(self, ufunc, method, *inputs, **kwargs):
         inputs = tuple(x.__array__() if isinstance(x, _LazyArray) else x for x in inputs)
         if "out" in kwargs:
+            for x in kwargs["out"]:
+                if isinstance(x, _LazyArray):  # written in place (np.clip(f, 0, 1, out=f), f *= 2): the caller's array from then on,
+                    x.__array__()              # like an assignment through __setitem__ -- it no longer names a resident scene
+                    x._edited = True
             kwargs["out"] = tuple(x.__array__() if isinstance(x, _LazyArray) else x for x in kwargs["out"])
         return getattr(ufunc, method)(*inputs, **kwargs)
 
@@ -100,7 +104,16 @@ class LazyCostField(_LazyArray):
         cannot be kept resident (another camera than the grid's cloud, an edited array): the caller then takes the array."""
         if self._edited or self.grid_dpc is None:
             return None
-        return self.robot._depth_scene_for(self.dpc, self.epsilon, self.w_inside, self.grid_dpc)
+        # the latency path (plan / plan_goalset / solve_ik ask for both fields on every call): the answer of the last call
+        # stands while the scene's build number and a cheap stamp of both clouds' inputs are what they were -- the by-value
+        # comparison of two full images per field (and the snapshot copies) only runs when the stamp moved
+        stamp = (cloud_stamp(self.dpc), cloud_stamp(self.grid_dpc), id(self.robot.__dict__.get("_pending_depth")))
+        c = self.__dict__.get("_res_cache")
+        if c is not None and c[1] == stamp and c[0].gen == c[0].handle.scene_generation(c[0].sid):
+            return c[0]
+        r = self.robot._depth_scene_for(self.dpc, self.epsilon, self.w_inside, self.grid_dpc)
+        self._res_cache = None if r is None else (r, stamp)
+        return r
 
     def ensure_scene(self):
         """(handle, scene id) of the resident scene that holds this field (see `resident` for which half)."""
@@ -121,6 +134,18 @@ class LazyCostField(_LazyArray):
 def resident_of(field):
     """`Resident` of a cost field argument, or None for anything that is not a resident lazy field."""
     return field.resident() if isinstance(field, LazyCostField) else None
+
+
+def cloud_stamp(dpc):
+    """Identity and a sampled checksum of a DepthPointCloud's inputs (a few hundred pixels): moves when the cloud is another
+    object, when its arrays were replaced, and for in-place edits that touch a sampled pixel or change the image's corners.
+    An in-place edit the sample misses is NOT seen by the fast path of LazyCostField.resident(): build a new DepthPointCloud
+    for a new image, as the reference's driver does (examples/pybullet_gto_planning.py:176-190)."""
+    d, m = dpc.depth, dpc.target_mask
+    flat = d.reshape(-1)
+    chk = float(np.asarray(flat[::1009], dtype=np.float64).sum()) + float(flat[0]) + float(flat[-1])
+    mchk = None if m is None else int(np.asarray(m).reshape(-1)[::1009].astype(np.int64).sum())
+    return (id(dpc), id(d), d.shape, chk, None if m is None else id(m), mchk, float(dpc.threshold))
 
 
 def same_image(a, b) -> bool:

@@ -113,7 +113,10 @@ typedef struct gto_handle gto_handle;
 /* Fill opts with the reference's constants and this solver's defaults. */
 void gto_default_opts(gto_solver_opts* opts);
 
-/* Library/ABI version (major*1000 + minor). */
+/* Library/ABI version (major*1000 + minor): GTO_ABI_VERSION of the header the library was built from.  A binding checks it
+ * when it loads the library and refuses another number (grasptrajopt_amd/_capi.py load_library): every change of a
+ * signature or of a struct in this header bumps the minor. */
+#define GTO_ABI_VERSION 1006
 int32_t gto_version(void);
 
 /*
@@ -248,13 +251,18 @@ int gto_set_mode(gto_handle* h, int32_t mode);
 
 /*
  * Lanes of a solve call.  gto_solve_batch / gto_solve_batch_device deal the instances of a call to up to `max_lanes`
- * lanes (contiguous ranges of at least `min_per_lane` instances; default 4 and 256), each with a HIP stream and lists
- * of its own over the one workspace of the call, fed round-robin by the calling thread: one lane's evaluation launch
- * overlaps another's step launch while the GPU is full.  A lane with at most `adopt_below` instances left (default 48;
- * 0: never) hands them to lane 0, which runs the stragglers of the whole call as one chain of launches.  Lane 0 runs on
- * the handle's stream (the `stream` argument of gto_solve_batch_device); the call's results are ordered behind all
- * lanes on that stream.  Results do not depend on any of the three numbers (tests/test_gpu_parity.py).  The reference
- * has no counterpart: gto/gto_planner.py:185-245 solves one instance per call.
+ * lanes (contiguous ranges of at least `min_per_lane` instances), each with a HIP stream and lists of its own over the
+ * one workspace of the call and a host thread of the call feeding it (lane 0: the calling thread): one lane's evaluation
+ * launch overlaps another's step launch while the GPU is full.  A lane with at most `adopt_below` instances left
+ * (0: never) hands them to lane 0, which runs the stragglers of the whole call as one chain of launches.
+ * DEFAULTS of a new handle: max_lanes 1, min_per_lane 256, adopt_below 0 (environment: GTO_LANES, GTO_LANE_MIN,
+ * GTO_ADOPT) -- one lane, no thread but the caller's, everything on the handle's stream.
+ * With ONE lane the call runs on the handle's stream (the `stream` argument of gto_solve_batch_device).  With SEVERAL,
+ * every lane -- lane 0 too -- runs on a stream of its own (the handle's, created with the greatest priority, or the
+ * caller's: gto_set_lane_streams); the caller's stream only BRACKETS the call: it carries the seeds and the static-link
+ * pass in front, the lanes wait for that, and the results are ordered behind all lanes on it.  Results do not depend on
+ * any of the three numbers (tests/test_gpu_parity.py).  The reference has no counterpart: gto/gto_planner.py:185-245
+ * solves one instance per call.
  */
 int gto_set_lanes(gto_handle* h, int32_t max_lanes, int32_t min_per_lane, int32_t adopt_below);
 /*

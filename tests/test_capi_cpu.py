@@ -33,7 +33,21 @@ def test_default_opts_match_reference_constants(capi, oracle_mod):
     for name, _ in capi.CSolverOpts._fields_:
         assert getattr(o, name) == getattr(r, name), name
     assert (o.T, o.Tmax, o.standoff_offset, o.w_obstacle, o.w_vel, o.max_iter) == (50, 10.0, -10, 10.0, 0.01, 100)
-    assert capi.load_library().gto_version() >= 1000
+    hdr = open(os.path.join(ROOT, "include", "gto_solver.h")).read()
+    abi = int(re.search(r"#define GTO_ABI_VERSION (\d+)", hdr).group(1))
+    assert capi.load_library().gto_version() == abi == capi.ABI_VERSION
+
+
+def test_library_of_another_abi_is_refused(capi, tmp_path):
+    """A library named by GTO_HIP_LIB for an A/B run has to speak this wrapper's ABI: one whose gto_version() says otherwise is
+    refused when it is loaded, not called with the signatures of another header."""
+    import subprocess
+    src = tmp_path / "old.c"
+    src.write_text("int gto_version(void) { return 1000; }\n")
+    so = tmp_path / "libgto_old.so"
+    subprocess.check_call(["gcc", "-shared", "-fPIC", str(src), "-o", str(so)])
+    with pytest.raises(RuntimeError, match="ABI version 1000"):
+        capi.load_library(str(so))
 
 
 def test_create_validates_and_has_no_cpu_fallback(capi):
