@@ -95,8 +95,8 @@ def gather_results(mine: np.ndarray, result: tuple, B: int, rank: int, world: in
     width = ndof * T + ndof * (T - 1) + 1
     payload, ipay = np.zeros((mx, width)), np.zeros((mx, 2), dtype=np.int32)
     n = len(mine)
-    payload[:n, : ndof * T] = Q.reshape(n, -1)
-    payload[:n, ndof * T: ndof * T + ndof * (T - 1)] = dQ.reshape(n, -1)
+    payload[:n, : ndof * T] = np.asarray(Q).reshape(n, ndof * T)  # (explicit widths: a rank may hold no instance at all)
+    payload[:n, ndof * T: ndof * T + ndof * (T - 1)] = np.asarray(dQ).reshape(n, ndof * (T - 1))
     payload[:n, -1] = cost
     ipay[:n, 0], ipay[:n, 1] = iters, status
     t0 = time.perf_counter()

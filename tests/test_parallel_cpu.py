@@ -244,6 +244,14 @@ def _wq_worker(rank, world, port, tmp):
         for a, b in zip(ref, got):
             np.testing.assert_array_equal(a, b)
         assert sum(st["instances_by_rank"]) == B and st["chunks_total"] == len(chunks)
+    # a rank that comes late finds the queue empty: it claims nothing and still takes part in the gather
+    if rank == 2:
+        time.sleep(1.5)
+    st = {}
+    got = solve_work_queue(fake, chunks, make, B, rank, world, stats=st)
+    for a, b in zip(ref, got):
+        np.testing.assert_array_equal(a, b)
+    assert st["instances_by_rank"][2] == 0 and sum(st["instances_by_rank"]) == B
     own = solve_work_queue(fake, chunks, make, B, rank, world, gather=False)
     assert np.all(np.diff(own[0]) > 0)
     np.testing.assert_array_equal(own[1], ref[1][own[0]])
