@@ -45,6 +45,13 @@ struct Blk {
 // launch; the next step kernel walks them in order and stops at the first one the sequential rule accepts.  Same
 // iterates, same iteration counts as one candidate per round (oracle/gto_oracle.c solve_instance), fewer dependent rounds.
 #define GTO_KSPEC 4
+// Issue priority of the step kernels' wavefronts (s_setprio, 0..3): a step workgroup is one dependent chain per instance
+// and sits on its lane's critical path, while the obstacle launches of the OTHER lanes fill the same SIMDs with five
+// waves of throughput work each; measured with four lanes in flight (rocprofv3 kernel trace, profiles/r06_*): the
+// step launch takes 3-4x its duration alone (configs[4]: 450 us against 123; configs[2]: 120 against 38).
+#ifndef GTO_STEP_PRIO
+#define GTO_STEP_PRIO 0
+#endif
 // job-list entry: instance id in the low 24 bits, the block set the evaluation writes to above it, the candidate above
 // that (-1: void).  The set rides in the entry so that the obstacle kernel needs nothing of the instance's state.
 #define GTO_JOB_SHIFT 28
@@ -67,6 +74,11 @@ struct InstState {
   int32_t cflags;                    // bit j: the solve of candidate j >= 1 failed numerically; bit 8 + j: its step is below tol_step;
                                      // bits 16..23: rounds in a row in which the FIRST candidate was accepted (saturating)
   unsigned long long nz0, nz1;       // non-zero blocks of the current iterate's set: bit s = waypoint s + 2 (nz0), s + 66 (nz1)
+  // emptiness certificates (launches with few instances in flight; BatchPtrs::room): room_ok: the block set of the current
+  // iterate has a room for every (waypoint, link); cand_rooms: so will the sets of the candidates generated last, once they
+  // have been evaluated (the step that generated them certified or listed every group, and the launch that evaluates the
+  // listed ones leaves their rooms)
+  int32_t room_ok, cand_rooms;
 };
 
 struct SolveParams {
@@ -91,6 +103,10 @@ struct SolveParams {
   // waypoints per group and groups per job of that layout; pb_pw: waypoints per pass of the tail (what its LDS holds);
   // pb_mC: division magic of the chunk count; pb_verify (debug builds): every group is listed, the settled ones marked
   int32_t pb_next, pb_tg, pb_ng, pb_pw, pb_verify;
+  // Emptiness certificates ahead of the obstacle launch (launches with FEW instances in flight, k_lm_step<8, 4>): the step
+  // kernel settles the waypoint groups of its candidates whose links all keep room (cert_tail) and lists the others, over
+  // groups of their own (one waypoint each: the heavy waypoints near the goal then sit in workgroups of their own)
+  int32_t cert_next, cert_tg, cert_ng;  // (cert_tg consecutive waypoints per group of the certificates' item list, cert_ng groups per job)
   int32_t pb_C, pb_tab0, pb_npar;  // chunks of moving links; first double of the tail's tables in LDS (PbLayout); actuated joints that are not optimised
   uint32_t pb_mC, pb_mF;  // division magics of the chunk count and of the frame count
   double pb_eps;          // metres by which the culling radius is widened (transforms stored in single precision)
@@ -140,6 +156,12 @@ struct BatchPtrs {
   // items[p][i], i < nitems[p] (= nlive[8 + p]): the (job, group) pairs the obstacle kernel of the round of parity p has
   // to look at (the others were settled by the step kernel's broad phase): .x = the job's list entry, .y = job index << 8 | group.
   int2* items;         // [2][cap * kcap * groups]
+  // Emptiness certificates: room[set][b][t][l] = metres every point of link l at waypoint t of the trajectory whose
+  // evaluation block set `set` holds may still move before a bounding sphere of the link could reach a non-zero voxel
+  // record (< 0: none / a sphere survives; 1e30: a link that is never tested).  Written by the obstacle launch that looks
+  // at the (waypoint, link) -- (d - R - 1) voxels of the tightest culled sphere, in metres -- and by the step kernel for
+  // the groups it certifies (what is left after the candidate's step).  Null: no certificates in this call.
+  float* room;         // [kcap + 1][B][T][L]
   const SceneDev* scenes;
   int32_t cap, n_total;
   // lanes of one call (gto_api.hip): this lane's lists serve the instances b0 .. n_total - 1 of the batch, the first w0 of
@@ -758,7 +780,9 @@ __device__ __forceinline__ void trial_goal_terms_wave(const RobotDev* rb, const 
 // HOT: the launches of the solve loop under the shipped gradient mode (fixed_mode == 0, voxel records with central
 // differences): the value-only gather, the init pass's virtual waypoints and the static-link bookkeeping are compiled out of
 // the variant that runs nine launches in ten, with the scalars and branches they kept alive in its loop.
-template <int NP, int PD = GTO_OBS_MAIN_PD, bool SWEEP = false, bool HOT = false>
+// ROOM: the launch leaves BatchPtrs::room behind for every (waypoint, link) it looks at (emptiness certificates: the
+// itemized launches of the rounds with few instances in flight, behind k_lm_step<8, 4>'s cert_tail)
+template <int NP, int PD = GTO_OBS_MAIN_PD, bool SWEEP = false, bool HOT = false, bool ROOM = false>
 __global__ __launch_bounds__(256, PD == GTO_OBS_MAIN_PD ? GTO_OBS_MIN_WAVES : 2) void k_obstacle_gram(const int32_t* __restrict__ jobs_par, const int32_t* __restrict__ njobs_par,
                                                        const int2* __restrict__ items_par, const int32_t* __restrict__ nitems_par, int nG_pre, uint32_t m_nG_pre,
                                                        int n_regular, int B,
@@ -780,6 +804,13 @@ __global__ __launch_bounds__(256, PD == GTO_OBS_MAIN_PD ? GTO_OBS_MIN_WAVES : 2)
   // (RobotDev::entry_links) -- staged here, beside the kinematics' tables, so that the projection walks the set bits of
   // (touched & mask) in LDS instead of asking the robot table in memory link by link
   __shared__ unsigned s_emask[NP * NP + NP];
+  // (ROOM) per (waypoint of the group, link): index steps the tightest culled sphere of the link is clear of the nearest
+  // non-zero record, beyond its culling radius (-1: a sphere survives; 127: no sphere of the link was tested)
+  int* s_room = nullptr;
+  if constexpr (ROOM) {
+    __shared__ int s_room_store[GTO_MAX_TG * GTO_MAX_LINKS];
+    s_room = s_room_store;
+  }
 
   const int bid = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int L = geo.L, n = geo.n, T = sp.T, F = geo.F, TG = geo.TG, cap_active = geo.cap_active;
@@ -948,6 +979,9 @@ __global__ __launch_bounds__(256, PD == GTO_OBS_MAIN_PD ? GTO_OBS_MIN_WAVES : 2)
     s_sc[2 * idx + 1] = c;
   }
   if (tid < GTO_MAX_TG) s_touched[tid] = 0u;
+  if constexpr (ROOM) {
+    for (int i = tid; i < GTO_MAX_TG * GTO_MAX_LINKS; i += 256) s_room[i] = 127;
+  }
   for (int e = tid; e < NP * NP + NP; e += 256) s_emask[e] = rb->entry_links[NP == 8 ? 0 : 1][e];  // (read in the epilogue, many barriers from here)
   __syncthreads();
   if (dbg_wg && tid == 0) bp.dbg[16] = clock64();
@@ -1008,9 +1042,15 @@ __global__ __launch_bounds__(256, PD == GTO_OBS_MAIN_PD ? GTO_OBS_MIN_WAVES : 2)
         const uint8_t* __restrict__ dist = use_all(kq) ? sc.d_all : sc.d_obs;
         const int dd = (int)as_global(dist)[c2 + nz * (c1 + sc.ny * c0)];
         keep = dd <= R;
+        if constexpr (ROOM) {
+          if (!keep) atomicMin(&s_room[kq * L + cc.link], dd - R - 1);
+        }
 #ifdef GTO_DEBUG_LONGEST_WG
         if (!keep) atomicMin(&s_dbg_room, dd - R - 1);
 #endif
+      }
+      if constexpr (ROOM) {
+        if (keep) atomicMin(&s_room[kq * L + cc.link], -1);
       }
 #ifdef GTO_DEBUG_LONGEST_WG
       if (keep) atomicMin(&s_dbg_room, -1);
@@ -1030,6 +1070,16 @@ __global__ __launch_bounds__(256, PD == GTO_OBS_MAIN_PD ? GTO_OBS_MIN_WAVES : 2)
     __syncthreads();
   }
   const int NA = na_run;
+  if constexpr (ROOM) {
+    // what this look found, in metres (cert_tail subtracts what a candidate's step can move a point of the link by): a
+    // sphere whose centre's voxel is d > R index steps from the nearest non-zero record stays culled while its points move
+    // by at most (d - R - 1) voxels -- they then lie within R + (d - R - 1) < d index steps of that voxel.  The last barrier
+    // of the loop above is behind every atomicMin.
+    if (bp.room && !fixed_mode && tid < ng * L) {
+      const int kq = fast_div(tid, L, geo.m_L), l = tid - kq * L, v = s_room[tid];
+      bp.room[(((size_t)set_out * B + b) * T + wp(kq)) * L + l] = v == 127 ? 1e30f : (v < 1 ? -1.f : (float)((double)v * sc.res * 0.999999));
+    }
+  }
 #ifdef GTO_DEBUG_LONGEST_WG
   // verification of the step kernel's broad phase (GTO_DEBUG_CUT=10): a group it marked as settled is looked at anyway and
   // must come out without a contribution (counted at the end of the workgroup).  Without a surviving chunk, too, as long
@@ -2001,6 +2051,94 @@ __device__ __forceinline__ void prebroad_tail(const RobotDev* __restrict__ rb, c
   if (dbg_t) bp.dbg[39] = clock64();
 }
 
+// Emptiness certificates ahead of the obstacle launch, for the launches with FEW instances in flight (k_lm_step<8, 4>;
+// DESIGN.md section 5).  There the obstacle launch is laid out over every waypoint group of every job -- 1000-2000
+// workgroups for 60-190 instances, two dispatch waves of them, four fifths of which run entry -> kinematics -> broad phase
+// to find nothing -- and running the exact sphere tests in the step kernel (prebroad_tail) costs the step what it saves the
+// evaluation (measured in round 5).  What the stragglers of a call do in those rounds is creep: steps of a millimetre.
+// So the LOOK leaves behind how much room it found (k_obstacle_gram<.., ROOM>: per (waypoint, link), the metres every point
+// of the link may move before a bounding sphere of it could reach a non-zero voxel record), and this tail only subtracts
+// what a candidate's step can move a point of the link by, sum_j reach_link[l][j] |dq_j| (RobotDev::reach_link: the
+// farthest a point of link l gets from the axis of joint j, over all configurations; 1 for a prismatic joint).  A group
+// all of whose (waypoint, link) pairs keep room is SETTLED: its records (the static links' constant, flag 0) and what is
+// left of the room go to the candidate's block set and it gets no workgroup; the others go on the item list the next
+// obstacle launch is laid out over, and that launch renews their rooms.  Exact: a culled sphere contributes exact zeros,
+// and the bound is the triangle inequality (points within rho of the sphere's centre at the look, moved by at most delta:
+// within rho + delta of it now, i.e. within R + ceil(delta / res) index steps of its voxel, which is d > R + room away).
+// Rooms are relative to the CURRENT iterate's set (`slot`); `room_ok` says whether that set has them all.
+//   s_xs   [KC][m][8] projected steps of the candidates (LDS)      s_work  dead LDS (the systems' region): flags, reach, rooms
+template <int NT, int KC>
+__device__ __forceinline__ void cert_tail(const RobotDev* __restrict__ rb, const BatchPtrs& bp, const SolveParams& sp, int B, int b, int slot, int NS,
+                                          int Kg, bool room_ok, int job0, const double* __restrict__ s_xs, double* __restrict__ s_work, int tid) {
+  const int lane = tid & 63;
+  const int T = sp.T, m = T - 2, L = rb->n_links, n = rb->n_opt, TG = sp.cert_tg, nG = sp.cert_ng, par = sp.parity;
+  int* __restrict__ s_fail = reinterpret_cast<int*>(s_work);          // [KC][64] per candidate and group: has to be looked at
+  double* __restrict__ s_rch = s_work + KC * 32;                      // [L][8]
+  float* __restrict__ s_av = reinterpret_cast<float*>(s_rch + GTO_MAX_LINKS * 8);  // [Kg][m][L] what is left of the room
+  for (int i = tid; i < KC * 64; i += NT) s_fail[i] = room_ok ? 0 : 1;
+  for (int i = tid; i < L * 8; i += NT) {
+    const int l = i >> 3, j = i & 7;
+    s_rch[i] = (j < n && ((rb->link_anc[l] >> j) & 1u)) ? rb->reach_link[l][j] : 0.0;
+  }
+  __syncthreads();
+  if (room_ok) {
+    const float* __restrict__ room_c = bp.room + (((size_t)slot * B + b) * T + 2) * L;
+    for (int idx = tid; idx < m * L; idx += NT) {
+      const int sI = idx / L, l = idx - sI * L;
+      const double rm = (double)room_c[idx];
+#pragma unroll
+      for (int j = 0; j < KC; ++j)
+        if (j < Kg) {
+          const double* __restrict__ xj = s_xs + ((size_t)j * m + sI) * 8;
+          double d = 0.0;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) d = fma(fabs(xj[i]), s_rch[l * 8 + i], d);
+          // (rounding of the sum and of the float the result is stored as: a part in a million and a nanometre, off the room)
+          const double a = rm > 0.0 ? (rm - d * 1.000001 - 1e-9) * 0.999999 : -1.0;
+          const bool ok = a > 0.0;
+          s_av[((size_t)j * m + sI) * L + l] = ok ? (float)a : -1.f;
+          if (!ok) s_fail[j * 64 + sI / TG] = 1;
+        }
+    }
+  }
+  __syncthreads();
+  const double ss_a = bp.ss_fixed[4 * b + 2], ss_o = bp.ss_fixed[4 * b + 3];
+#pragma unroll
+  for (int j = 0; j < KC; ++j)
+    if (j < Kg) {  // uniform over the workgroup
+      const int set_j = (slot + 1 + j) % NS;
+      if (room_ok) {
+        double* __restrict__ wr = bp.wrec + (((size_t)set_j * B + b) * T + 2) * 8;
+        for (int i = tid; i < m * 8; i += NT) {  // eight lanes per waypoint: whole records
+          const int sI = i >> 3;
+          if (!s_fail[j * 64 + sI / TG]) wr[i] = (i & 7) == 0 ? 0.0 + (sI + 2 < sp.ts ? ss_a : ss_o) : 0.0;
+        }
+        float* __restrict__ room_n = bp.room + (((size_t)set_j * B + b) * T + 2) * L;
+        for (int idx = tid; idx < m * L; idx += NT)
+          if (!s_fail[j * 64 + (idx / L) / TG]) room_n[idx] = s_av[(size_t)j * m * L + idx];
+      }
+      if (tid < 64) {  // the groups that have to be looked at: one list entry each (debug builds, pb_verify: all, the settled ones marked)
+        const bool hit = tid < nG && s_fail[j * 64 + tid] != 0;
+        const bool on = tid < nG && (hit || sp.pb_verify);
+        const unsigned long long mask = __ballot(on), hitm = __ballot(hit);
+        (void)hitm;
+        int base = 0;
+        if (lane == 0 && mask) base = atomicAdd(bp.nlive + 8 + (1 - par), __popcll(mask));
+        base = __shfl(base, 0, 64);
+        if (on) bp.items[(size_t)(1 - par) * ((size_t)bp.cap * sp.kcap * (T - 2) + GTO_ITEM_SLACK) + base + __popcll(mask & ((1ull << lane) - 1ull))] =
+                    make_int2(GTO_JOB_ENTRY(b, set_j, j), ((job0 + j) << 8) | tid | (hit ? 0 : 0x80));
+#ifndef GTO_DEBUG_LONGEST_WG
+        if (bp.dbg && lane == 0) {  // (GTO_DEBUG_TIMING: groups listed / groups in all, by round of the call)
+          atomicAdd(reinterpret_cast<unsigned long long*>(bp.dbg + 128 + min(sp.round, 63)), (unsigned long long)__popcll(hitm));
+          atomicAdd(reinterpret_cast<unsigned long long*>(bp.dbg + 192 + min(sp.round, 63)), (unsigned long long)nG);
+        }
+#endif
+      }
+    }
+}
+// doubles of dead LDS cert_tail needs for KL candidates of m free waypoints (the step kernel's systems' region holds KL m 64)
+__host__ __device__ inline size_t cert_tail_doubles(int KC, int KL, int m, int L) { return (size_t)KC * 32 + GTO_MAX_LINKS * 8 + ((size_t)KL * m * L + 1) / 2; }
+
 // raw != 0: take Q0's optimised rows as they are (evaluation entry points); otherwise build the seed.
 template <int NP>
 __global__ __launch_bounds__(256) void k_lm_init(const RobotDev* __restrict__ rb, BatchPtrs bp, SolveParams sp, int B, int raw) {
@@ -2025,6 +2163,7 @@ __global__ __launch_bounds__(256) void k_lm_init(const RobotDev* __restrict__ rb
     st->status = GTO_STATUS_MAX_ITER;
     st->evals = 0;
     st->argmin_cur = 0;
+    st->room_ok = st->cand_rooms = 0;
   }
   if (bp.live && tid == 0) {  // the lane's first w0 instances are in flight from round 0 on; the rest wait for one of them to finish
     if (bl < bp.w0) bp.live[bl] = b, bp.jobs[bl] = GTO_JOB_ENTRY(b, 1, 0);  // candidate 0 into set slot + 1
@@ -2159,6 +2298,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 4 : 1) void k_lm_step(const Robo
   static_assert(KC <= GTO_KSPEC, "candidate copies of the workspace");
   constexpr int NT = 64 * NW;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if constexpr (GTO_STEP_PRIO != 0) __builtin_amdgcn_s_setprio(GTO_STEP_PRIO);
   if (blockIdx.x == 0 && threadIdx.x == 0 && bp.progress) {  // lagged by design: what had finished when this launch started
     const int nd = __hip_atomic_load(bp.n_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(bp.progress, bp.progress_tag | (unsigned long long)(unsigned)nd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -2185,6 +2325,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 4 : 1) void k_lm_step(const Robo
   InstState* st = bp.state + b;
   // the whole state in one round trip (the walk over the candidates below is then arithmetic only)
   const int st_done = st->done, first = st->first, slot0 = st->slot, st_ncand = st->ncand, cflags = st->cflags;
+  const int st_room_ok = KC > 1 ? st->room_ok : 0, st_cand_rooms = KC > 1 ? st->cand_rooms : 0;  // (emptiness certificates: few-instance launches only)
   double st_pred[KC], st_fg[KC], st_fv[KC];
   int st_am[KC];
 #pragma unroll
@@ -2440,8 +2581,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 4 : 1) void k_lm_step(const Robo
       if (nid >= 0) {                             \
         double* __restrict__ dst_ = bp.qfs + ((size_t)(1 - par) * bp.cap * sp.kcap + s_pos) * sp.T * rb->n_frames; \
         for (int i_ = tid; i_ < sp.T * rb->n_frames; i_ += NT) dst_[i_] = bp.qf[(size_t)nid * sp.T * rb->n_frames + i_]; \
-        if (sp.pb_next && tid < 64) { /* nothing is known about a seed: every group of its job goes on the item list */ \
-          const bool on_ = tid < sp.pb_ng;        \
+        if (KC > 1 && sp.cert_next && tid == 0) bp.state[nid].cand_rooms = 1; /* (its seed's look will leave the rooms of every group) */ \
+        if ((sp.pb_next || (KC > 1 && sp.cert_next)) && tid < 64) { /* nothing is known about a seed: every group of its job goes on the item list */ \
+          const bool on_ = tid < (sp.pb_next ? sp.pb_ng : sp.cert_ng); \
           const unsigned long long mk_ = __ballot(on_); \
           int base_ = 0;                          \
           if (lane == 0) base_ = atomicAdd(bp.nlive + 8 + (1 - par), __popcll(mk_)); \
@@ -2683,7 +2825,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 4 : 1) void k_lm_step(const Robo
     }
     if (lane == 0) s_red[2 * cj] = __any(fail) ? 1.0 : 0.0;
   } else if (solver) {
-    if constexpr (NW == 8) __builtin_amdgcn_s_setprio(2);
+    if constexpr (NW == 8) __builtin_amdgcn_s_setprio(GTO_STEP_PRIO > 2 ? GTO_STEP_PRIO : 2);
     int fail = 0;
     double Zprev = 0.0, yprev_c = 0.0;
     for (int s = m - 1; s > mid; --s) {
@@ -2702,7 +2844,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 4 : 1) void k_lm_step(const Robo
       yprev_c = __shfl(pr, c << 3, 64);
     }
     if (lane == 0) s_red[2 * cj + 1] = __any(fail) ? 1.0 : 0.0;
-    if constexpr (NW == 8) __builtin_amdgcn_s_setprio(0);
+    if constexpr (NW == 8) __builtin_amdgcn_s_setprio(GTO_STEP_PRIO > 2 ? GTO_STEP_PRIO : (GTO_STEP_PRIO ? GTO_STEP_PRIO : 0));
     if (bp.dbg && b == 0 && tid == 64) bp.dbg[17] = clock64();
   }
   if (bp.dbg && b == 0 && tid == 0) bp.dbg[41] = clock64();
@@ -2882,6 +3024,17 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 4 : 1) void k_lm_step(const Robo
     st->status = status;
     st->evals = k + 1;
     st->argmin_cur = argmin_cur;
+    if constexpr (KC > 1) {
+      st->room_ok = accept ? st_cand_rooms : st_room_ok;
+      st->cand_rooms = sp.cert_next ? 1 : 0;
+    }
+  }
+  // Emptiness certificates of the next round's jobs of this instance (launches with few instances in flight: cert_tail)
+  if constexpr (KC > 1) {
+    if (sp.cert_next) {
+      __syncthreads();  // P5 is through with the steps' consumers of s_Z (the systems' region is dead since the back substitution)
+      cert_tail<NT, KC>(rb, bp, sp, B, b, slot, NS, Kg, (accept ? st_cand_rooms : st_room_ok) != 0, pos_next, s_x, s_Z, tid);
+    }
   }
   // Broad phase of the next round's job of this instance (the rounds that fill the GPU; prebroad_tail says what and why):
   // here the trial point is still in LDS, and the obstacle launch then only holds workgroups that have something to gather.
@@ -3857,6 +4010,7 @@ __global__ __launch_bounds__(GTO_WIDE_NT) void k_lm_step_wide(const RobotDev* __
   constexpr int NT = GTO_WIDE_NT, NW = NT / 64;
   static_assert(NW == 2 || NW == 4, "two solver waves; the data-parallel phases are strided by the workgroup size");
   const int tid = threadIdx.x, lane = tid & 63;
+  if constexpr (GTO_STEP_PRIO != 0) __builtin_amdgcn_s_setprio(GTO_STEP_PRIO);
   if (blockIdx.x == 0 && threadIdx.x == 0 && bp.progress) {  // lagged by design: what had finished when this launch started
     const int nd = __hip_atomic_load(bp.n_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(bp.progress, bp.progress_tag | (unsigned long long)(unsigned)nd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

@@ -236,12 +236,11 @@ class GTORobotModel:
             return Resident(h, DEPTH_SCENE, 0, c["gen"])
         if cache_ok and c["obs"] is not None and c["obs"].matches(dpc):
             return Resident(h, DEPTH_SCENE, 1, c["gen"])
-        # a field of a PREVIOUS grid (its cloud is not the one setup_points_field was last called with, or the grid has since
-        # been given as numbers) must not rebuild the resident scene: the robot's field_shape / origin describe the new grid
-        pend = self.__dict__.get("_pending_depth")
-        if pend is None or not (pend is grid or CloudSnapshot(grid).matches(pend)):
-            raise RuntimeError("this cost field belongs to a grid that is no longer the robot's: it was asked for before the last "
-                               "setup_points_field() / setup_workspace_field() call -- ask the cloud for its field again")
+        # (A field of a PREVIOUS grid -- asked for before the last setup_points_field() -- still resolves to its own field on its
+        # own grid: the resident scene is rebuilt for it, borrowers of the build that is gone share again, and the robot's
+        # field_shape / origin go on describing the grid they were last set up for: a resident consumer reads the scene's own
+        # geometry; one that takes the ARRAY of a stale field gets what the reference's driver gets when it keeps an array of
+        # the previous object: an array that does not fit the grid, refused by gto_set_scene's size check.)
         is_grid_cloud = dpc is grid or CloudSnapshot(grid).matches(dpc)
         if not is_grid_cloud and not (same_camera(grid, dpc) and float(grid.threshold) == float(dpc.threshold)):
             return None  # another camera or cut-off than the grid's cloud: one call cannot serve both; the host path does

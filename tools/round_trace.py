@@ -23,8 +23,8 @@ for q, v in byq.items():
     for s, e, n, _, g, w in v:
         if n == "k_lm_init":
             cur = {"q": q, "t0": s, "ev": [], "B": g // max(w, 1)}
-        elif cur is not None and n in ("k_obstacle_gram", "k_lm_step"):
-            cur["ev"].append((s, e, n, g // max(w, 1)))
+        elif cur is not None and n in ("k_obstacle_gram", "k_lm_step", "k_lm_step_wide"):
+            cur["ev"].append((s, e, "k_lm_step" if n == "k_lm_step_wide" else n, g // max(w, 1)))
         elif cur is not None and n == "k_lm_finalize":
             cur["t1"] = e
             calls.append(cur)
