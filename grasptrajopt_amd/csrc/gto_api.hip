@@ -64,11 +64,6 @@ struct gto_handle {
   unsigned long long* d_progress = nullptr;  // its device address
   unsigned progress_tag = 0;
   int ahead = 8;           // GTO_AHEAD: rounds the host may enqueue beyond the last one it has seen running
-  // emptiness certificates in the launches with few instances in flight (gto_kernels.h cert_tail; GTO_CERT=0: off): above
-  // cert_min instances in flight (below, one dispatch wave holds every group of every job anyway: GTO_CERT_MIN)
-  int cert = 1, cert_min = 32;
-  double cert_frac = 0.5;  // GTO_CERT_FRAC: a round's launch is laid out over the certificates' list when at most this share of the waypoints is on it
-  DevBuf roombuf;
   int nap_us = 50, nap_few_us = 10;  // GTO_NAP_US / GTO_NAP_FEW_US: the throttle's naps (the host thread of a lane sleep-polls two pinned words)
   int ahead_few = 4;       // ... in launches with few instances in flight (short rounds: four of them cover the host's launch time, and every round enqueued beyond the last instance's end runs empty)
   // speculation (gto_kernels.h GTO_KSPEC): candidates a step generates ahead of their evaluation in launches with few
@@ -257,9 +252,6 @@ int gto_create(const gto_robot_desc* d, const gto_solver_opts* opts, int device,
   }
   h->opts = *opts;
   if (const char* e = getenv("GTO_AHEAD")) h->ahead = h->ahead_few = std::max(1, atoi(e));
-  if (const char* e = getenv("GTO_CERT")) h->cert = atoi(e) != 0;
-  if (const char* e = getenv("GTO_CERT_MIN")) h->cert_min = std::max(0, atoi(e));
-  if (const char* e = getenv("GTO_CERT_FRAC")) h->cert_frac = atof(e);
   if (const char* e = getenv("GTO_NAP_US")) h->nap_us = std::max(1, atoi(e));
   if (const char* e = getenv("GTO_NAP_FEW_US")) h->nap_few_us = std::max(1, atoi(e));
   if (const char* e = getenv("GTO_SPEC_REJ")) h->spec_rej = std::max(1, std::min(GTO_KSPEC, atoi(e)));
@@ -660,7 +652,6 @@ int gto_create(const gto_robot_desc* d, const gto_solver_opts* opts, int device,
   if (!ok) { gto_destroy(h); return fail(nullptr, GTO_ERR_ALLOC, "device allocation failed in gto_create"); }
   h->np = rb.n_opt <= GTO_NB ? GTO_NB : 16;
   h->lm_lds = h->np == GTO_NB ? lm_lds_bytes(opts->T, 1) : lm_wide_lds_bytes(opts->T, 16);
-  if (const char* e = getenv("GTO_STEP_LDS_PAD")) h->lm_lds += (size_t)std::max(0, atoi(e));  // (experiments: the CU's LDS couples the step and the evaluation launches of different lanes)
   if (h->lm_lds > 160 * 1024) { gto_destroy(h); return fail(nullptr, GTO_ERR_UNSUPPORTED, "T too large for the step kernel's LDS"); }
   // candidates per step the eight-wave step kernel's LDS has room for at this T
   h->spec_kmax = 1;
@@ -711,7 +702,7 @@ void gto_destroy(gto_handle* h) {
   (void)hipFree(h->d_perm);
   (void)hipFree(h->d_chunks);
   (void)hipFree(h->d_pbchunks);
-  DevBuf* bufs[] = {&h->roombuf, &h->zws, &h->counters, &h->state, &h->Qcur, &h->Qtry, &h->vis, &h->screw, &h->blocks, &h->goalblk, &h->ssfixed, &h->ndone, &h->qf, &h->livebuf, &h->qfs, &h->wrecbuf, &h->itembuf};
+  DevBuf* bufs[] = {&h->zws, &h->counters, &h->state, &h->Qcur, &h->Qtry, &h->vis, &h->screw, &h->blocks, &h->goalblk, &h->ssfixed, &h->ndone, &h->qf, &h->livebuf, &h->qfs, &h->wrecbuf, &h->itembuf};
   if (h->h_ndone) (void)hipHostFree(h->h_ndone);
   if (h->h_progress) (void)hipHostFree(h->h_progress);
   for (DevBuf* b : bufs) (void)hipFree(b->p);
@@ -1067,7 +1058,6 @@ static int ensure_workspace(gto_handle* h, int B) {
   if ((rc = ensure(h, h->ndone, 64 * GTO_MAX_LANES))) return rc;  // a finished-counter per lane, a cache line apart
   if ((rc = ensure(h, h->qf, (size_t)B * T * rb.n_frames * sizeof(double)))) return rc;
   if ((rc = ensure(h, h->wrecbuf, (size_t)(kcap + 1) * B * T * 8 * sizeof(double)))) return rc;
-  if (h->cert && h->np == GTO_NB && (rc = ensure(h, h->roombuf, (size_t)(kcap + 1) * B * T * rb.n_links * sizeof(float)))) return rc;
   if (!h->h_ndone) HIPCHK(h, hipHostMalloc((void**)&h->h_ndone, 64));
   if (!h->h_progress) {
     HIPCHK(h, hipHostMalloc((void**)&h->h_progress, 64 * GTO_MAX_LANES, hipHostMallocMapped));  // eight words per lane
@@ -1102,7 +1092,6 @@ static BatchPtrs make_ptrs(gto_handle* h, const int32_t* scene_id, const double*
   bp.qfs = nullptr;
   bp.wrec = (double*)h->wrecbuf.p;
   bp.items = nullptr;
-  bp.room = nullptr;  // (the solve loop sets it when the call can use certificates)
   bp.scenes = h->d_scenes;
   bp.cap = 0;
   bp.n_total = 0;
@@ -1142,7 +1131,7 @@ static int prof_end(gto_handle* h, hipStream_t st) {
 
 static int launch_obstacle(gto_handle* h, hipStream_t st, const BatchPtrs& bp, const SolveParams& sp, int B, int t_begin,
                            int nT, int fixed_mode, bool timed, bool with_goal_terms = false, int n_jobs = 0, int tg = 0, bool deep = false,
-                           bool itemized = false, int items_hint = 0, bool room = false) {
+                           bool itemized = false, int items_hint = 0) {
   // waypoints per workgroup: groups of h->obs_tg (the two pinned waypoints form one group)
   const int TG = fixed_mode ? 1 : std::max(1, std::min(tg > 0 ? tg : h->obs_tg, nT));  // the init pass has 4 virtual waypoints
   const ObsGeom geo(h->rb.n_cframes, h->rb.n_frames, h->rb.fk_rounds_c, h->rb.n_links, h->rb.n_opt, h->rb.n_chunks, TG, nT, h->np);
@@ -1173,12 +1162,7 @@ static int launch_obstacle(gto_handle* h, hipStream_t st, const BatchPtrs& bp, c
   const int2* items_par = listed && itemized ? bp.items + (size_t)sp.parity * items_cap : nullptr;
   const int32_t* nitems_par = listed && itemized ? bp.nlive + 8 + sp.parity : nullptr;
   const bool hot = !fixed_mode && sp.grad_mode == GTO_GRAD_CENTRAL_DIFF && h->hot_variants;
-  if (room && hot && h->np == GTO_NB && !deep)  // the look leaves its rooms behind (emptiness certificates)
-    hipLaunchKernelGGL((k_obstacle_gram<GTO_NB, GTO_OBS_MAIN_PD, false, true, true>), grid, dim3(256), lds, st, jobs_par, njobs_par, items_par, nitems_par, geo.nG, geo.m_nG, n_regular, B, h->d_rb, h->d_px, h->d_py, h->d_pz, h->d_chunks, h->d_scenes, bpl, sp,
-                       t_begin, nT, fixed_mode, geo, 0);
-  else if (room)
-    return fail(h, GTO_ERR_HIP, "launch_obstacle: a launch that has to leave rooms behind was asked for in a variant that cannot");
-  else if (hot && h->np == GTO_NB && deep)
+  if (hot && h->np == GTO_NB && deep)
     hipLaunchKernelGGL((k_obstacle_gram<GTO_NB, GTO_OBS_DEEP_PD, false, true>), grid, dim3(256), lds, st, jobs_par, njobs_par, items_par, nitems_par, geo.nG, geo.m_nG, n_regular, B, h->d_rb, h->d_px, h->d_py, h->d_pz, h->d_chunks, h->d_scenes,
                        bpl, sp, t_begin, nT, fixed_mode, geo, 0);
   else if (hot && h->np == GTO_NB)
@@ -1196,10 +1180,7 @@ static int launch_obstacle(gto_handle* h, hipStream_t st, const BatchPtrs& bp, c
   else
     hipLaunchKernelGGL(k_obstacle_gram<16>, grid, dim3(256), lds, st, jobs_par, njobs_par, items_par, nitems_par, geo.nG, geo.m_nG, n_regular, B, h->d_rb, h->d_px, h->d_py, h->d_pz, h->d_chunks, h->d_scenes, bpl, sp,
                        t_begin, nT, fixed_mode, geo, 0);
-  if (sweep && room) {  // the crew of a launch that leaves rooms behind
-    hipLaunchKernelGGL((k_obstacle_gram<GTO_NB, GTO_OBS_MAIN_PD, true, false, true>), dim3(GTO_SWEEP_WGS), dim3(256), lds, st, jobs_par, njobs_par, items_par, nitems_par, geo.nG, geo.m_nG, GTO_SWEEP_WGS, B, h->d_rb, h->d_px, h->d_py, h->d_pz,
-                       h->d_chunks, h->d_scenes, bpl, sp, t_begin, nT, fixed_mode, geo, n_regular);
-  } else if (sweep) {  // the crew: items n_regular, n_regular + 1, ... of the list, if there are any
+  if (sweep) {  // the crew: items n_regular, n_regular + 1, ... of the list, if there are any
     hipLaunchKernelGGL((k_obstacle_gram<GTO_NB, GTO_OBS_MAIN_PD, true>), dim3(GTO_SWEEP_WGS), dim3(256), lds, st, jobs_par, njobs_par, items_par, nitems_par, geo.nG, geo.m_nG, GTO_SWEEP_WGS, B, h->d_rb, h->d_px, h->d_py, h->d_pz,
                        h->d_chunks, h->d_scenes, bpl, sp, t_begin, nT, fixed_mode, geo, n_regular);
   }
@@ -1265,8 +1246,6 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
     int n_resp = 0;                     // instances whose end this lane's finished-counter counts (own + adopted)
     int k = 0, known_done = 0, seen_round = -1, k_prev = 1;
     bool items_ready = false, pb_off = false, handed = false;
-    bool cert_pending = false;  // the step launch enqueued last certified / listed the groups of this round's jobs (cert_tail)
-    int cert_rounds = 0;        // rounds in a row with certificates (the published item counts are the certificates' after a few)
     double ratio_max = 0.0;  // items per job, the largest the lane's rounds published
     long end_us = 0, few_us = 0;  // (GTO_LANE_DEBUG) when the lane's thread returned / enqueued its first few-instance round, from the start of the threads
     unsigned long long* h_prog = nullptr;
@@ -1351,19 +1330,10 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
   const int pb_tg = std::max(1, std::min(h->obs_tg, T - 2)), pb_ng = (T - 2 + pb_tg - 1) / pb_tg;
   const PbLayout pbl(T, h->rb.n_frames, h->pb_C, h->rb.pb_npar);
   const bool pb_able = h->prebroad && h->np == GTO_NB && pb_ng <= 64 && h->obs_interleave != 1 && h->rb.n_xst <= GTO_PB_PARK && pbl.pw >= 1 && h->pb_C >= 1;
-  // Emptiness certificates in the launches with few instances in flight (cert_tail in k_lm_step<8, 4>, rooms left by
-  // k_obstacle_gram<.., ROOM>): one lane (a hand-over between lanes carries no item list), the shipped gradient mode (the
-  // ROOM variant is a HOT one), reach bounds for every joint, the groups of the itemized launches, room for the tail's
-  // tables in the step kernel's dead LDS
-  const bool cert_able = h->cert && L == 1 && h->np == GTO_NB && h->step_nw_few == 8 && h->hot_variants && sp.grad_mode == GTO_GRAD_CENTRAL_DIFF &&
-                         T - 2 <= 64 && h->rb.reach[0] >= 0.0 && h->roombuf.p != nullptr &&
-                         cert_tail_doubles(GTO_KSPEC, 1, T - 2, h->rb.n_links) + 8 <= (size_t)(T - 2) * 64;
   for (int l = 0; l < L; ++l) {
     SolveParams& lsp = lanes[l].sp;
     lsp.pb_tg = pb_tg, lsp.pb_ng = pb_ng, lsp.pb_pw = std::max(1, pbl.pw), lsp.pb_tab0 = pbl.tab0;
     lsp.pb_verify = h->dbg_cut == 10;
-    lsp.cert_next = 0, lsp.cert_tg = 1, lsp.cert_ng = T - 2;
-    lanes[l].bp.room = cert_able ? (float*)h->roombuf.p : nullptr;
   }
   sp.pb_tg = pb_tg, sp.pb_ng = pb_ng, sp.pb_pw = std::max(1, pbl.pw), sp.pb_tab0 = pbl.tab0;
   for (int l = 0; l < L; ++l) {  // seeds, goal terms of the seeds, the lane's lists of round 0
@@ -1402,34 +1372,10 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
     ln.span_prev = 0;
     if (few && !ln.few_us) ln.few_us = (long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - tp_start).count();
     const bool large_call = ln.n_resp > h->spec_deep;  // (its tail: the other lanes' launches are on the GPU, too)
-    // a round whose groups the last step launch certified or listed (cert_tail): the launch is laid out over that list, in
-    // the list's groups (consecutive waypoints, h->obs_tg of them), and leaves the rooms of what it looks at
-    const bool cert_now = ln.cert_pending;
-    ln.cert_pending = false;
-    // ... laid out over the list when the last count the step launches published says it is short (the rounds in which the
-    // instances creep); while most waypoints are still listed (the first iterations of an instance move the arm by
-    // decimetres) the launch looks at every group as ever -- balanced groups of waypoints far apart -- and leaves the rooms
-    bool cert_items = false;
-    int cert_hint = 0;
-    const bool lsp_verify = ln.sp.pb_verify != 0;
-    ln.cert_rounds = cert_now ? ln.cert_rounds + 1 : 0;
-    if (cert_now && lsp_verify) {  // (debug builds, GTO_DEBUG_CUT=10: every waypoint is listed, the settled ones marked and checked by the look)
-      cert_items = true;
-      cert_hint = 0;
-    } else if (cert_now && ln.cert_rounds > (few ? h->ahead_few : h->ahead) + 2) {  // (the host runs that many rounds ahead of what it reads)
-      const unsigned long long p2 = __atomic_load_n(ln.h_prog + 2, __ATOMIC_RELAXED);
-      if ((unsigned)(p2 >> 32) == h->progress_tag && (p2 & 0xfffffull) > 0 && (p2 & 0xfffffull) < 0xfffffull) {
-        const double items_seen = (double)(p2 & 0xfffffull), jobs_seen = (double)((p2 >> 20) & 0xfffull);
-        if (jobs_seen > 0 && jobs_seen < 4095 && items_seen <= h->cert_frac * jobs_seen * (T - 2)) {
-          cert_items = true;
-          cert_hint = h->item_hint_forced > 0 ? h->item_hint_forced : (int)(1.5 * items_seen) + 256;
-        }
-      }
-    }
-    const int tg = cert_items ? 1 : (few ? (large_call ? h->obs_tg_few_tail : h->obs_tg_few) : h->obs_tg);
+    const int tg = few ? (large_call ? h->obs_tg_few_tail : h->obs_tg_few) : h->obs_tg;
     SolveParams& lsp = ln.sp;
-    lsp.interleave = !cert_items && (h->obs_interleave == 1 || (h->obs_interleave == 2 && few));
-    const bool itemized = cert_items || (ln.items_ready && !few);
+    lsp.interleave = h->obs_interleave == 1 || (h->obs_interleave == 2 && few);
+    const bool itemized = ln.items_ready && !few;
     ln.items_ready = false;
     lsp.round = k;
     lsp.parity = k & 1;
@@ -1451,8 +1397,7 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
       }
       if (h->item_hint_forced > 0) items_hint = h->item_hint_forced;  // (tests: a launch of a few workgroups, the crew does the rest)
     }
-    if ((rc_ = launch_obstacle(h, ln.st, ln.bp, lsp, B, 2, T - 2, 0, h->profiling, true, span * ln.k_prev, tg, !cert_now && few && h->obs_deep && in_flight <= h->obs_deep_max, itemized,
-                               cert_items ? cert_hint : items_hint, cert_now))) return rc_;
+    if ((rc_ = launch_obstacle(h, ln.st, ln.bp, lsp, B, 2, T - 2, 0, h->profiling, true, span * ln.k_prev, tg, few && h->obs_deep && in_flight <= h->obs_deep_max, itemized, items_hint))) return rc_;
     if (h->np == GTO_NB) {
       if (few && h->step_nw_few == 8) {
         // few instances in flight: eight waves per instance and candidate trial points ahead of their evaluation
@@ -1462,10 +1407,6 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
         lsp.k_rej = in_flight <= h->spec_few ? std::min(std::max(std::min(h->spec_rej, k_budget), h->spec_rej_few), h->spec_kmax) : 1;
         const int kl = std::max(lsp.k_acc, lsp.k_rej);
         lsp.pb_next = 0;
-        // certificates for the next round's jobs: between the launches that fill the GPU (which run the exact tests in the
-        // step kernel) and the handful of instances whose every group fits one dispatch wave of the deep variant anyway
-        lsp.cert_next = cert_able && in_flight > h->cert_min && cert_tail_doubles(GTO_KSPEC, kl, T - 2, h->rb.n_links) + 8 <= (size_t)kl * (T - 2) * 64;
-        ln.cert_pending = lsp.cert_next != 0;
         if (h->profiling && (rc_ = prof_begin(h, ln.st, GTO_PROF_STEP_FEW, in_flight))) return rc_;
         lsp.static_pos = 0;
         hipLaunchKernelGGL((k_lm_step<8, GTO_KSPEC>), dim3(span), dim3(512), lm_lds_bytes(T, kl), ln.st, h->d_rb, h->d_pbchunks, ln.bp, lsp, B);
@@ -1671,13 +1612,6 @@ int gto_solve_batch_device(gto_handle* h, int32_t B, int32_t n_max, const int32_
       fprintf(stderr, "\n");
     }
     fprintf(stderr, "[gto dbg] broad phase of the step kernel (GTO_DEBUG_CUT=10, -DGTO_DEBUG_LONGEST_WG: settled groups are looked at anyway): %lld groups settled, %lld of them with a surviving chunk, %lld with a CONTRIBUTION (must be 0)\n", t[49], t[50], t[55]);
-#ifndef GTO_DEBUG_LONGEST_WG
-    {
-      fprintf(stderr, "[gto dbg] emptiness certificates (cert_tail), groups listed / groups of the candidates, by round of the call:");
-      for (int i = 0; i < 64; ++i) if (t[192 + i]) fprintf(stderr, " r%d %lld/%lld", i, t[128 + i], t[192 + i]);
-      fprintf(stderr, "\n");
-    }
-#endif
     {
       fprintf(stderr, "[gto dbg] workgroups without a surviving chunk by the index shift their closest chunk tolerates (0,1,2,...,63+):");
       for (int i = 128; i < 192; ++i) fprintf(stderr, " %lld", t[i]);

@@ -65,7 +65,7 @@ def _run(robot, B, out, env_extra):
     return r.stderr
 
 
-@pytest.mark.parametrize("robot,B", [("panda_5k", 512), ("fetch", 320), ("panda_5k", 120)])
+@pytest.mark.parametrize("robot,B", [("panda_5k", 512), ("fetch", 320)])
 def test_groups_settled_by_the_step_kernel_get_no_contribution(debug_library, tmp_path, robot, B):
     a, b = str(tmp_path / "verify.npz"), str(tmp_path / "plain.npz")
     err = _run(robot, B, a, {"GTO_HIP_LIB": debug_library, "GTO_DEBUG_TIMING": "1", "GTO_DEBUG_CUT": "10"})
@@ -77,9 +77,7 @@ def test_groups_settled_by_the_step_kernel_get_no_contribution(debug_library, tm
         assert m, l
         settled += int(m.group(1))
         contributions += int(m.group(3))
-    # the broad phase ran and settled groups (B = 512 / 320 instances in flight: the rounds that fill the GPU, then the rounds
-    # with few instances in flight, whose groups the step kernel settles by their rooms: cert_tail; B = 120: those alone)
-    assert settled > 1000, lines
+    assert settled > 1000, lines  # the broad phase ran and settled groups (B instances in flight: the rounds that fill the GPU)
     assert contributions == 0, lines
     _run(robot, B, b, {})  # the shipped library, nothing listed that does not have to be
     va, vb = np.load(a), np.load(b)

@@ -376,9 +376,7 @@ def test_step_kernel_broad_phase_other_robots_and_horizons(capi, oracle_mod, mon
                                         ("GTO_SPEC_ACC,GTO_SPEC_DEEP,GTO_SPEC_REJ", "1,0,1"), ("GTO_OBS_DEEP", "0"),
                                         ("GTO_SPEC_FEW,GTO_SPEC_REJ,GTO_SPEC_JOBS", "100000,4,100000"), ("GTO_SPEC_FEW", "0"),
                                         ("GTO_SPEC_STREAK,GTO_SPEC_JOBS", "1,100000"), ("GTO_SPEC_STREAK,GTO_SPEC_JOBS", "0,100000"),
-                                        ("GTO_SPEC_JOBS,GTO_SPEC_REJ_FEW", "1,1"), ("GTO_SPEC_JOBS,GTO_SPEC_REJ_FEW", "48,4"),
-                                        ("GTO_CERT", "0"), ("GTO_CERT_MIN", "0"), ("GTO_CERT_MIN,GTO_OBS_TG", "0,2"),
-                                        ("GTO_CERT_MIN,GTO_SPEC_JOBS,GTO_SPEC_REJ_FEW", "0,48,4")])
+                                        ("GTO_SPEC_JOBS,GTO_SPEC_REJ_FEW", "1,1"), ("GTO_SPEC_JOBS,GTO_SPEC_REJ_FEW", "48,4")])
 def test_launch_geometry_does_not_change_results(capi, oracle_mod, monkeypatch, knob, value):
     """How the waypoints are dealt to the workgroups of the obstacle kernel (group size, consecutive or interleaved), how
     far the host runs ahead of the GPU, when a call switches to the launches for few instances in flight, and how many
@@ -410,49 +408,6 @@ def test_launch_geometry_does_not_change_results(capi, oracle_mod, monkeypatch, 
         assert work[0] == work[1] and work[0] > 0
     h2.close()
     h.close()
-
-
-@pytest.mark.parametrize("robot,B,T,scene_seed,shelf", [("panda", 100, 50, 3, False), ("panda_5k", 150, 50, 1, False), ("fetch", 70, 30, 5, True)])
-def test_emptiness_certificates_do_not_change_results(capi, oracle_mod, monkeypatch, robot, B, T, scene_seed, shelf):
-    """Launches with few instances in flight (33 .. 192 here): the step kernel settles the waypoint groups whose links all
-    keep room -- the metres the last look found, less what the candidates' steps can move a point by (cert_tail) -- and
-    the obstacle launch is laid out over the others.  Scheduling only: GTO_CERT=0 (every group of every job is looked at),
-    the default, and certificates for every launch with few instances in flight (GTO_CERT_MIN=0), with two and with three
-    waypoints per group and with up to four candidates per instance, give every instance the same bits; a sample against
-    the oracle (which culls nothing)."""
-    prob = Problem(robot, B=B, scene_seed=scene_seed, T=T, n_goals=2, shelf=shelf, **({"table_z": 0.75} if shelf else {}))
-    kw = dict(max_iter=45, T=T, standoff_offset=-max(2, T // 5))
-    monkeypatch.setenv("GTO_CERT", "0")
-    h, o = make_pair(capi, oracle_mod, prob, **kw)
-    ref = h.solve_batch(*prob.solve_args())
-    h.set_profiling(True)
-    h.solve_batch(*prob.solve_args())
-    pts_all = h.last_kernel_work()[0]
-    h.close()
-    assert len(set(ref[3].tolist())) > 3
-    wgs = {}
-    for env in ({}, {"GTO_CERT_MIN": "0"}, {"GTO_CERT_MIN": "0", "GTO_OBS_TG": "2"}, {"GTO_CERT_MIN": "0", "GTO_SPEC_JOBS": "100000", "GTO_SPEC_REJ_FEW": "4", "GTO_SPEC_ACC": "4", "GTO_SPEC_DEEP": "100000"},
-                {"GTO_SLOTS": "40", "GTO_CERT_MIN": "8"}):
-        monkeypatch.delenv("GTO_CERT", raising=False)
-        for k_ in ("GTO_CERT_MIN", "GTO_OBS_TG", "GTO_SPEC_JOBS", "GTO_SPEC_REJ_FEW", "GTO_SPEC_ACC", "GTO_SPEC_DEEP", "GTO_SLOTS"):
-            monkeypatch.delenv(k_, raising=False)
-        for k_, v_ in env.items():
-            monkeypatch.setenv(k_, v_)
-        h2 = capi.SolverHandle(prob.desc, prob.cfg["link_ee"], prob.cfg["link_gripper"], oracle_mod.reference_opts(**kw), device=0)
-        h2.set_scene(*prob.scene_args())
-        for _ in range(2):
-            got = h2.solve_batch(*prob.solve_args())
-            for a, b in zip(ref, got):
-                np.testing.assert_array_equal(a, b)
-        h2.set_profiling(True)
-        h2.solve_batch(*prob.solve_args())
-        wgs[tuple(sorted(env.items()))] = h2.last_kernel_work()[0]
-        h2.close()
-    ns = 6
-    Qo, _, fo, ito, sto = o.solve_batch(0, prob.qc[:ns], prob.goals[:ns], prob.n_goals, prob.S, prob.base[:ns], prob.Q0[:ns])
-    np.testing.assert_array_equal(ref[3][:ns], ito)
-    np.testing.assert_array_equal(ref[4][:ns], sto)
-    np.testing.assert_allclose(ref[0][:ns], Qo, rtol=0, atol=1e-6)
 
 
 @pytest.mark.parametrize("robot,B,T", [("panda", 96, 50), ("fetch", 40, 30), ("fetch_mobile", 24, 20)])
