@@ -893,6 +893,12 @@ def main(argv=None, emit=True):
                                      "what": "points gathered by the region's solver calls (counted while one lane repeats them) x 28 B over the "
                                              "median timed region; one_lane_kernel_ms_per_step = kernel time of the solve loop per step with ONE "
                                              "lane on the GPU (it exceeds ms_per_step when the lanes overlap)"},
+                    # what the counters mean here (profiles/r06_counter_calibration.txt, tools/probes/gather32_probe.hip): one memory-side
+                    # read request fetches a 128-B line and FETCH_SIZE tallies it at 64 B, for 32-B random gathers as for streaming
+                    # reads (x 2 holds); WRITE_SIZE is exact for whole 64-B lines.  A COLD 32-B record gather therefore moves
+                    # 128 B per 28 algorithmic bytes: traffic_over_alg_bytes 4.57 means "every lookup a line of its own", below it
+                    # the records are re-used out of L2 / Infinity Cache
+                    "traffic_calibration": "FETCH_SIZE x 2 + WRITE_SIZE; cold 32-B gathers: 4.57 x alg (profiles/r06_counter_calibration.txt)",
                     "instances_per_call": B * max(plan), "slots": slots,
                     # the kernel is bound by instruction issue and latency, not by HBM: the same PMC passes give the share of the
                     # time the FP64 vector units are busy (a second roofline axis: 1.0 = every SIMD issuing vector work every cycle)

@@ -5,7 +5,7 @@
 # file name's companion STAMP and inside every text file; tools/run_evidence.sh (local) refuses to start from a dirty tree
 # and copies what is worth judging to profiles/.
 # usage (through tools/run_evidence.sh): tools/evidence.sh <tag> <git head>
-tag=${1:-r05}; head=${2:-unknown}
+tag=${1:-r06}; head=${2:-unknown}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/evidence; mkdir -p $out
 cd $root
@@ -30,8 +30,12 @@ prof pipelined
 prof pipelined_steps20 --steps 20 --warmup 5
 rm -rf /tmp/tl_ev; timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/tl_ev -o p -- python $root/bench.py --steps 20 --warmup 5 --no-cpu-baseline --merged-launches-only --repeats 2 > $out/${tag}_rounds.log 2>&1
 csv=$(ls /tmp/tl_ev/*kernel_trace.csv /tmp/tl_ev/*/*kernel_trace.csv 2>/dev/null | head -1); python $root/tools/round_trace.py $csv 0 > $out/${tag}_rounds_steps20.txt; python $root/tools/timeline.py $csv 3 > $out/${tag}_timeline_steps20.txt 2>&1
+# the same listing for BASELINE configs[2] and [4] (four lanes, calls of 8 steps: the lines of other_configs)
+for cfgn in "cfg2 --robot fetch --batch 256 --shelf" "cfg4 --robot fetch_mobile --T 80 --grid 256 --shelf --batch 64"; do set -- $cfgn; nm=$1; shift
+  rm -rf /tmp/tl_$nm; timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/tl_$nm -o p -- python $root/bench.py --light --no-cpu-baseline --no-next-rows --no-other-configs --repeats 2 --warmup 1 --merge 8 --steps 32 "$@" > $out/${tag}_rounds_$nm.log 2>&1
+  csv=$(ls /tmp/tl_$nm/*kernel_trace.csv /tmp/tl_$nm/*/*kernel_trace.csv 2>/dev/null | head -1); python $root/tools/round_trace.py $csv 0 | awk 'NR<=40 || NR%10==0' > $out/${tag}_rounds_$nm.txt; st $out/${tag}_rounds_$nm.txt; done
 cd $root
-python tools/serial_latency.py > $out/${tag}_serial_latency.txt 2>&1
+B=1,4,8,64,150 python tools/serial_latency.py > $out/${tag}_serial_latency.txt 2>&1
 python tools/planner_latency.py > $out/${tag}_planner_latency.txt 2>&1
 python tools/pipeline_latency.py > $out/${tag}_pipeline_latency.txt 2>&1
 st $out/${tag}_rounds_steps20.txt $out/${tag}_timeline_steps20.txt $out/${tag}_serial_latency.txt $out/${tag}_planner_latency.txt $out/${tag}_pipeline_latency.txt

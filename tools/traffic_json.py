@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """profiles/traffic.json from the PMC passes of tools/pmc_pass.sh: HBM traffic (FETCH_SIZE x 2 + WRITE_SIZE, KB -> bytes; the
-factor 2 is MI355X_MICROARCH.md's gfx950 correction: FETCH_SIZE counts 128-B requests at 64 B) and issue-side figures of
+factor 2 is MI355X_MICROARCH.md's gfx950 correction: FETCH_SIZE counts 128-B requests at 64 B -- calibrated for this
+kernel's 32-B random record gathers in round 6: tools/counter_calibration.py, profiles/r06_counter_calibration.txt) and issue-side figures of
 the dominant kernel per launch, one entry per call size.
 Per kernel VARIANT of the solve loop as well ("variants"), so that bench.py can put a variant's counter traffic next to the
 algorithmic bytes of the same population of launches.
@@ -63,7 +64,7 @@ for spec in sys.argv[2:]:
                   f"--merged-launches-only with calls of {size} instances)",
         "kernel": kname, "variants": variants, "launches": k["launches"], "mean_launch_us_profiled": round(us, 2),
         "FETCH_SIZE_KB_mean_per_launch": round(k["FETCH_SIZE"], 1), "WRITE_SIZE_KB_mean_per_launch": round(k["WRITE_SIZE"], 1),
-        "correction": "FETCH_SIZE doubled (gfx950 counts 128-B requests at 64 B, MI355X_MICROARCH.md); WRITE_SIZE uncalibrated, taken as is",
+        "correction": "FETCH_SIZE doubled (a request is a 128-B line tallied at 64 B, for 32-B random gathers as for streaming reads; WRITE_SIZE exact for whole 64-B lines, 32 B per partial line: profiles/r06_counter_calibration.txt)",
         "hbm_bytes_per_launch": int(round((2 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024)),
         "issue": {
             "fp64_valu_busy_frac": round(4 * k["SQ_ACTIVE_INST_VALU"] / simd_cycles, 3),
