@@ -673,7 +673,11 @@ int gto_create(const gto_robot_desc* d, const gto_solver_opts* opts, int device,
       gto_destroy(h);
       return fail(nullptr, GTO_ERR_HIP, "hipFuncSetAttribute failed");
     }
-    if (w) h->obs_tg = h->obs_tg_few = h->obs_tg_few_tail = std::min(h->obs_tg, 2);  // wider blocks: two waypoints per workgroup keep its LDS small
+    if (w) {  // wider blocks: at most three waypoints per workgroup (GTO_OBS_TG_WIDE; until round 6 two: configs[4] 28.2 -> 29.1 k
+      // with three, 24.4 k with four, 20.5 k with one)
+      const int cap_w = getenv("GTO_OBS_TG_WIDE") ? std::max(1, std::min(GTO_MAX_TG, atoi(getenv("GTO_OBS_TG_WIDE")))) : 3;
+      h->obs_tg = h->obs_tg_few = h->obs_tg_few_tail = std::min(h->obs_tg, cap_w);
+    }
   }
   *out = h;
   return GTO_OK;
