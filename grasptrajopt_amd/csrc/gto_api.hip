@@ -659,7 +659,12 @@ int gto_create(const gto_robot_desc* d, const gto_solver_opts* opts, int device,
     while (h->spec_kmax < GTO_KSPEC && lm_lds_bytes(opts->T, h->spec_kmax + 1) <= 160 * 1024 - 256) ++h->spec_kmax;
   {
     const int w = h->np == GTO_NB ? 0 : 1;
-    const ObsLds lay(w ? 2 : GTO_MAX_TG, rb.n_frames, rb.n_links, (w ? 2 : GTO_MAX_TG) * rb.n_chunks, h->np);
+    // waypoints per obstacle workgroup of the wide robots (see below), fewer if the robot's tables would not fit the CU's LDS
+    int tg_w = getenv("GTO_OBS_TG_WIDE") ? std::max(1, std::min(GTO_MAX_TG, atoi(getenv("GTO_OBS_TG_WIDE")))) : 5;
+    if (w && getenv("GTO_OBS_TG")) tg_w = std::max(tg_w, h->obs_tg);  // (GTO_OBS_TG, when given, is the group size of every robot)
+    while (w && tg_w > 1 && (size_t)ObsLds(tg_w, rb.n_frames, rb.n_links, tg_w * rb.n_chunks, h->np).total_doubles * sizeof(double) > 150 * 1024) --tg_w;
+    const int tg_lds = w ? tg_w : GTO_MAX_TG;
+    const ObsLds lay(tg_lds, rb.n_frames, rb.n_links, tg_lds * rb.n_chunks, h->np);
     const size_t lds = std::min<size_t>((size_t)lay.total_doubles * sizeof(double), 160 * 1024);
     if ((size_t)lay.total_doubles * sizeof(double) > 150 * 1024) { gto_destroy(h); return fail(nullptr, GTO_ERR_UNSUPPORTED, "robot too large for the obstacle kernel's LDS"); }
     hipError_t e1 = raise_dynamic_lds(w ? (const void*)k_obstacle_gram<16> : (const void*)k_obstacle_gram<GTO_NB>, lds);
@@ -673,10 +678,12 @@ int gto_create(const gto_robot_desc* d, const gto_solver_opts* opts, int device,
       gto_destroy(h);
       return fail(nullptr, GTO_ERR_HIP, "hipFuncSetAttribute failed");
     }
-    if (w) {  // wider blocks: at most three waypoints per workgroup (GTO_OBS_TG_WIDE; until round 6 two: configs[4] 28.2 -> 29.1 k
-      // with three, 24.4 k with four, 20.5 k with one)
-      const int cap_w = getenv("GTO_OBS_TG_WIDE") ? std::max(1, std::min(GTO_MAX_TG, atoi(getenv("GTO_OBS_TG_WIDE")))) : 3;
-      h->obs_tg = h->obs_tg_few = h->obs_tg_few_tail = std::min(h->obs_tg, cap_w);
+    if (w) {  // wider blocks (GTO_OBS_TG_WIDE): five waypoints per workgroup.  The fixed part of a 16-wide workgroup (tables, matrix-core
+      // prefix, projection onto sixteen screws) is larger than an 8-wide one's, and since round 6 the epilogue projects one
+      // waypoint at a time (ObsLds: its scratch no longer grows with the group): configs[4] with 2 / 3 / 4 / 5 / 6 / 8 waypoints
+      // per workgroup 29.0 / 33.1 / 35.4 / 36.6 / 34.8 / 28.7 k trajectories/s (until round 6: two, 28.2 k)
+      h->obs_tg = getenv("GTO_OBS_TG") ? std::min(h->obs_tg, tg_w) : tg_w;
+      h->obs_tg_few = std::min(h->obs_tg_few, h->obs_tg), h->obs_tg_few_tail = std::min(h->obs_tg_few_tail, h->obs_tg);
     }
   }
   *out = h;
