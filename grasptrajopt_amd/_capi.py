@@ -106,7 +106,7 @@ def pack_robot_desc(desc: RobotDesc, link_ee: str, link_gripper: str,
 # include/gto_solver.h
 GTO_GRAD_CENTRAL_DIFF, GTO_GRAD_ZERO = 0, 1
 GTO_STATUS_CONVERGED, GTO_STATUS_MAX_ITER, GTO_STATUS_NUMERICAL = 0, 1, 2
-ABI_VERSION = 1006  # include/gto_solver.h GTO_ABI_VERSION (checked against gto_version() when the library is loaded)
+ABI_VERSION = 1007  # include/gto_solver.h GTO_ABI_VERSION (checked against gto_version() when the library is loaded)
 
 _lib = None
 
@@ -210,6 +210,8 @@ def load_library(path: Optional[str] = None):
     lib.gto_get_scene_fields.restype = C.c_int
     lib.gto_eval_fk.argtypes = [H, C.c_int32, _pd, _pd]
     lib.gto_eval_points.argtypes = [H, C.c_int32, C.c_int32, _pd, _pd, C.c_int32, _pd, _pi, _pd, _pd]
+    lib.gto_eval_points_hessian.argtypes = [H, C.c_int32, C.c_int32, _pd, _pd, C.c_int32, _pd]
+    lib.gto_eval_points_hessian.restype = C.c_int
     lib.gto_eval_objective.argtypes = [H, C.c_int32, C.c_int32, _pi, _pd, _pi, _pd, _pd, _pd, _pd, _pd, _pd, _pi]
     lib.gto_eval_obstacle_normal_eq.argtypes = [H, C.c_int32, _pi, _pd, _pd, _pd, _pd, _pd]
     lib.gto_plan_cost.argtypes = [H, C.c_int32, C.c_int32, _pd, _pd, _pd, _pd]
@@ -221,7 +223,7 @@ def load_library(path: Optional[str] = None):
                                        C.c_float, C.c_float, _pf, _pu8, _pf, _pd, _pu8]
     for fn in ("gto_create", "gto_set_opts", "gto_set_scene", "gto_set_scene_values", "gto_drop_scene", "gto_solve_batch",
                "gto_solve_batch_device", "gto_last_kernel_time", "gto_last_kernel_work", "gto_set_profiling", "gto_set_stream", "gto_set_mode", "gto_set_lanes", "gto_set_lane_streams", "gto_share_scene",
-               "gto_eval_fk", "gto_eval_points", "gto_eval_objective", "gto_eval_obstacle_normal_eq", "gto_plan_cost", "gto_solve_ik_batch",
+               "gto_eval_fk", "gto_eval_points", "gto_eval_points_hessian", "gto_eval_objective", "gto_eval_obstacle_normal_eq", "gto_plan_cost", "gto_solve_ik_batch",
                "gto_solve_base_batch", "gto_eval_base_objective", "gto_depth_sdf_cost"):
         getattr(lib, fn).restype = C.c_int
     if path is None:
@@ -233,7 +235,7 @@ EXPORTED_SYMBOLS = (
     "gto_default_opts", "gto_version", "gto_create", "gto_destroy", "gto_last_error", "gto_set_opts",
     "gto_set_scene", "gto_set_scene_values", "gto_drop_scene", "gto_solve_batch", "gto_solve_batch_device",
     "gto_last_kernel_time", "gto_last_kernel_work", "gto_last_kernel_profile", "gto_set_profiling", "gto_set_stream", "gto_set_mode", "gto_set_lanes", "gto_set_lane_streams", "gto_share_scene", "gto_share_scene_halves",
-    "gto_eval_fk", "gto_eval_points",
+    "gto_eval_fk", "gto_eval_points", "gto_eval_points_hessian",
     "gto_eval_objective", "gto_eval_obstacle_normal_eq", "gto_plan_cost", "gto_solve_ik_batch", "gto_solve_base_batch",
     "gto_eval_base_objective", "gto_depth_sdf_cost", "gto_scene_from_depth", "gto_get_scene_fields",
 )
@@ -490,6 +492,15 @@ class SolverHandle:
                                              _p(xyz, _pd), _p(off, _pi), _p(val, _pd), _p(grad, _pd)),
                     "gto_eval_points")
         return xyz, off, val, grad
+
+    def eval_points_hessian(self, scene_id, q, base_pos, use_obs=False):
+        """Hessian of the selected cost field at the surface points of configurations q: (nq, P, 3, 3), gto/sdf_callback.py:165-183."""
+        q = _f64(q).reshape(-1, self.desc.ndof)
+        nq, P = q.shape[0], self.desc.n_points
+        base = _f64(np.broadcast_to(_f64(base_pos).reshape(-1, 3), (nq, 3)))
+        out = np.empty((nq, P, 3, 3))
+        self._check(self.lib.gto_eval_points_hessian(self._h, scene_id, nq, _p(q, _pd), _p(base, _pd), int(use_obs), _p(out, _pd)), "gto_eval_points_hessian")
+        return out
 
     def eval_objective(self, scene_id, goals, n_goals, standoff, base_pos, Q):
         d, T = self.desc, self.T

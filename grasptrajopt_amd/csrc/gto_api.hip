@@ -1940,6 +1940,32 @@ int gto_eval_points(gto_handle* h, int32_t scene_id, int32_t nq, const double* q
   return GTO_OK;
 }
 
+int gto_eval_points_hessian(gto_handle* h, int32_t scene_id, int32_t nq, const double* q, const double* base_pos, int32_t use_obs,
+                            double* hess_out) {
+  if (!h || !q || !base_pos || !hess_out || nq < 0) return h ? fail(h, GTO_ERR_INVALID_ARG, "bad argument") : GTO_ERR_INVALID_ARG;
+  if (nq == 0) return GTO_OK;
+  if (scene_id < 0 || (size_t)scene_id >= h->scenes.size() || !h->scenes[scene_id].valid) return fail(h, GTO_ERR_NO_SCENE, "unknown scene");
+  HIPCHK(h, hipSetDevice(h->device));
+  const int P = h->rb.n_points, L = h->rb.n_links;
+  const void *dq, *dbase;
+  void* dh;
+  int rc;
+  if ((rc = stage_in(h, 0, q, (size_t)nq * h->rb.ndof * sizeof(double), &dq))) return rc;
+  if ((rc = stage_in(h, 1, base_pos, (size_t)nq * 3 * sizeof(double), &dbase))) return rc;
+  if ((rc = ensure(h, h->vis, (size_t)nq * L * 12 * sizeof(double)))) return rc;
+  if ((rc = stage_out(h, 0, hess_out, (size_t)nq * P * 9 * sizeof(double), &dh))) return rc;
+  {
+    const size_t lds = sizeof(double) * eval_kin_lds_doubles(h->rb.n_frames, h->rb.n_links, h->rb.n_opt);
+    HIPCHK(h, raise_dynamic_lds((const void*)k_eval_kin, lds));
+    hipLaunchKernelGGL(k_eval_kin, dim3((nq + GTO_EVAL_TG - 1) / GTO_EVAL_TG), dim3(256), lds, h->stream, h->d_rb, nq, (const double*)dq,
+                       (double*)nullptr, (double*)h->vis.p);
+  }
+  hipLaunchKernelGGL(k_eval_points_hessian, dim3((P + 255) / 256, nq), dim3(256), 0, h->stream, h->d_rb, h->d_px, h->d_py, h->d_pz, h->d_plink,
+                     h->d_perm, h->d_scenes + scene_id, nq, (const double*)h->vis.p, (const double*)dbase, use_obs, (double*)dh);
+  if ((rc = fetch_out(h, 0, hess_out, (size_t)nq * P * 9 * sizeof(double)))) return rc;
+  return sync_and_finish_out(h);
+}
+
 // Shared by gto_eval_objective / gto_eval_obstacle_normal_eq: run init (kinematics + goal terms of Q as
 // the "trial") and the obstacle kernel over all waypoints, then read the pieces back.
 static int eval_common(gto_handle* h, int B, int n_max, const int32_t* scene_id, const double* goals,

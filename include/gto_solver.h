@@ -116,7 +116,7 @@ void gto_default_opts(gto_solver_opts* opts);
 /* Library/ABI version (major*1000 + minor): GTO_ABI_VERSION of the header the library was built from.  A binding checks it
  * when it loads the library and refuses another number (grasptrajopt_amd/_capi.py load_library): every change of a
  * signature or of a struct in this header bumps the minor. */
-#define GTO_ABI_VERSION 1006
+#define GTO_ABI_VERSION 1007
 int32_t gto_version(void);
 
 /*
@@ -320,6 +320,13 @@ int gto_eval_points(gto_handle* h, int32_t scene_id, int32_t nq, const double* q
                     const double* base_pos /*[nq,3]*/, int32_t use_obs,
                     double* xyz_out /*[nq,P,3]*/, int32_t* offset_out /*[nq,P]*/,
                     double* value_out /*[nq,P]*/, double* grad_out /*[nq,P,3]*/);
+
+/* The Hessian of the field selected by `use_obs` at the same surface points, [nq, P, 9] row-major 3x3: mixed central
+ * differences (f(i+e_a+e_b) - f(i+e_a-e_b) - f(i-e_a+e_b) + f(i-e_a-e_b)) / (4 res^2) of the nearest-voxel values with every
+ * sample's indices clipped on their own (gto/sdf_callback.py:159-183, HesFun.eval / get_value).  The solve never reads it
+ * (Gauss-Newton); it completes the SDFCallback / JacFun / HesFun triple of the reference behind this ABI. */
+int gto_eval_points_hessian(gto_handle* h, int32_t scene_id, int32_t nq, const double* q /*[nq,ndof]*/,
+                            const double* base_pos /*[nq,3]*/, int32_t use_obs, double* hess_out /*[nq,P,9]*/);
 
 /* Objective terms of SURVEY.md Appendix A at given trajectories Q [B, ndof, T]:
  * f_goal (min over the goal set), f_obs (incl. w_obstacle), f_vel (incl. w_vel), arg-min goal.

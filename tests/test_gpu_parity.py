@@ -74,6 +74,11 @@ def test_field_lookup_against_reference_golden(capi, oracle_mod):
     np.testing.assert_array_equal(xyz[0], s["points"])
     np.testing.assert_array_equal(val[0], s["value"])
     np.testing.assert_allclose(grad[0], s["jac"], rtol=2e-15, atol=0)
+    # HesFun.eval (gto/sdf_callback.py:165-183) on the same points, incl. the clipped samples at the grid's border
+    hess = h.eval_points_hessian(0, np.zeros((1, 1)), [0, 0, 0])
+    np.testing.assert_allclose(hess[0], s["hess"], rtol=2e-15, atol=0)
+    _, _, ho = oracle_mod.sdf_eval(s["data"], s["shape"], s["origin"], float(s["res"]), s["points"])
+    np.testing.assert_array_equal(hess[0], ho.reshape(-1, 3, 3))
     ref_off = oracle_mod.points_to_offsets(s["points"], s["origin"], float(s["res"]), s["shape"])
     np.testing.assert_array_equal(off[0], ref_off)
     h.close()
