@@ -50,6 +50,23 @@ def plan_calls(n, lanes, merge):
     return [n // L + (1 if i < n % L else 0) for i in range(L)]
 
 
+LANE_CORES, RANK_CORES = 0.27, 0.5  # measured: cores a lane's host thread takes, cores of a rank's main thread
+
+
+def lanes_that_fit(asked, world, quota):
+    """Lanes per rank that fit the CPUs the cgroup may use: world x (RANK_CORES + lanes x LANE_CORES) <= quota (None: no limit).
+    Returns (lanes, the decision in words)."""
+    if world <= 1 or quota is None:
+        return asked, f"{asked} lanes per rank as asked for"
+    fit = int((quota / world - RANK_CORES) / LANE_CORES + 1e-9)
+    if fit < asked:
+        lanes = max(1, fit)
+        return lanes, (f"{lanes} lanes per rank: cgroup CPU quota {quota} / {world} ranks = {quota / world:.2f} cores per rank < "
+                       f"{RANK_CORES} + {asked} lanes x {LANE_CORES} cores (measured per lane)")
+    return asked, (f"{asked} lanes per rank as asked for: {world} ranks x ({RANK_CORES} + {asked} x {LANE_CORES} measured cores per lane) = "
+                   f"{world * (RANK_CORES + asked * LANE_CORES):.1f} <= cgroup CPU quota {quota}")
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` outside torch.distributed.run: launch N ranks on this node (one per GPU) the way the
     driver does and hand their output through."""
@@ -327,19 +344,8 @@ def main(argv=None, emit=True):
     # N ranks x D lanes plus RANK_CORES for a rank's main thread must fit the CPUs this cgroup may use, or the lanes' naps
     # turn into scheduling delays on every rank.  (Round 5 cut to quota // ranks lanes -- one core per lane, four times
     # what a lane takes: 2 lanes per rank at quota 16 / 8 ranks, where 8 x (0.5 + 4 x 0.27) = 12.6 cores fit.)
-    LANE_CORES, RANK_CORES = 0.27, 0.5
     quota_ = cpu_quota()
-    lane_decision = f"{D} lanes per rank as asked for"
-    if world > 1 and quota_ is not None:
-        fit = int((quota_ / world - RANK_CORES) / LANE_CORES + 1e-9)
-        if fit < D:
-            D_new = max(1, fit)
-            lane_decision = (f"{D_new} lanes per rank: cgroup CPU quota {quota_} / {world} ranks = {quota_ / world:.2f} cores per rank < "
-                             f"{RANK_CORES} + {D} lanes x {LANE_CORES} cores (measured per lane)")
-            D = D_new
-        else:
-            lane_decision = (f"{D} lanes per rank as asked for: {world} ranks x ({RANK_CORES} + {D} x {LANE_CORES} measured cores per lane) = "
-                             f"{world * (RANK_CORES + D * LANE_CORES):.1f} <= cgroup CPU quota {quota_}")
+    D, lane_decision = lanes_that_fit(D, world, quota_)
     slots = int(os.environ.get("GTO_SLOTS", "512"))  # instances a solver call keeps in flight (gto_api.hip)
     mode = _capi.SolverHandle.MODE_ROUNDS
     kernel_name = "k_obstacle_gram"

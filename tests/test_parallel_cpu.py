@@ -293,3 +293,24 @@ def test_work_queue_single_process_without_a_group():
     assert idx.tolist() == list(range(6))
     np.testing.assert_array_equal(Q, Q0 + 1)
     np.testing.assert_array_equal(it, sid)
+
+
+def test_bench_lanes_per_rank_fit_the_cgroup_quota():
+    """bench.py, N > 1: a lane is a host thread of 0.27 cores (measured), a rank's main thread 0.5: four lanes at the 16 CPUs
+    the driver box's container showed for eight ranks (round 5 cut to quota // ranks = 2), fewer when the quota is smaller,
+    never none, and whatever was asked for without a quota or with one rank."""
+    import importlib.util
+    import pathlib
+    spec = importlib.util.spec_from_file_location("bench", pathlib.Path(__file__).resolve().parents[1] / "bench.py")
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench.lanes_that_fit(4, 8, 16.0)[0] == 4
+    assert bench.lanes_that_fit(4, 8, 12.0)[0] == 3
+    assert bench.lanes_that_fit(4, 8, 8.0)[0] == 1
+    assert bench.lanes_that_fit(4, 8, 2.0)[0] == 1
+    assert bench.lanes_that_fit(4, 8, None)[0] == 4 and bench.lanes_that_fit(4, 1, 1.0)[0] == 4
+    assert bench.lanes_that_fit(4, 2, 16.0)[0] == 4 and bench.lanes_that_fit(6, 4, 8.0)[0] == 5
+    for asked, world, quota in ((4, 8, 16.0), (4, 8, 9.0), (2, 4, 3.0)):
+        lanes, why = bench.lanes_that_fit(asked, world, quota)
+        assert 1 <= lanes <= asked and str(lanes) in why
+        assert lanes == 1 or world * (bench.RANK_CORES + lanes * bench.LANE_CORES) <= quota + 1e-9
